@@ -1,0 +1,185 @@
+"""Pin the CPU oracle against fixtures captured from the imported reference.
+
+The reference ships no tests; ``tests/golden/make_golden.py`` dumped
+these by running the reference itself in the build container.  CPU only.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from interactron_amd.synthetic import (hash_normal, hash_randint, hash_uniform, procedural_state_dict,
+                                       synthetic_episodes)
+from oracle import criterion as oc
+from oracle import detector as od
+from oracle import episode as oe
+from oracle import fusion as of
+from tests.helpers import check_grad, check_record
+
+CFG = dict(NUM_CLASSES=1235, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=2060, IMG_FEATURE_SIZE=256,
+           OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1, ATTENTION_PDROP=0.1,
+           ADAPTIVE_LR=1e-3)
+
+
+@pytest.fixture(scope="module")
+def det_sd():
+    return procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()})
+
+
+def strip(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items()}
+
+
+@pytest.fixture(scope="module")
+def det(det_sd):
+    return strip(det_sd, "detector.")
+
+
+def fusion_sd(style="gpt"):
+    shapes = {"fusion." + k: v for k, v in of.fusion_state_shapes(CFG, style).items()}
+    sd = strip(procedural_state_dict(shapes), "fusion.")
+    if style == "decoder":
+        sd["pos_embed"] = of.decoder_fusion_pos_embed()
+    return sd
+
+
+def test_g1_box_ops(golden):
+    g = golden("golden_small.pt")["g1"]
+    torch.testing.assert_close(oc.cxcywh_to_xyxy(g["pred"]), g["xyxy"], atol=0, rtol=0)
+    got = oc.pairwise_giou(oc.cxcywh_to_xyxy(g["pred"]), oc.cxcywh_to_xyxy(g["tgt"]))
+    torch.testing.assert_close(got, g["giou"], atol=1e-6, rtol=1e-6)
+
+
+def _g2_inputs():
+    logits = torch.from_numpy((hash_normal("g2/logits", 5 * 50 * 1236) * 2.0).astype(np.float32)).reshape(5, 50, 1236)
+    boxes = torch.from_numpy(np.concatenate([hash_uniform("g2/c", 500, 0.2, 0.8).reshape(250, 2),
+                                             hash_uniform("g2/wh", 500, 0.05, 0.5).reshape(250, 2)], 1)
+                             .astype(np.float32)).reshape(5, 50, 4)
+    return logits, boxes
+
+
+def test_g2_matcher(golden):
+    g = golden("golden_small.pt")["g2"]
+    logits, boxes = _g2_inputs()
+    got = oc.hungarian_match(logits, boxes, g["targets"])
+    for (a, b), (ra, rb) in zip(got, g["indices"]):
+        assert torch.equal(a, ra) and torch.equal(b, rb)
+
+
+def test_g3_criterion(golden):
+    G = golden("golden_small.pt")
+    logits, boxes = _g2_inputs()
+    lg, bx = logits.clone().requires_grad_(True), boxes.clone().requires_grad_(True)
+    losses = oc.set_criterion(lg, bx, G["g2"]["targets"], 1235, 0.1)
+    (losses["loss_ce"] + 5 * losses["loss_giou"] + 2 * losses["loss_bbox"]).backward()
+    assert list(losses) == list(G["g3"]["losses"])
+    for k, v in G["g3"]["losses"].items():
+        torch.testing.assert_close(losses[k].detach(), v, atol=1e-5, rtol=1e-5, msg=k)
+    check_record(G["g3"]["grad_logits"], lg.grad, atol=1e-8, rtol=1e-4)
+    torch.testing.assert_close(bx.grad, G["g3"]["grad_boxes"], atol=1e-7, rtol=1e-4)
+
+
+def test_g4_sine_position(golden):
+    g = golden("golden_small.pt")["g4"]
+    for hw in (19, 50):
+        check_record(g["zero_%d" % hw], od.sine_position(torch.zeros(1, hw, hw, dtype=torch.bool)), atol=1e-6)
+    m = torch.zeros(2, 19, 19, dtype=torch.bool)
+    m[0, 15:, :] = True
+    m[1, :, 12:] = True
+    check_record(g["padded_19"], od.sine_position(m), atol=1e-6)
+
+
+def test_g10_clipped_sgd(golden):
+    g = golden("golden_small.pt")["g10"]
+    p = [torch.from_numpy(hash_normal("g10/p%d" % i, n).astype(np.float32)) for i, n in enumerate((1000, 37, 4096))]
+    gr = [torch.from_numpy((hash_normal("g10/g%d" % i, n) * 12.0).astype(np.float32)) for i, n in enumerate((1000, 37, 4096))]
+    gr[1] = None
+    for a, b in zip(oe.clipped_sgd(p, gr, 1e-3), g["out"]):
+        assert torch.equal(a, b)
+
+
+def test_g14_path_storage(golden):
+    g = golden("golden_small.pt")["g14"]
+    trie = oe.PathTrie()
+    for (path, rew), want in zip(g["script"], g["labels"]):
+        trie.add_path(torch.tensor(path), rew)
+        assert trie.get_label(torch.tensor(path)) == want
+
+
+def test_theta_and_state_layout(golden):
+    M = golden("golden_model.pt")
+    shapes = od.detr_state_shapes()
+    assert list(shapes) == M["detector_state_keys"]
+    assert od.theta_names(shapes) == M["theta_names"]
+    assert len(M["theta_names"]) == 199
+    assert od.trainable_names(shapes) == M["detector_trainable"]
+    assert {k: tuple(v) for k, v in of.fusion_state_shapes(CFG, "gpt").items()} == \
+        {k: tuple(v) for k, v in M["fusion_state_keys"].items()}
+    assert list(of.fusion_state_shapes(CFG, "gpt")) == list(M["fusion_state_keys"])
+
+
+def test_g5_bottlenecks(golden, det):
+    M = golden("golden_model.pt")
+    x = torch.from_numpy(hash_normal("g5/x", 2 * 256 * 20 * 20).astype(np.float32)).reshape(2, 256, 20, 20).abs()
+    with torch.no_grad():
+        check_record(M["g5_layer2_0"], od.bottleneck(x, det, "backbone.0.body.layer2.0.", 2, 1), atol=1e-5)
+        x4 = torch.from_numpy(hash_normal("g5/x4", 2 * 1024 * 10 * 10).astype(np.float32)).reshape(2, 1024, 10, 10).abs()
+        y = od.bottleneck(x4, det, "backbone.0.body.layer4.0.", 1, 1)
+        check_record(M["g5_layer4_0"], y, atol=1e-5)
+        check_record(M["g5_layer4_1"], od.bottleneck(y, det, "backbone.0.body.layer4.1.", 1, 2), atol=1e-5)
+
+
+def test_g6_transformer_layers(golden, det):
+    M = golden("golden_model.pt")
+    src = torch.from_numpy(hash_normal("g6/src", 30 * 2 * 256).astype(np.float32)).reshape(30, 2, 256)
+    pos = torch.from_numpy(hash_normal("g6/pos", 30 * 2 * 256).astype(np.float32)).reshape(30, 2, 256)
+    kpm = torch.zeros(2, 30, dtype=torch.bool)
+    kpm[1, 25:] = True
+    with torch.no_grad():
+        enc = od.encoder_layer(src, pos, kpm, det, "transformer.encoder.layers.0.")
+        check_record(M["g6_enc"], enc, atol=2e-5)
+        tgt = torch.from_numpy(hash_normal("g6/tgt", 7 * 2 * 256).astype(np.float32)).reshape(7, 2, 256)
+        qp = torch.from_numpy(hash_normal("g6/qp", 7 * 2 * 256).astype(np.float32)).reshape(7, 2, 256)
+        dec = od.decoder_layer(tgt, enc, pos, qp, kpm, det, "transformer.decoder.layers.0.")
+        check_record(M["g6_dec"], dec, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def episode1():
+    return synthetic_episodes(1, tag="golden")
+
+
+@pytest.mark.slow
+def test_g7_g8_g9_detector_fusion_and_learned_grad(golden, det, episode1):
+    M = golden("golden_model.pt")
+    fus = fusion_sd("gpt")
+    names = od.theta_names()
+    d = dict(det)
+    for k in names:
+        d[k] = det[k].clone().requires_grad_(True)
+    out = od.detr_forward(d, episode1["frames"][0], episode1["masks"][0])
+    for k, rec in M["g7"].items():
+        check_record(rec, out[k], atol=2e-4, rtol=1e-3, what="g7/" + k)
+    pre = {k: (v.unsqueeze(0) if k != "image_features" else v) for k, v in out.items()}
+    fo = of.fusion_gpt_forward(fus, pre, CFG)
+    for k, rec in M["g8"].items():
+        check_record(rec, fo[k], atol=2e-4, rtol=1e-3, what="g8/" + k)
+    learned = torch.norm(fo["loss"])
+    assert abs(float(learned) - M["g9"]["learned_loss"]) < 1e-3 * abs(M["g9"]["learned_loss"]) + 1e-5
+    g = torch.autograd.grad(learned, [d[k] for k in names], allow_unused=True)
+    for k, gi in zip(names, g):
+        check_grad(M["g9"]["grads"][k], gi, rel=2e-3, what="g9/" + k)
+
+
+@pytest.mark.slow
+def test_g11_g12_predict_and_policy(golden, det, episode1):
+    M = golden("golden_model.pt")
+    fus = fusion_sd("gpt")
+    pred = oe.interactron_predict(det, fus, episode1, CFG)
+    for k, rec in M["g11"].items():
+        check_record(rec, pred[k], atol=2e-4, rtol=1e-3, what="g11/" + k)
+    for s in range(1, 5):
+        dd = {"frames": episode1["frames"][:, :s], "masks": episode1["masks"][:, :s]}
+        a, _ = oe.interactron_next_action(det, fus, dd, CFG)
+        assert a == M["g12"][s - 1]
