@@ -1,0 +1,127 @@
+/* C-ABI of libinteractron_hip.so -- the gfx950 (MI355X) kernel library behind the Interactron
+ * adaptive-detection hot path.
+ *
+ * The reference (allenai/interactron) has no native layer: every FLOP goes through ATen ops dispatched from
+ * Python.  This header is therefore the boundary SURVEY.md 8(b) defines: each entry point names the reference
+ * call site (path:line under the reference checkout) whose ATen/scipy work it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every pointer except the explicitly marked host arrays is a DEVICE pointer to f32
+ *     (or int64 / uint8 where stated) owned by the caller; the library never allocates or frees device memory;
+ *   - all work is enqueued on `stream` (pass torch.cuda.current_stream().cuda_stream); no internal syncs;
+ *   - return 0 on success, negative on error; ix_last_error() returns a thread-local message;
+ *   - re-entrant, no global mutable state.
+ */
+#ifndef INTERACTRON_HIP_H
+#define INTERACTRON_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ix_stream_t; /* == hipStream_t */
+
+int ix_version(void);
+const char* ix_last_error(void);
+
+/* ---- contractions ------------------------------------------------------------------------------------------
+ * C[b] (MxN, row-major, ldc) = alpha * A[b] (MxK) * B[b] (KxN) (+ bias[n]); b = bo*batch_inner + bi.
+ * a_kcontig: A(m,k)=A[m*lda+k] else A[k*lda+m]; b_kcontig: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+ * tile_hint in {0,64,128}, split_k_hint 0 = auto.  f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32).
+ * Replaces: nn.Linear / F.linear in models/detr_models/transformer.py:148-232, models/gpt.py:39-78,
+ * models/transformer.py:49-60, models/detr_models/detr.py:69-72,299-311; torch.bmm inside nn.MultiheadAttention
+ * and `q @ k.transpose` / `att @ v` in models/gpt.py:48-53; conv2d of torchvision resnet50 + input_proj
+ * (models/detr_models/backbone.py:88-90, detr.py:40,68) after ix_im2col_f32; and all their autograd derivatives. */
+int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int a_kcontig,
+                int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo,
+                int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, float alpha, int tile_hint,
+                int split_k_hint, ix_stream_t stream);
+
+/* ---- convolution gather / scatter (NHWC) -- torchvision resnet50 convs, backbone.py:88-90 ------------------- */
+int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,
+                  int64_t sxc, int KH, int KW, int stride, int pad, int dil, int Kp, ix_stream_t stream);
+int ix_col2im_f32(const float* cols, float* dx, int n, int H, int W, int C, int KH, int KW, int stride, int pad,
+                  int dil, int Kp, ix_stream_t stream);
+int ix_maxpool_nhwc_f32(const float* x, float* y, int n, int H, int W, int C, int k, int stride, int pad,
+                        ix_stream_t stream);
+int ix_nhwc_to_nchw_f32(const float* x, float* y, int n, int64_t HW, int C, ix_stream_t stream);
+
+/* ---- FrozenBatchNorm2d (backbone.py:44-54) ---------------------------------------------------------------- */
+int ix_bn_fold_f32(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* shift,
+                   int C, float eps, ix_stream_t stream);
+int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
+                          int64_t n, int C, int relu, ix_stream_t stream);
+
+/* ---- elementwise (transformer.py:148-232 residuals/ReLU/dropout, gpt.py:66-78 GELU, detr.py:72 sigmoid) ---- */
+int ix_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, ix_stream_t stream);
+int ix_mul_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
+int ix_scale_f32(const float* x, float* out, int64_t n, float alpha, ix_stream_t stream);
+int ix_scale_dev_f32(const float* x, const float* s, float* out, int64_t n, ix_stream_t stream);
+int ix_relu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
+int ix_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix_stream_t stream);
+int ix_gelu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
+int ix_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, ix_stream_t stream);
+int ix_gelu_bwd_bwd_f32(const float* G, const float* dy, const float* x, float* grad_dy, float* grad_x, int64_t n,
+                        ix_stream_t stream);
+int ix_sigmoid_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
+int ix_sigmoid_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix_stream_t stream);
+int ix_sigmoid_bwd_bwd_f32(const float* G, const float* dy, const float* y, float* grad_dy, float* grad_y, int64_t n,
+                           ix_stream_t stream);
+int ix_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
+int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, ix_stream_t stream);
+int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, ix_stream_t stream);
+int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, ix_stream_t stream);
+int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
+
+/* ---- wavefront-reduction kernels: softmax (transformer.py MHA, gpt.py:50) and LayerNorm --------------------- */
+int ix_softmax_fwd_f32(const float* x, float* y, int64_t rows, int len, int64_t ld, const uint8_t* mask,
+                       int rows_per_mask, int64_t mask_ld, ix_stream_t stream);
+int ix_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows, int len, int64_t ld,
+                       ix_stream_t stream);
+int ix_softmax_bwd_bwd_f32(const float* G, const float* y, const float* dy, float* grad_y, float* grad_dy,
+                           int64_t rows, int len, int64_t ld, ix_stream_t stream);
+int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                         int64_t rows, int D, float eps, ix_stream_t stream);
+int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                         float* dx, float* dgamma, float* dbeta, int64_t rows, int D, ix_stream_t stream);
+int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy, const float* x,
+                             const float* gamma, const float* mean, const float* rstd, float* grad_dy, float* grad_x,
+                             float* grad_gamma, int64_t rows, int D, ix_stream_t stream);
+
+/* ---- set criterion ---------------------------------------------------------------------------------------
+ * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the
+ * scipy.optimize.linear_sum_assignment call of matcher.py:76; weighted CE: detr.py:111-132; box losses:
+ * detr.py:148-167 with box_ops.py:8-58; sine position embedding: position_encoding.py:28-48; mask resize:
+ * backbone.py:77. */
+int ix_match_cost_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes,
+                      float* cost, int rows, int C, int T, float w_class, float w_bbox, float w_giou,
+                      ix_stream_t stream);
+int ix_lsap_f32(const float* cost_host, int64_t nr, int64_t nc, int64_t* row_idx_host, int64_t* col_idx_host);
+int ix_weighted_ce_fwd_f32(const float* logits, const int64_t* target, const float* weight, float* lse,
+                           int64_t* argmax, float* sums, int rows, int C, ix_stream_t stream);
+int ix_weighted_ce_bwd_f32(const float* logits, const int64_t* target, const float* weight, const float* lse,
+                           const float* sums, const float* gout, float* dlogits, int rows, int C, ix_stream_t stream);
+int ix_box_loss_fwd_f32(const float* pred, const int64_t* src_idx, const float* tgt, float* out, int K,
+                        ix_stream_t stream);
+int ix_box_loss_bwd_f32(const float* pred, const int64_t* src_idx, const float* tgt, const float* gout, float* dpred,
+                        int R, int K, ix_stream_t stream);
+int ix_sine_pos_f32(const uint8_t* mask, float* pos, int n, int h, int w, int num_pos_feats, float temperature,
+                    float scale, ix_stream_t stream);
+int ix_mask_nearest_u8(const uint8_t* in, uint8_t* out, int n, int H, int W, int h, int w, ix_stream_t stream);
+
+/* ---- MAML fast weights (utils/meta_utils.py:135-142) and outer step (engine/interactron_trainer.py:107-111) --
+ * p / g / out / G are HOST arrays of `ntensors` device pointers, sizes a HOST array of element counts. */
+int ix_sgd_clip_multi_f32(const float* const* p, const float* const* g, float* const* out, const int64_t* sizes,
+                          int ntensors, float lr, float clip, ix_stream_t stream);
+int ix_sgd_clip_bwd_multi_f32(const float* const* G, const float* const* g, float* const* out, const int64_t* sizes,
+                              int ntensors, float lr, float clip, ix_stream_t stream);
+int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, ix_stream_t stream);
+int ix_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     int step, const float* sumsq, float max_norm, int zero_grad, ix_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTERACTRON_HIP_H */

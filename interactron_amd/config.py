@@ -1,0 +1,55 @@
+"""YAML config objects and factories with the reference's keys (utils/config_utils.py:9-113).
+
+``Config`` applies the reference's coercion rule: every scalar goes through ``float()`` and becomes ``int`` when
+integral, otherwise it is left as is -- so ``"1e-3"`` -> 0.001, ``True`` -> 1 and non-numeric strings stay strings.
+"""
+import argparse
+import os
+
+import yaml
+
+
+class Config:
+    def __init__(self, **entries):
+        out = {}
+        for key, value in entries.items():
+            if type(value) is dict:
+                out[key] = Config(**value)
+                continue
+            try:
+                value = float(value)
+                if value.is_integer():
+                    value = int(value)
+            except (TypeError, ValueError):
+                pass
+            out[key] = value
+        self.__dict__.update(out)
+
+    def dictionarize(self):
+        return {k: (v.dictionarize() if isinstance(v, Config) else v) for k, v in self.__dict__.items()}
+
+
+def get_config(cfg):
+    assert os.path.exists(cfg), "File {} does not exist".format(cfg)
+    with open(cfg) as f:
+        return Config(**yaml.safe_load(f))
+
+
+def get_args():
+    parser = argparse.ArgumentParser(description="Train Interactron Model")
+    parser.add_argument("--config_file", type=str, required=True,
+                        help="path to the configuration file for this training run")
+    return parser.parse_args()
+
+
+MODEL_TYPES = ["detr", "detr_multiframe", "interactron_random", "interactron"]
+
+
+def arg_check(arg, choices, argname):
+    assert arg in choices, "{} is not a valid {}. Please select one from {}".format(arg, argname, choices)
+
+
+def build_model(args):
+    arg_check(args.TYPE, MODEL_TYPES, "model")
+    from . import episode
+    return getattr(episode, args.TYPE)(args)

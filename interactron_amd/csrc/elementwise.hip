@@ -1,0 +1,346 @@
+// HBM-bound elementwise / broadcast / column-reduction kernels of the Interactron hot path.
+// All are grid-stride, 16-byte vectorised when the pointers allow, and hold no state.
+//
+// reference sites: residual adds and ReLU/GELU/sigmoid/dropout in models/detr_models/transformer.py:148-232,
+// models/gpt.py:39-78, models/detr_models/detr.py:299-311; FrozenBatchNorm2d affine in
+// models/detr_models/backbone.py:44-54.  The *_bwd / *_bwd_bwd forms are what the MAML meta-gradient
+// (models/interactron.py:99-123, create_graph=True) differentiates through a second time.
+#include "common.h"
+
+#define EW_BLOCK 256
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- generic unary / binary / ternary map with float4 bulk + scalar tail ------------------------------------
+template <typename F>
+__global__ void map1_kernel(const float* __restrict__ a, float* __restrict__ o, int64_t n, bool vec, F f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t k = i; k < n4; k += stride) {
+            float4 x = reinterpret_cast<const float4*>(a)[k];
+            float4 y = make_float4(f(x.x), f(x.y), f(x.z), f(x.w));
+            reinterpret_cast<float4*>(o)[k] = y;
+        }
+        for (int64_t k = (n4 << 2) + i; k < n; k += stride) o[k] = f(a[k]);
+    } else {
+        for (int64_t k = i; k < n; k += stride) o[k] = f(a[k]);
+    }
+}
+
+template <typename F>
+__global__ void map2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n,
+                            bool vec, F f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t k = i; k < n4; k += stride) {
+            float4 x = reinterpret_cast<const float4*>(a)[k];
+            float4 y = reinterpret_cast<const float4*>(b)[k];
+            reinterpret_cast<float4*>(o)[k] = make_float4(f(x.x, y.x), f(x.y, y.y), f(x.z, y.z), f(x.w, y.w));
+        }
+        for (int64_t k = (n4 << 2) + i; k < n; k += stride) o[k] = f(a[k], b[k]);
+    } else {
+        for (int64_t k = i; k < n; k += stride) o[k] = f(a[k], b[k]);
+    }
+}
+
+// two outputs from three inputs (the *_bwd_bwd kernels)
+template <typename F>
+__global__ void map3x2_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                              float* __restrict__ o0, float* __restrict__ o1, int64_t n, F f) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
+        float r0, r1;
+        f(a[k], b[k], c[k], r0, r1);
+        o0[k] = r0;
+        o1[k] = r1;
+    }
+}
+
+#define LAUNCH1(name, a, o, n, stream, ...)                                                                  \
+    do {                                                                                                     \
+        if ((n) <= 0) return IX_OK;                                                                          \
+        IX_CHECK_ARG((a) && (o), name ": null pointer");                                                     \
+        const bool vec__ = al16(a) && al16(o);                                                               \
+        hipLaunchKernelGGL(map1_kernel, dim3(ix_grid_1d(((n) + 3) / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, \
+                           a, o, (int64_t)(n), vec__, __VA_ARGS__);                                          \
+        IX_CHECK_LAUNCH(name);                                                                               \
+        return IX_OK;                                                                                        \
+    } while (0)
+
+#define LAUNCH2(name, a, b, o, n, stream, ...)                                                               \
+    do {                                                                                                     \
+        if ((n) <= 0) return IX_OK;                                                                          \
+        IX_CHECK_ARG((a) && (b) && (o), name ": null pointer");                                              \
+        const bool vec__ = al16(a) && al16(b) && al16(o);                                                    \
+        hipLaunchKernelGGL(map2_kernel, dim3(ix_grid_1d(((n) + 3) / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, \
+                           a, b, o, (int64_t)(n), vec__, __VA_ARGS__);                                       \
+        IX_CHECK_LAUNCH(name);                                                                               \
+        return IX_OK;                                                                                        \
+    } while (0)
+
+// out = alpha*a + beta*b
+extern "C" int ix_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha, float beta,
+                            hipStream_t stream) {
+    LAUNCH2("ix_axpby_f32", a, b, out, n, stream, [=] __device__(float x, float y) { return alpha * x + beta * y; });
+}
+
+extern "C" int ix_mul_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
+    LAUNCH2("ix_mul_f32", a, b, out, n, stream, [] __device__(float x, float y) { return x * y; });
+}
+
+extern "C" int ix_scale_f32(const float* x, float* out, int64_t n, float alpha, hipStream_t stream) {
+    LAUNCH1("ix_scale_f32", x, out, n, stream, [=] __device__(float v) { return alpha * v; });
+}
+
+// out = x * s[0], s a device scalar (keeps scalar second-order terms on the device)
+extern "C" int ix_scale_dev_f32(const float* x, const float* s, float* out, int64_t n, hipStream_t stream) {
+    IX_CHECK_ARG(s, "ix_scale_dev_f32: null scalar");
+    LAUNCH1("ix_scale_dev_f32", x, out, n, stream, [=] __device__(float v) { return v * s[0]; });
+}
+
+extern "C" int ix_relu_f32(const float* x, float* out, int64_t n, hipStream_t stream) {
+    LAUNCH1("ix_relu_f32", x, out, n, stream, [] __device__(float v) { return v > 0.f ? v : 0.f; });
+}
+
+// dx = dy * [y > 0]   (y = relu output; linear in dy, so it is its own second-order form)
+extern "C" int ix_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, hipStream_t stream) {
+    LAUNCH2("ix_relu_bwd_f32", dy, y, dx, n, stream, [] __device__(float g, float v) { return v > 0.f ? g : 0.f; });
+}
+
+__device__ __forceinline__ float gelu_cdf(float x) { return 0.5f * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_pdf(float x) { return 0.39894228040143267794f * __expf(-0.5f * x * x); }
+
+// exact (erf) GELU, as nn.GELU() in reference models/gpt.py:68
+extern "C" int ix_gelu_f32(const float* x, float* out, int64_t n, hipStream_t stream) {
+    LAUNCH1("ix_gelu_f32", x, out, n, stream, [] __device__(float v) { return v * gelu_cdf(v); });
+}
+
+extern "C" int ix_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, hipStream_t stream) {
+    LAUNCH2("ix_gelu_bwd_f32", dy, x, dx, n, stream,
+            [] __device__(float g, float v) { return g * (gelu_cdf(v) + v * gelu_pdf(v)); });
+}
+
+// given G = dL/d(dx) of the gelu_bwd node: grad_dy = G * gelu'(x), grad_x = G * dy * gelu''(x),
+// gelu''(x) = pdf(x) * (2 - x^2)
+extern "C" int ix_gelu_bwd_bwd_f32(const float* G, const float* dy, const float* x, float* grad_dy, float* grad_x,
+                                   int64_t n, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(G && dy && x && grad_dy && grad_x, "ix_gelu_bwd_bwd_f32: null pointer");
+    hipLaunchKernelGGL(map3x2_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, G, dy, x, grad_dy,
+                       grad_x, n, [] __device__(float g, float d, float v, float& r0, float& r1) {
+                           const float pdf = gelu_pdf(v);
+                           r0 = g * (gelu_cdf(v) + v * pdf);
+                           r1 = g * d * pdf * (2.f - v * v);
+                       });
+    IX_CHECK_LAUNCH("ix_gelu_bwd_bwd_f32");
+    return IX_OK;
+}
+
+extern "C" int ix_sigmoid_f32(const float* x, float* out, int64_t n, hipStream_t stream) {
+    LAUNCH1("ix_sigmoid_f32", x, out, n, stream, [] __device__(float v) { return 1.f / (1.f + __expf(-v)); });
+}
+
+extern "C" int ix_sigmoid_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, hipStream_t stream) {
+    LAUNCH2("ix_sigmoid_bwd_f32", dy, y, dx, n, stream, [] __device__(float g, float v) { return g * v * (1.f - v); });
+}
+
+// G = dL/d(dx): grad_dy = G*y*(1-y), grad_y = G*dy*(1-2y)
+extern "C" int ix_sigmoid_bwd_bwd_f32(const float* G, const float* dy, const float* y, float* grad_dy, float* grad_y,
+                                      int64_t n, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(G && dy && y && grad_dy && grad_y, "ix_sigmoid_bwd_bwd_f32: null pointer");
+    hipLaunchKernelGGL(map3x2_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, G, dy, y, grad_dy,
+                       grad_y, n, [] __device__(float g, float d, float v, float& r0, float& r1) {
+                           r0 = g * v * (1.f - v);
+                           r1 = g * d * (1.f - 2.f * v);
+                       });
+    IX_CHECK_LAUNCH("ix_sigmoid_bwd_bwd_f32");
+    return IX_OK;
+}
+
+// ---- dropout: counter-hash mask regenerated from (seed, element index), so backward needs no stored mask ----
+__device__ __forceinline__ uint32_t mix32(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, uint32_t thresh,
+                               float scale, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
+        const uint32_t r = mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull));
+        o[k] = r >= thresh ? x[k] * scale : 0.f;
+    }
+}
+
+// out = x * keep / (1-p); the same (seed) applied to a gradient is the exact adjoint (the op is linear).
+extern "C" int ix_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && out, "ix_dropout_f32: null pointer");
+    IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_dropout_f32: p=%f outside [0,1)", p);
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(dropout_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, out, n, thresh,
+                       1.f / (1.f - p), seed);
+    IX_CHECK_LAUNCH("ix_dropout_f32");
+    return IX_OK;
+}
+
+// ---- row-vector broadcast and column reductions ----------------------------------------------------------
+__global__ void add_rowvec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ o,
+                                  int64_t n, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) o[k] = a[k] + v[k % C];
+}
+
+// out[r, c] = a[r, c] + v[c]   (a may be null: pure broadcast of v over R rows)
+extern "C" int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, hipStream_t stream) {
+    const int64_t n = rows * C;
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(a && v && out, "ix_add_rowvec_f32: null pointer");
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, a, v, out, n, C);
+    IX_CHECK_LAUNCH("ix_add_rowvec_f32");
+    return IX_OK;
+}
+
+__global__ void bcast_rows_kernel(const float* __restrict__ v, float* __restrict__ o, int64_t n, int C) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) o[k] = v[k % C];
+}
+
+// out[r, c] = v[c]  -- the adjoint of ix_colsum_f32
+extern "C" int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, hipStream_t stream) {
+    const int64_t n = rows * C;
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(v && out, "ix_bcast_rows_f32: null pointer");
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, v, out, n, C);
+    IX_CHECK_LAUNCH("ix_bcast_rows_f32");
+    return IX_OK;
+}
+
+// Each block owns a band of rows and a 256-wide band of columns; lanes walk down rows (coalesced across columns),
+// then one atomic per column per block.
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C,
+                              int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
+    unsafeAtomicAdd(&out[c], s);
+}
+
+// out[c] = sum_r x[r, c]
+extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, hipStream_t stream) {
+    IX_CHECK_ARG(out && C >= 0, "ix_colsum_f32: bad args");
+    if (C == 0) return IX_OK;
+    hipMemsetAsync(out, 0, sizeof(float) * C, stream);
+    if (rows <= 0) return IX_OK;
+    IX_CHECK_ARG(x, "ix_colsum_f32: null input");
+    int rpb = 64;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    dim3 grid(ix_div_up(C, 256), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
+    IX_CHECK_LAUNCH("ix_colsum_f32");
+    return IX_OK;
+}
+
+__global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) s += a[k] * b[k];
+    s = ix_block_sum_256(s, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+// out[0] = sum_i a[i]*b[i]
+extern "C" int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
+    IX_CHECK_ARG(out, "ix_dot_f32: null output");
+    hipMemsetAsync(out, 0, sizeof(float), stream);
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(a && b, "ix_dot_f32: null input");
+    int g = ix_grid_1d(n, 256);
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, stream, a, b, out, n);
+    IX_CHECK_LAUNCH("ix_dot_f32");
+    return IX_OK;
+}
+
+// ---- FrozenBatchNorm2d folded into a per-channel affine, NHWC (channel = fastest dim) ------------------------
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                               float* shift, int C, float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = w[c] * rsqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = b[c] - rm[c] * s;
+}
+
+// scale = w * rsqrt(var + eps), shift = b - mean * scale   (reference backbone.py:44-54)
+extern "C" int ix_bn_fold_f32(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                              float* shift, int C, float eps, hipStream_t stream) {
+    if (C <= 0) return IX_OK;
+    IX_CHECK_ARG(w && b && rm && rv && scale && shift, "ix_bn_fold_f32: null pointer");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ix_div_up(C, 256)), dim3(256), 0, stream, w, b, rm, rv, scale, shift, C,
+                       eps);
+    IX_CHECK_LAUNCH("ix_bn_fold_f32");
+    return IX_OK;
+}
+
+template <bool RELU, bool RES, bool SHIFT>
+__global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, const float* __restrict__ res,
+                                      float* __restrict__ o, int64_t n4, int C4) {
+    // C % 4 == 0: each thread owns one float4 = 4 consecutive channels
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n4; k += stride) {
+        const int c4 = (int)(k % C4);
+        float4 v = reinterpret_cast<const float4*>(x)[k];
+        const float4 s = reinterpret_cast<const float4*>(scale)[c4];
+        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        if (SHIFT) {
+            const float4 t = reinterpret_cast<const float4*>(shift)[c4];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (RES) {
+            const float4 r = reinterpret_cast<const float4*>(res)[k];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (RELU) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4*>(o)[k] = v;
+    }
+}
+
+// out = [relu]( x*scale[c] (+ shift[c]) (+ residual) ), x NHWC with C % 4 == 0.  shift / residual may be null.
+extern "C" int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual,
+                                     float* out, int64_t n, int C, int relu, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && scale && out, "ix_channel_affine_f32: null pointer");
+    IX_CHECK_ARG(C % 4 == 0 && n % C == 0, "ix_channel_affine_f32: need C %% 4 == 0 and n %% C == 0 (C=%d)", C);
+    IX_CHECK_ARG(al16(x) && al16(out) && al16(scale) && (!shift || al16(shift)) && (!residual || al16(residual)),
+                 "ix_channel_affine_f32: pointers must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    dim3 g(ix_grid_1d(n4, EW_BLOCK)), b(EW_BLOCK);
+#define CA(R, S, H) hipLaunchKernelGGL((channel_affine_kernel<R, S, H>), g, b, 0, stream, x, scale, shift, residual, out, n4, C / 4)
+    const bool has_shift = shift != nullptr;
+    if (relu) {
+        if (residual) { if (has_shift) CA(true, true, true); else CA(true, true, false); }
+        else { if (has_shift) CA(true, false, true); else CA(true, false, false); }
+    } else {
+        if (residual) { if (has_shift) CA(false, true, true); else CA(false, true, false); }
+        else { if (has_shift) CA(false, false, true); else CA(false, false, false); }
+    }
+#undef CA
+    IX_CHECK_LAUNCH("ix_channel_affine_f32");
+    return IX_OK;
+}

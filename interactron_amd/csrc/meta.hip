@@ -1,0 +1,138 @@
+// MAML fast-weight update and the outer optimiser step as fused multi-tensor / flat-buffer kernels.
+//   fast = theta - clamp(lr * g, -clip, +clip)            reference utils/meta_utils.py:135-142
+//   clip_grad_norm_ + Adam                                reference engine/interactron_trainer.py:107-111
+// The 199 adapted tensors are updated by a handful of launches (pointer tables travel in the kernel-argument
+// segment), so the adapt loop never round-trips to the host.
+#include "common.h"
+
+#define MT_MAX 48  // tensors per launch: 48 * (3 ptr + size + block offset) stays well inside the 4 KB kernarg limit
+#define MT_CHUNK 4096  // elements per block
+
+struct MultiArgs {
+    const float* a[MT_MAX];
+    const float* b[MT_MAX];
+    float* o[MT_MAX];
+    int64_t n[MT_MAX];
+    int block_start[MT_MAX + 1];
+    int count;
+};
+
+template <typename F>
+__global__ __launch_bounds__(256) void multi_map2_kernel(MultiArgs m, F f) {
+    // locate the tensor this block belongs to (count <= 48: linear scan in SGPRs)
+    int t = 0;
+    while (t + 1 < m.count && (int)blockIdx.x >= m.block_start[t + 1]) ++t;
+    const int64_t base = (int64_t)(blockIdx.x - m.block_start[t]) * MT_CHUNK;
+    const int64_t end = base + MT_CHUNK < m.n[t] ? base + MT_CHUNK : m.n[t];
+    const float* a = m.a[t];
+    const float* b = m.b[t];
+    float* o = m.o[t];
+    for (int64_t k = base + threadIdx.x; k < end; k += 256) o[k] = f(a[k], b[k]);
+}
+
+template <typename F>
+static int launch_multi(const char* name, const float* const* a, const float* const* b, float* const* o,
+                        const int64_t* sizes, int ntensors, hipStream_t stream, F f) {
+    IX_CHECK_ARG(ntensors >= 0 && (ntensors == 0 || (a && b && o && sizes)), "%s: bad args", name);
+    int i = 0;
+    while (i < ntensors) {
+        MultiArgs m;
+        int cnt = 0, blocks = 0;
+        while (i < ntensors && cnt < MT_MAX) {
+            if (sizes[i] > 0) {
+                IX_CHECK_ARG(a[i] && b[i] && o[i], "%s: null tensor %d", name, i);
+                m.a[cnt] = a[i]; m.b[cnt] = b[i]; m.o[cnt] = o[i]; m.n[cnt] = sizes[i];
+                m.block_start[cnt] = blocks;
+                blocks += (int)((sizes[i] + MT_CHUNK - 1) / MT_CHUNK);
+                ++cnt;
+            }
+            ++i;
+        }
+        if (cnt == 0) break;
+        m.block_start[cnt] = blocks;
+        m.count = cnt;
+        hipLaunchKernelGGL(multi_map2_kernel, dim3(blocks), dim3(256), 0, stream, m, f);
+        IX_CHECK_LAUNCH(name);
+    }
+    return IX_OK;
+}
+
+// out_i = p_i - clamp(lr*g_i, -clip, clip) for every tensor i (host arrays of device pointers)
+extern "C" int ix_sgd_clip_multi_f32(const float* const* p, const float* const* g, float* const* out,
+                                     const int64_t* sizes, int ntensors, float lr, float clip, hipStream_t stream) {
+    return launch_multi("ix_sgd_clip_multi_f32", p, g, out, sizes, ntensors, stream,
+                        [=] __device__(float pv, float gv) { return pv - fminf(fmaxf(lr * gv, -clip), clip); });
+}
+
+// Adjoint w.r.t. g of the update above: out_i = -lr * G_i * [ |lr*g_i| <= clip ]   (torch.clip passes the gradient
+// on the closed interval)
+extern "C" int ix_sgd_clip_bwd_multi_f32(const float* const* G, const float* const* g, float* const* out,
+                                         const int64_t* sizes, int ntensors, float lr, float clip,
+                                         hipStream_t stream) {
+    return launch_multi("ix_sgd_clip_bwd_multi_f32", G, g, out, sizes, ntensors, stream, [=] __device__(float Gv, float gv) {
+        const float s = lr * gv;
+        return (s >= -clip && s <= clip) ? -lr * Gv : 0.f;
+    });
+}
+
+// ---- flat-buffer outer step ------------------------------------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n >> 2;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n4; k += gs) {
+        const float4 v = reinterpret_cast<const float4*>(x)[k];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t k = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) s += x[k] * x[k];
+    s = ix_block_sum_256(s, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+}
+
+// out[0] += sum x^2   (caller zeroes out; lets several buffers accumulate into one total norm)
+extern "C" int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && out && ((uintptr_t)x & 15) == 0, "ix_sumsq_accum_f32: bad args (x must be 16-byte aligned)");
+    int g = ix_grid_1d((n + 3) / 4, 256);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, stream, x, n, out);
+    IX_CHECK_LAUNCH("ix_sumsq_accum_f32");
+    return IX_OK;
+}
+
+// Adam with the clip_grad_norm_ coefficient folded in: c = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)), g' = c*g
+// (torch.nn.utils.clip_grad_norm_ + torch.optim.Adam, no weight decay, no amsgrad).  Grad buffer is left untouched
+// except when zero_grad != 0 (then it is cleared for the next accumulation).
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2,
+                            const float* __restrict__ sumsq, float max_norm, int zero_grad) {
+    float c = 1.f;
+    if (sumsq) {
+        const float cc = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+        c = cc < 1.f ? cc : 1.f;
+    }
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) {
+        const float gg = g[k] * c;
+        const float mm = b1 * m[k] + (1.f - b1) * gg;
+        const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+        m[k] = mm;
+        v[k] = vv;
+        const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
+        p[k] -= (lr / bc1) * (mm / denom);
+        if (zero_grad) g[k] = 0.f;
+    }
+}
+
+extern "C" int ix_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, int step, const float* sumsq, float max_norm, int zero_grad,
+                                hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(p && g && m && v && step >= 1, "ix_adam_step_f32: bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ix_grid_1d(n, 256)), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, bc1, bc2, sumsq, max_norm, zero_grad);
+    IX_CHECK_LAUNCH("ix_adam_step_f32");
+    return IX_OK;
+}

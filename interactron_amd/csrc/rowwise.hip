@@ -1,0 +1,406 @@
+// Wavefront-reduction kernels: row softmax and LayerNorm with their first- and second-order backward forms.
+// One 64-lane wave owns one row; lane l touches elements l, l+64, ... (coalesced), the row lives in registers
+// between the reduction and the write so every operand is read from HBM exactly once.
+//
+// reference sites: softmax inside nn.MultiheadAttention (models/detr_models/transformer.py:153,216,219) and the
+// explicit softmax of models/gpt.py:48-52; nn.LayerNorm in transformer.py:139-140,199-201 and gpt.py:64-65,98.
+// The bwd_bwd kernels are the analytic double-backward that autograd's SoftmaxBackwardDataBackward0 /
+// NativeLayerNormBackwardBackward0 nodes compute for the MAML meta-gradient (models/interactron.py:99-123).
+#include "common.h"
+
+#define ROWS_PER_BLOCK 4  // 256 threads = 4 waves = 4 rows
+
+// ------------------------------------------------------------------------------------------------------------
+// softmax
+// ------------------------------------------------------------------------------------------------------------
+template <int NREG>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int64_t rows, int len, int64_t ld,
+                                                          const uint8_t* __restrict__ mask, int rows_per_mask,
+                                                          int64_t mask_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float* yr = y + row * ld;
+    const uint8_t* mr = mask ? mask + (row / rows_per_mask) * mask_ld : nullptr;
+    float v[NREG];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        float t = -INFINITY;
+        if (c < len) {
+            t = xr[c];
+            if (mr && mr[c]) t = -INFINITY;
+        }
+        v[i] = t;
+        mx = fmaxf(mx, t);
+    }
+    mx = ix_wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        v[i] = __expf(v[i] - mx);  // exp(-inf) = 0 for padded / masked slots
+        s += v[i];
+    }
+    s = ix_wave_sum(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < len) yr[c] = v[i] * inv;
+    }
+}
+
+// streaming fallback for rows longer than the register-resident variants (three passes over L2-resident data)
+__global__ __launch_bounds__(256) void softmax_fwd_stream_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 int64_t rows, int len, int64_t ld,
+                                                                 const uint8_t* __restrict__ mask, int rows_per_mask,
+                                                                 int64_t mask_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;
+    float* yr = y + row * ld;
+    const uint8_t* mr = mask ? mask + (row / rows_per_mask) * mask_ld : nullptr;
+    float mx = -INFINITY;
+    for (int c = lane; c < len; c += 64) {
+        const float t = (mr && mr[c]) ? -INFINITY : xr[c];
+        mx = fmaxf(mx, t);
+    }
+    mx = ix_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) {
+        const float t = (mr && mr[c]) ? -INFINITY : xr[c];
+        s += __expf(t - mx);
+    }
+    s = ix_wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < len; c += 64) {
+        const float t = (mr && mr[c]) ? -INFINITY : xr[c];
+        yr[c] = __expf(t - mx) * inv;
+    }
+}
+
+// y = softmax(x + (-inf where mask)) along the last dim. x, y: [rows, len] with row pitch ld.
+// mask (optional): uint8 [n_mask_rows, mask_ld], row r uses mask row r / rows_per_mask (key-padding mask per frame).
+extern "C" int ix_softmax_fwd_f32(const float* x, float* y, int64_t rows, int len, int64_t ld, const uint8_t* mask,
+                                  int rows_per_mask, int64_t mask_ld, hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(x && y && ld >= len, "ix_softmax_fwd_f32: bad args");
+    IX_CHECK_ARG(!mask || rows_per_mask > 0, "ix_softmax_fwd_f32: rows_per_mask must be > 0 with a mask");
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define SM(N) hipLaunchKernelGGL(softmax_fwd_kernel<N>, grid, block, 0, stream, x, y, rows, len, ld, mask, rows_per_mask, mask_ld)
+    if (len <= 64) SM(1);
+    else if (len <= 256) SM(4);
+    else if (len <= 512) SM(8);
+    else if (len <= 1024) SM(16);
+    else if (len <= 2304) SM(36);
+    else hipLaunchKernelGGL(softmax_fwd_stream_kernel, grid, block, 0, stream, x, y, rows, len, ld, mask, rows_per_mask, mask_ld);
+#undef SM
+    IX_CHECK_LAUNCH("ix_softmax_fwd_f32");
+    return IX_OK;
+}
+
+// dx = y * (dy - sum(y*dy))
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int64_t rows, int len, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* yr = y + row * ld;
+    const float* gr = dy + row * ld;
+    float* o = dx + row * ld;
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) s += yr[c] * gr[c];
+    s = ix_wave_sum(s);
+    for (int c = lane; c < len; c += 64) o[c] = yr[c] * (gr[c] - s);
+}
+
+extern "C" int ix_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows, int len, int64_t ld,
+                                  hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(y && dy && dx && ld >= len, "ix_softmax_bwd_f32: bad args");
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    hipLaunchKernelGGL(softmax_bwd_kernel, grid, dim3(256), 0, stream, y, dy, dx, rows, len, ld);
+    IX_CHECK_LAUNCH("ix_softmax_bwd_f32");
+    return IX_OK;
+}
+
+// Node: dx = y*(dy - s), s = sum(y*dy).  Given G = dL/d(dx):
+//   grad_dy = y*(G - t),            t = sum(G*y)
+//   grad_y  = G*(dy - s) - dy*t
+__global__ __launch_bounds__(256) void softmax_bwd_bwd_kernel(const float* __restrict__ G, const float* __restrict__ y,
+                                                              const float* __restrict__ dy, float* __restrict__ grad_y,
+                                                              float* __restrict__ grad_dy, int64_t rows, int len,
+                                                              int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    float s = 0.f, t = 0.f;
+    for (int c = lane; c < len; c += 64) {
+        const float yy = y[off + c];
+        s += yy * dy[off + c];
+        t += yy * G[off + c];
+    }
+    s = ix_wave_sum(s);
+    t = ix_wave_sum(t);
+    for (int c = lane; c < len; c += 64) {
+        const float yy = y[off + c], g = G[off + c], d = dy[off + c];
+        grad_dy[off + c] = yy * (g - t);
+        grad_y[off + c] = g * (d - s) - d * t;
+    }
+}
+
+extern "C" int ix_softmax_bwd_bwd_f32(const float* G, const float* y, const float* dy, float* grad_y, float* grad_dy,
+                                      int64_t rows, int len, int64_t ld, hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(G && y && dy && grad_y && grad_dy && ld >= len, "ix_softmax_bwd_bwd_f32: bad args");
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    hipLaunchKernelGGL(softmax_bwd_bwd_kernel, grid, dim3(256), 0, stream, G, y, dy, grad_y, grad_dy, rows, len, ld);
+    IX_CHECK_LAUNCH("ix_softmax_bwd_bwd_f32");
+    return IX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim D (D <= 64*NREG), eps inside the sqrt, biased variance (torch semantics)
+// ------------------------------------------------------------------------------------------------------------
+template <int NREG>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                     int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    float v[NREG];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mu = ix_wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < D ? v[i] - mu : 0.f;
+        q += d * d;
+    }
+    const float r = rsqrtf(ix_wave_sum(q) / D + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = r;
+    }
+    float* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) yr[c] = (v[i] - mu) * r * gamma[c] + beta[c];
+    }
+}
+
+extern "C" int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                    float* rstd, int64_t rows, int D, float eps, hipStream_t stream) {
+    if (rows <= 0) return IX_OK;
+    IX_CHECK_ARG(x && gamma && beta && y && mean && rstd, "ix_layernorm_fwd_f32: null pointer");
+    IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_fwd_f32: D=%d unsupported (1..1024)", D);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define LN(N) hipLaunchKernelGGL(ln_fwd_kernel<N>, grid, block, 0, stream, x, gamma, beta, y, mean, rstd, rows, D, eps)
+    if (D <= 256) LN(4);
+    else if (D <= 512) LN(8);
+    else LN(16);
+#undef LN
+    IX_CHECK_LAUNCH("ix_layernorm_fwd_f32");
+    return IX_OK;
+}
+
+// Backward.  g = dy*gamma; dx = r*(g - mean(g) - xhat*mean(g*xhat)); dgamma += dy*xhat; dbeta += dy
+// Column reductions: per-block LDS partials over its 4 rows x many row-groups, then one atomic per column.
+template <int NREG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int64_t rows, int D, int row_groups) {
+    __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
+    __shared__ float sb[ROWS_PER_BLOCK][64 * NREG];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[NREG], ab[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) ag[i] = ab[i] = 0.f;
+    for (int g = 0; g < row_groups; ++g) {
+        const int64_t row = ((int64_t)blockIdx.x * row_groups + g) * ROWS_PER_BLOCK + w;
+        if (row >= rows) break;
+        const float mu = mean[row], r = rstd[row];
+        const float* xr = x + row * D;
+        const float* gr = dy + row * D;
+        float xh[NREG], gg[NREG];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float d = gr[c];
+                xh[i] = (xr[c] - mu) * r;
+                gg[i] = d * gamma[c];
+                ag[i] += d * xh[i];
+                ab[i] += d;
+            } else {
+                xh[i] = gg[i] = 0.f;
+            }
+            a += gg[i];
+            b += gg[i] * xh[i];
+        }
+        a = ix_wave_sum(a) / D;
+        b = ix_wave_sum(b) / D;
+        float* o = dx + row * D;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) o[c] = r * (gg[i] - a - xh[i] * b);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        sg[w][lane + 64 * i] = ag[i];
+        sb[w][lane + 64 * i] = ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        unsafeAtomicAdd(&dgamma[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+        unsafeAtomicAdd(&dbeta[c], sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    }
+}
+
+extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
+                                    const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
+                                    hipStream_t stream) {
+    IX_CHECK_ARG(dgamma && dbeta, "ix_layernorm_bwd_f32: null dgamma/dbeta");
+    IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_f32: D=%d unsupported (1..1024)", D);
+    hipMemsetAsync(dgamma, 0, sizeof(float) * D, stream);
+    hipMemsetAsync(dbeta, 0, sizeof(float) * D, stream);
+    if (rows <= 0) return IX_OK;
+    IX_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ix_layernorm_bwd_f32: null pointer");
+    const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups))), block(256);
+#define LNB(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups)
+    if (D <= 256) LNB(4);
+    else if (D <= 512) LNB(8);
+    else LNB(16);
+#undef LNB
+    IX_CHECK_LAUNCH("ix_layernorm_bwd_f32");
+    return IX_OK;
+}
+
+// Double backward of the node (dy, x, gamma) -> (dx, dgamma, dbeta).  Upstream grads: Gx [rows,D] (for dx),
+// Gg [D] (for dgamma), Gb [D] (for dbeta); any may be null (= zero).  With m(.) the feature mean, per row:
+//   g = dy*gamma, a = m(g), b = m(g*xh), dx = r*(g - a - xh*b), P(v) = r*(v - m(v) - xh*m(v*xh))
+//   grad_dy    = P(Gx)*gamma + Gg*xh + Gb
+//   grad_gamma = sum_rows P(Gx)*dy
+//   Xh         = -r*b*Gx - r*g*m(Gx*xh) + Gg*dy
+//   grad_x     = P(Xh) - r*xh*m(Gx*dx)
+template <int NREG>
+__global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict__ Gx, const float* __restrict__ Gg,
+                                                         const float* __restrict__ Gb, const float* __restrict__ dy,
+                                                         const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ grad_dy,
+                                                         float* __restrict__ grad_x, float* __restrict__ grad_gamma,
+                                                         int64_t rows, int D, int row_groups) {
+    __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float ag[NREG];
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) ag[i] = 0.f;
+    for (int grp = 0; grp < row_groups; ++grp) {
+        const int64_t row = ((int64_t)blockIdx.x * row_groups + grp) * ROWS_PER_BLOCK + w;
+        if (row >= rows) break;
+        const float mu = mean[row], r = rstd[row];
+        const int64_t off = row * D;
+        float xh[NREG], g[NREG], gx[NREG], d[NREG];
+        float a = 0.f, b = 0.f, mgx = 0.f, mgxxh = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                d[i] = dy[off + c];
+                xh[i] = (x[off + c] - mu) * r;
+                g[i] = d[i] * gamma[c];
+                gx[i] = Gx ? Gx[off + c] : 0.f;
+            } else {
+                d[i] = xh[i] = g[i] = gx[i] = 0.f;
+            }
+            a += g[i];
+            b += g[i] * xh[i];
+            mgx += gx[i];
+            mgxxh += gx[i] * xh[i];
+        }
+        a = ix_wave_sum(a) / D;
+        b = ix_wave_sum(b) / D;
+        mgx = ix_wave_sum(mgx) / D;
+        mgxxh = ix_wave_sum(mgxxh) / D;
+        // second round of row statistics: m(Gx*dx), m(Xh), m(Xh*xh)
+        float Xh[NREG];
+        float mgxdx = 0.f, mX = 0.f, mXxh = 0.f;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float dxv = r * (g[i] - a - xh[i] * b);
+                const float gg = Gg ? Gg[c] : 0.f;
+                Xh[i] = -r * b * gx[i] - r * g[i] * mgxxh + gg * d[i];
+                mgxdx += gx[i] * dxv;
+                mX += Xh[i];
+                mXxh += Xh[i] * xh[i];
+            } else {
+                Xh[i] = 0.f;
+            }
+        }
+        mgxdx = ix_wave_sum(mgxdx) / D;
+        mX = ix_wave_sum(mX) / D;
+        mXxh = ix_wave_sum(mXxh) / D;
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float pgx = r * (gx[i] - mgx - xh[i] * mgxxh);
+                const float gg = Gg ? Gg[c] : 0.f;
+                const float gb = Gb ? Gb[c] : 0.f;
+                grad_dy[off + c] = pgx * gamma[c] + gg * xh[i] + gb;
+                grad_x[off + c] = r * (Xh[i] - mX - xh[i] * mXxh) - r * xh[i] * mgxdx;
+                ag[i] += pgx * d[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) sg[w][lane + 64 * i] = ag[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256)
+        unsafeAtomicAdd(&grad_gamma[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+}
+
+extern "C" int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy,
+                                        const float* x, const float* gamma, const float* mean, const float* rstd,
+                                        float* grad_dy, float* grad_x, float* grad_gamma, int64_t rows, int D,
+                                        hipStream_t stream) {
+    IX_CHECK_ARG(grad_gamma, "ix_layernorm_bwd_bwd_f32: null grad_gamma");
+    IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_bwd_f32: D=%d unsupported (1..1024)", D);
+    hipMemsetAsync(grad_gamma, 0, sizeof(float) * D, stream);
+    if (rows <= 0) return IX_OK;
+    IX_CHECK_ARG(dy && x && gamma && mean && rstd && grad_dy && grad_x, "ix_layernorm_bwd_bwd_f32: null pointer");
+    const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups))), block(256);
+#define LNBB(N) hipLaunchKernelGGL(ln_bwd_bwd_kernel<N>, grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups)
+    if (D <= 256) LNBB(4);
+    else if (D <= 512) LNBB(8);
+    else LNBB(16);
+#undef LNBB
+    IX_CHECK_LAUNCH("ix_layernorm_bwd_bwd_f32");
+    return IX_OK;
+}

@@ -1,0 +1,285 @@
+"""DETR ResNet-50-DC5 detector on the HIP kernels, behind the reference's module tree / forward contract.
+
+reference: models/detr_models/detr.py:21-83,299-341 (DETR, MLP, build), backbone.py:19-118, transformer.py:18-296,
+position_encoding.py:12-48.  Attribute names and child order follow the reference so that ``state_dict()`` keys
+(``backbone.0.body.layer2.0.conv1.weight`` ...) and the recursive-children parameter order used by the MAML
+helpers are identical.
+
+Internal layout is channels-last: activations are NHWC in the backbone and [frames, tokens, channels] in the
+transformer; the NCHW tensors the reference returns are zero-copy permuted views.
+"""
+import torch
+from torch import nn
+
+from . import hipops as ops
+from .nn import (Conv2dNHWC, Dropout, Embedding, FrozenBatchNorm2d, LayerNorm, Linear, MultiheadAttention,
+                 PointwiseConv2d)
+
+
+class NestedTensor(object):
+    """reference models/detr_models/util/misc.py:282-302."""
+
+    def __init__(self, tensors, mask):
+        self.tensors = tensors
+        self.mask = mask
+
+    def to(self, device):
+        return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
+
+    def decompose(self):
+        return self.tensors, self.mask
+
+    def __repr__(self):
+        return str(self.tensors)
+
+
+class Bottleneck(nn.Module):
+    """torchvision ResNet v1.5 bottleneck (stride on the 3x3)."""
+
+    def __init__(self, inplanes, planes, stride, dilation, downsample):
+        super().__init__()
+        self.conv1 = Conv2dNHWC(inplanes, planes, 1)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = Conv2dNHWC(planes, planes, 3, stride, dilation, dilation)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = Conv2dNHWC(planes, planes * 4, 1)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x
+        if self.downsample is not None:
+            idt = self.downsample[1](self.downsample[0](x))
+        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn2(self.conv2(y), relu=True)
+        return self.bn3(self.conv3(y), residual=idt, relu=True)
+
+
+def _make_layer(inplanes, planes, blocks, stride, first_dilation, dilation):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(Conv2dNHWC(inplanes, planes * 4, 1, stride), FrozenBatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, first_dilation, down)]
+    layers += [Bottleneck(planes * 4, planes, 1, dilation, None) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class ResNet50Body(nn.Module):
+    """conv1..layer4 of resnet50(replace_stride_with_dilation=[False, False, True]) (reference backbone.py:88-90)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = Conv2dNHWC(3, 64, 7, 2, 3)
+        self.bn1 = FrozenBatchNorm2d(64)
+        self.layer1 = _make_layer(64, 64, 3, 1, 1, 1)
+        self.layer2 = _make_layer(256, 128, 4, 2, 1, 1)
+        self.layer3 = _make_layer(512, 256, 6, 2, 1, 1)
+        self.layer4 = _make_layer(1024, 512, 3, 1, 1, 2)
+
+    def forward(self, frames_nchw):
+        n, c, H, W = frames_nchw.shape
+        with torch.no_grad():   # conv1 / bn1 / layer1 are frozen and the input carries no gradient (backbone.py:61-63)
+            g = ops.conv_geom(n, H, W, c, 7, 7, 2, 3, 1)
+            cols = ops.im2col_any_layout(frames_nchw, g, channels_last=False)
+            w = self.conv1.weight.permute(0, 2, 3, 1).reshape(64, -1)
+            if g.Kp != w.shape[1]:
+                w = torch.nn.functional.pad(w, (0, g.Kp - w.shape[1]))
+            x = ops.linear(cols, w).reshape(n, g.OH, g.OW, 64)
+            x = self.bn1(x, relu=True)
+            x = ops.maxpool_nhwc(x, 3, 2, 1)
+            x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        return self.layer4(x)
+
+
+class Backbone(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.body = ResNet50Body()
+        self.num_channels = 2048
+        for name, p in self.body.named_parameters():
+            if "layer2" not in name and "layer3" not in name and "layer4" not in name:
+                p.requires_grad_(False)
+
+    def forward(self, tensor_list):
+        feat = self.body(tensor_list.tensors)                       # [n, h, w, 2048]
+        m = tensor_list.mask
+        assert m is not None
+        mask = ops.mask_nearest((m != 0).to(torch.uint8).contiguous(), feat.shape[1], feat.shape[2])
+        return feat, mask
+
+
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=128, temperature=10000.0):
+        super().__init__()
+        self.num_pos_feats, self.temperature = num_pos_feats, temperature
+
+    def forward(self, mask_u8):
+        return ops.sine_position(mask_u8, self.num_pos_feats, self.temperature)
+
+
+class Joiner(nn.Module):
+    """Children named "0" (backbone) and "1" (position embedding) like the reference's nn.Sequential."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__()
+        self.add_module("0", backbone)
+        self.add_module("1", position_embedding)
+        self.num_channels = backbone.num_channels
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def forward(self, tensor_list):
+        feat, mask = self[0](tensor_list)
+        return feat, mask, self[1](mask)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.dropout1 = Dropout(dropout)
+        self.dropout2 = Dropout(dropout)
+
+    def forward(self, src, key_padding_mask, pos):
+        qk = ops.add(src, pos)
+        a = self.self_attn(qk, qk, src, key_padding_mask, qk_same=True)
+        src = self.norm1(ops.add(src, self.dropout1(a)))
+        f = self.linear2(self.dropout(ops.Relu.apply(self.linear1(src))))
+        return self.norm2(ops.add(src, self.dropout2(f)))
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.dropout = Dropout(dropout)
+        self.linear2 = Linear(dim_feedforward, d_model)
+        self.norm1 = LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
+        self.norm3 = LayerNorm(d_model)
+        self.dropout1 = Dropout(dropout)
+        self.dropout2 = Dropout(dropout)
+        self.dropout3 = Dropout(dropout)
+
+    def forward(self, tgt, memory, memory_key, memory_key_padding_mask, query_pos):
+        """tgt [n,Q,E]; memory_key = memory + pos (shared by all layers); query_pos [Q*E] broadcast over frames."""
+        n, Q, E = tgt.shape
+        qk = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos).reshape(n, Q, E)
+        a = self.self_attn(qk, qk, tgt, None, qk_same=True)
+        tgt = self.norm1(ops.add(tgt, self.dropout1(a)))
+        q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos).reshape(n, Q, E)
+        c = self.multihead_attn(q, memory_key, memory, memory_key_padding_mask)
+        tgt = self.norm2(ops.add(tgt, self.dropout2(c)))
+        f = self.linear2(self.dropout(ops.Relu.apply(self.linear1(tgt))))
+        return self.norm3(ops.add(tgt, self.dropout3(f)))
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, d_model, nhead, ffn, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(TransformerEncoderLayer(d_model, nhead, ffn, dropout) for _ in range(num_layers))
+        self.num_layers = num_layers
+        self.norm = None
+
+    def forward(self, src, key_padding_mask, pos):
+        for layer in self.layers:
+            src = layer(src, key_padding_mask, pos)
+        return src
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, d_model, nhead, ffn, dropout, num_layers, norm=True):
+        super().__init__()
+        self.layers = nn.ModuleList(TransformerDecoderLayer(d_model, nhead, ffn, dropout) for _ in range(num_layers))
+        self.num_layers = num_layers
+        self.norm = LayerNorm(d_model) if norm else None
+
+    def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos):
+        memory_key = ops.add(memory, pos) if pos is not None else memory
+        for layer in self.layers:
+            tgt = layer(tgt, memory, memory_key, memory_key_padding_mask, query_pos)
+        # return_intermediate=True in the reference, but only hs[-1] is consumed (detr.py:69): norm the last output
+        return self.norm(tgt) if self.norm is not None else tgt
+
+
+class Transformer(nn.Module):
+    """reference transformer.py:18-58, on [frames, tokens, d] tensors."""
+
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1):
+        super().__init__()
+        self.encoder = TransformerEncoder(d_model, nhead, dim_feedforward, dropout, num_encoder_layers)
+        self.decoder = TransformerDecoder(d_model, nhead, dim_feedforward, dropout, num_decoder_layers)
+        self.d_model, self.nhead = d_model, nhead
+
+    def forward(self, src, mask, query_embed, pos):
+        n, hw, E = src.shape
+        Q = query_embed.shape[0]
+        memory = self.encoder(src, mask, pos)
+        tgt = torch.zeros(n, Q, E, device=src.device, dtype=torch.float32)
+        hs = self.decoder(tgt, memory, mask, pos, query_embed.reshape(Q * E))
+        return hs, memory
+
+
+class MLP(nn.Module):
+    """reference detr.py:299-311."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = ops.Relu.apply(x)
+        return x
+
+
+class DETR(nn.Module):
+    """reference detr.py:21-75.  forward(NestedTensor) -> the same five-entry dict."""
+
+    def __init__(self, backbone, transformer, num_classes, num_queries):
+        super().__init__()
+        self.num_queries = num_queries
+        self.transformer = transformer
+        d = transformer.d_model
+        self.class_embed = Linear(d, num_classes + 1)
+        self.bbox_embed = MLP(d, d, 4, 3)
+        self.query_embed = Embedding(num_queries, d)
+        self.input_proj = PointwiseConv2d(backbone.num_channels, d)
+        self.backbone = backbone
+        self.aux_loss = False
+
+    def forward(self, samples):
+        frames = samples.tensors
+        if not frames.is_cuda:
+            raise RuntimeError("interactron_amd runs on the HIP kernels only: move the inputs to the GPU (no CPU path)")
+        feat, mask, pos = self.backbone(samples)                    # [n,h,w,2048], [n,h,w] u8, [n,hw,256]
+        n, h, w, c = feat.shape
+        src = self.input_proj(feat.reshape(n, h * w, c))
+        hs, memory = self.transformer(src, mask.reshape(n, h * w), self.query_embed.weight, pos)
+        return {
+            "pred_logits": self.class_embed(hs),
+            "pred_boxes": ops.Sigmoid.apply(self.bbox_embed(hs)),
+            "image_features": feat.permute(0, 3, 1, 2),
+            "embedded_memory_features": memory.reshape(n, h, w, -1).permute(0, 3, 1, 2),
+            "box_features": hs,
+        }
+
+
+def build_detector(num_classes, num_queries=50):
+    backbone = Joiner(Backbone(), PositionEmbeddingSine(128))
+    return DETR(backbone, Transformer(256, 8, 6, 6, 2048, 0.1), num_classes, num_queries)

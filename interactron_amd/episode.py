@@ -1,0 +1,270 @@
+"""The four per-episode models behind the reference's Python surface, computing on the HIP kernels.
+
+    interactron         reference models/interactron.py:14-197        (config interactron.yaml)
+    interactron_random  reference models/interactron_random.py:11-153 (config interactron_random.yaml)
+    detr_multiframe     reference models/detr_multiframe.py:9-131     (config multi_frame_baseline.yaml)
+    detr                reference models/detr.py:8-84                 (config single_frame_baseline.yaml)
+
+Contract: ``forward(data) -> (predictions, losses)`` with gradients already accumulated into
+``.grad`` of ``detector`` / ``fusion`` parameters; ``predict(data) -> dict``; ``get_next_action(data) -> int``;
+``train()/eval()``; ``set_logger``; attributes ``detector``, ``fusion``, ``criterion``, ``path_storage``, ``config``.
+
+Differences that do not change results: the adapted copy of theta shares storage with the parameters instead of
+being cloned twice, and the meta-step's second-order backward is asked only for the tensors whose ``.grad`` the
+reference keeps (fusion parameters and the never-adapted ``in_proj_*``), so the Hessian-vector product w.r.t. theta
+that the reference computes and throws away is never formed.
+"""
+import os
+import random
+
+import torch
+from torch import nn
+
+from . import hipops as ops
+from .criterion import HungarianMatcher, SetCriterion
+from .detector import NestedTensor, build_detector
+from .fusion import DecoderTransformer, Transformer
+from .meta import get_parameters, set_parameters, sgd_step
+from .storage import PathStorage
+from .synthetic import load_procedural
+
+
+def build(config):
+    """reference detr.py:314-341 -> (detector, criterion, postprocessors)."""
+    detector = build_detector(config.NUM_CLASSES, num_queries=int(getattr(config, "NUM_QUERIES", 50)))
+    matcher = HungarianMatcher(config.SET_COST_CLASS, config.SET_COST_BBOX, config.SET_COST_GIOU)
+    criterion = SetCriterion(config.NUM_CLASSES, matcher=matcher,
+                             weight_dict={"loss_ce": 1, "loss_bbox": 5, "loss_giou": 2}, eos_coef=0.1,
+                             losses=["labels", "boxes", "cardinality"])
+    return detector, criterion, {}
+
+
+def _load_detector_weights(detector, config):
+    w = getattr(config, "WEIGHTS", None)
+    if w in (None, "", "procedural", "__procedural__"):
+        load_procedural(detector, "detector.")
+        return
+    if not os.path.exists(str(w)):
+        raise FileNotFoundError("MODEL.WEIGHTS %r not found (use WEIGHTS: \"procedural\" for RNG-free synthetic weights)" % w)
+    detector.load_state_dict(torch.load(w, map_location="cpu")["model"])
+
+
+def _labels(data, b):
+    return [{"labels": data["category_ids"][b][j], "boxes": data["boxes"][b][j]}
+            for j in range(len(data["category_ids"][b]))]
+
+
+def _lift(out):
+    o = dict(out)
+    for k in ("embedded_memory_features", "box_features", "pred_logits", "pred_boxes"):
+        o[k] = o[k].unsqueeze(0)
+    return o
+
+
+def _weighted(l):
+    return l["loss_ce"] + 5 * l["loss_giou"] + 2 * l["loss_bbox"]
+
+
+def _mean_losses(per_task, tag):
+    return {k.replace("loss", tag): torch.mean(torch.stack([x[k] for x in per_task])) for k in per_task[0]}
+
+
+class _EpisodeModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.logger = None
+        self.mode = "train"
+
+    def eval(self):
+        return self.train(False)
+
+    def set_logger(self, logger):
+        assert self.logger is None, "This model already has a logger!"
+        self.logger = logger
+
+
+class _Adaptive(_EpisodeModel):
+    """Shared body of interactron / interactron_random: learned-loss inner step + meta-gradient."""
+
+    use_policy = False
+
+    def _second_order_targets(self):
+        """Leaves that keep a .grad from the supervisor backward: fusion parameters and the detector parameters that
+        are real nn.Parameters during the episode (MultiheadAttention.in_proj_*)."""
+        theta_ids = {id(p) for p in self._theta}
+        det = [p for p in self.detector.parameters() if p.requires_grad and id(p) not in theta_ids]
+        return [p for p in self.fusion.parameters() if p.requires_grad] + det
+
+    def _adapt(self, img, mask, create_graph):
+        dtheta = [p.detach().requires_grad_(True) for p in self._theta]
+        set_parameters(self.detector, dtheta)
+        pre = _lift(self.detector(NestedTensor(img, mask)))
+        fusion_out = self.fusion(pre)
+        learned_loss = ops.l2_norm(fusion_out["loss"])
+        grads = torch.autograd.grad(learned_loss, dtheta, create_graph=create_graph, retain_graph=create_graph,
+                                    allow_unused=True)
+        return dtheta, grads, fusion_out
+
+    def predict(self, data):
+        b, s, c, w, h = data["frames"].shape
+        img, mask = data["frames"].view(s, c, w, h), data["masks"].view(s, w, h)
+        self._theta = get_parameters(self.detector)
+        try:
+            with torch.enable_grad():
+                dtheta, grads, _ = self._adapt(img, mask, create_graph=False)
+            with torch.no_grad():
+                set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                post = self.detector(NestedTensor(img[0:1], mask[0:1]))
+        finally:
+            set_parameters(self.detector, self._theta)
+        return {k: v.unsqueeze(0) for k, v in post.items()}
+
+    def forward(self, data, train=True):
+        b, s, c, w, h = data["frames"].shape
+        img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
+        det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
+        self._theta = theta = get_parameters(self.detector)
+        targets2 = self._second_order_targets()
+        try:
+            for task in range(b):
+                labels = _labels(data, task)
+                dtheta, grads, fusion_out = self._adapt(img[task], mask[task], create_graph=True)
+                set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                post = self.detector(NestedTensor(img[task], mask[task]))
+                sup = self.criterion(post, labels, background_c=0.1)
+                if self.use_policy:
+                    first = {k: v[[0]] for k, v in post.items() if k in ("pred_logits", "pred_boxes")}
+                    gt = _weighted(self.criterion(first, [labels[0]], background_c=0.1))
+                    iip = data["initial_image_path"][task]
+                    store = self.path_storage.setdefault(iip, PathStorage())
+                    actions = data["actions"][task][:4].tolist()
+                    store.add_path(actions, torch.mean(gt).item())
+                    best = torch.tensor(store.get_label(actions), dtype=torch.long, device=gt.device)
+                    weight = torch.ones(4, device=gt.device)
+                    sup["loss_path"], _ = ops.WeightedCE.apply(fusion_out["actions"].reshape(4, 4), best, weight)
+                    sup["policy_reward"] = gt
+                sup_losses.append({k: v.detach() for k, v in sup.items()})
+                total = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
+                torch.autograd.backward(total, inputs=targets2)
+
+                # first-order detector update through the adapted weights (reference interactron.py:126-134)
+                fast1 = sgd_step(theta, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)
+                del grads, dtheta, fusion_out, post, sup, total
+                set_parameters(self.detector, fast1)
+                ridx = random.randint(0, 4)
+                post1 = self.detector(NestedTensor(img[task][ridx:ridx + 1], mask[task][ridx:ridx + 1]))
+                dl = self.criterion(post1, labels[ridx:ridx + 1], background_c=0.1)
+                det_losses.append({k: v.detach() for k, v in dl.items()})
+                _weighted(dl).backward()
+                logits_out.append(post1["pred_logits"].detach())
+                boxes_out.append(post1["pred_boxes"].detach())
+        finally:
+            set_parameters(self.detector, theta)
+        predictions = {"pred_logits": torch.stack(logits_out, dim=0), "pred_boxes": torch.stack(boxes_out, dim=0)}
+        losses = _mean_losses(det_losses, "loss_detector")
+        losses.update(_mean_losses(sup_losses, "loss_supervisor"))
+        return predictions, losses
+
+    def train(self, mode=True):
+        self.mode = "train" if mode else "test"
+        self.detector.train(mode)
+        self.fusion.train(mode)
+        return self
+
+
+class interactron(_Adaptive):
+    use_policy = True
+
+    def __init__(self, config):
+        super().__init__()
+        self.detector, self.criterion, self.postprocessor = build(config)
+        _load_detector_weights(self.detector, config)
+        self.fusion = Transformer(config)
+        self.path_storage = {}
+        self.config = config
+
+    def get_next_action(self, data):
+        b, s, c, w, h = data["frames"].shape
+        with torch.no_grad():
+            pre = _lift(self.detector(NestedTensor(data["frames"].view(b * s, c, w, h), data["masks"].view(b * s, w, h))))
+            actions = self.fusion(pre)["actions"]
+        return actions[s - 1].argmax(dim=-1).item()
+
+
+class interactron_random(_Adaptive):
+    use_policy = False
+
+    def __init__(self, config):
+        super().__init__()
+        self.detector, self.criterion, self.postprocessor = build(config)
+        _load_detector_weights(self.detector, config)
+        self.fusion = DecoderTransformer(config)
+        self.config = config
+
+
+class detr_multiframe(_EpisodeModel):
+    def __init__(self, config):
+        super().__init__()
+        self.detector, self.criterion, self.postprocessor = build(config)
+        _load_detector_weights(self.detector, config)
+        self.fusion = Transformer(config)
+        self.config = config
+
+    def predict(self, data):
+        b, s, c, w, h = data["frames"].shape
+        with torch.no_grad():
+            out = self.fusion(_lift(self.detector(NestedTensor(data["frames"].view(b * s, c, w, h),
+                                                               data["masks"].view(b * s, w, h)))))
+        return {"pred_boxes": out["pred_boxes"].view(b, s, *out["pred_boxes"].shape[1:]),
+                "pred_logits": out["pred_logits"].view(b, s, *out["pred_logits"].shape[1:])}
+
+    def forward(self, data):
+        b, s, c, w, h = data["frames"].shape
+        img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
+        losses, lo, bo = [], [], []
+        for task in range(b):
+            out = self.fusion(_lift(self.detector(NestedTensor(img[task], mask[task]))))
+            loss = self.criterion(out, _labels(data, task), background_c=0.1)
+            _weighted(loss).backward()
+            losses.append({k: v.detach() for k, v in loss.items()})
+            lo.append(out["pred_logits"][0:1].detach())
+            bo.append(out["pred_boxes"][0:1].detach())
+        return {"pred_logits": torch.stack(lo, dim=0), "pred_boxes": torch.stack(bo, dim=0)}, \
+            _mean_losses(losses, "loss_detector")
+
+    def train(self, mode=True):
+        self.mode = "train" if mode else "test"
+        self.detector.train(False)
+        self.detector.transformer.decoder.train(mode)
+        self.fusion.train(mode)
+        return self
+
+
+class detr(_EpisodeModel):
+    def __init__(self, config):
+        super().__init__()
+        self.model, self.criterion, self.postprocessor = build(config)
+        _load_detector_weights(self.model, config)
+        self.config = config
+
+    def _run(self, data):
+        b, s, c, w, h = data["frames"].shape
+        return self.model(NestedTensor(data["frames"].view(b * s, c, w, h), data["masks"].view(b * s, w, h))), b, s
+
+    def predict(self, data):
+        with torch.no_grad():
+            out, b, s = self._run(data)
+        return {k: v.reshape(b, s, *v.shape[1:]) for k, v in out.items()}
+
+    def forward(self, data):
+        out, b, s = self._run(data)
+        labels = [l for i in range(b) for l in _labels(data, i)]
+        losses = self.criterion(out, labels)
+        (losses["loss_ce"] + 5 * losses["loss_bbox"] + 2 * losses["loss_giou"]).backward()
+        return {k: v.detach().reshape(b, s, *v.shape[1:]) for k, v in out.items()}, \
+            {k.replace("loss", "loss_detector"): v for k, v in losses.items()}
+
+    def train(self, mode=True):
+        self.mode = "train" if mode else "test"
+        self.model.train(mode)
+        return self

@@ -1,0 +1,859 @@
+"""torch.autograd bindings of the HIP kernels (C-ABI in include/interactron_hip.h).
+
+Every compute op of the hot path is a ``torch.autograd.Function`` whose forward *and* backward launch
+hand-written gfx950 kernels through ctypes; PyTorch only provides device memory, streams and the autograd
+tape.  The backward of each Function is itself expressed with Functions from this file, so the op set is closed
+under differentiation: ``torch.autograd.grad(..., create_graph=True)`` followed by ``.backward()`` -- the MAML
+meta-gradient of reference models/interactron.py:99-123 -- runs entirely on these kernels.
+
+No CPU fallback exists: calling any op without the built library or with CPU tensors raises.
+"""
+import ctypes
+from collections import namedtuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+_c_void_p = ctypes.c_void_p
+
+
+def _L():
+    return _lib.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc, name):
+    if rc != 0:
+        _lib.check(rc, name)
+
+
+def _req(t, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.HipLibraryError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------
+# A strided matrix view into a flat tensor: elem(r, c) = base[offset + bo*so + bi*si + (c*ld + r if trans else r*ld + c)]
+View = namedtuple("View", "offset ld trans so si")
+# One batched contraction C = alpha * A(MxK) B(KxN): views for A, B and for C inside a fresh tensor `out_shape`
+GemmSpec = namedtuple("GemmSpec", "M N K bo bi A B C out_shape alpha")
+
+
+def _flip(v):
+    return View(v.offset, v.ld, not v.trans, v.so, v.si)
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _run_gemm(a, b, bias, sp):
+    covered = sp.bo * sp.bi * sp.M * sp.N == _numel(sp.out_shape)
+    out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
+    assert not sp.C.trans
+    esz = 4
+    rc = _L().ix_gemm_f32(a.data_ptr() + sp.A.offset * esz, b.data_ptr() + sp.B.offset * esz,
+                          out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
+                          sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
+                          sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
+                          sp.alpha, 0, 0, _stream())
+    _chk(rc, "ix_gemm_f32")
+    return out
+
+
+class Gemm(Function):
+    """out = alpha * A B (+ bias) for strided views A of `a` and B of `b`; see GemmSpec."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, sp):
+        a, b = _req(a, "gemm A"), _req(b, "gemm B")
+        ctx.sp = sp
+        ctx.has_bias = bias is not None
+        ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
+        ctx.save_for_backward(a, b)
+        return _run_gemm(a, b, bias, sp)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        sp = ctx.sp
+        dc = dc.contiguous()
+        da = db = dbias = None
+        if ctx.needs_input_grad[0]:
+            if not sp.A.trans:   # dA (MxK) = alpha * dC (MxN) * B^T (NxK)
+                s = GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B),
+                             View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), ctx.a_shape, sp.alpha)
+                da = Gemm.apply(dc, b, None, s)
+            else:                # storage holds A^T (KxM): dA^T = alpha * B (KxN) * dC^T (NxM)
+                s = GemmSpec(sp.K, sp.M, sp.N, sp.bo, sp.bi, sp.B, _flip(sp.C),
+                             View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), ctx.a_shape, sp.alpha)
+                da = Gemm.apply(b, dc, None, s)
+        if ctx.needs_input_grad[1]:
+            if not sp.B.trans:   # dB (KxN) = alpha * A^T (KxM) * dC (MxN)
+                s = GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C,
+                             View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
+                db = Gemm.apply(a, dc, None, s)
+            else:                # storage holds B^T (NxK): dB^T = alpha * dC^T (NxM) * A (MxK)
+                s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
+                             View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
+                db = Gemm.apply(dc, a, None, s)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = ColSum.apply(dc.reshape(-1, sp.N))
+        return da, db, dbias, None
+
+
+def linear(x, weight, bias=None):
+    """y[..., o] = sum_i x[..., i] * weight[o, i] + bias[o]   (nn.Linear semantics)."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    R = x.numel() // K
+    out_shape = tuple(x.shape[:-1]) + (N,)
+    sp = GemmSpec(R, N, K, 1, 1, View(0, K, False, 0, 0), View(0, K, True, 0, 0), View(0, N, False, 0, 0),
+                  out_shape, 1.0)
+    return Gemm.apply(x, weight, bias, sp)
+
+
+def matmul_nn(a, b):
+    """[M,K] @ [K,N] for plain contiguous 2-D tensors."""
+    M, K = a.shape
+    N = b.shape[1]
+    sp = GemmSpec(M, N, K, 1, 1, View(0, K, False, 0, 0), View(0, N, False, 0, 0), View(0, N, False, 0, 0), (M, N), 1.0)
+    return Gemm.apply(a, b, None, sp)
+
+
+def attention_scores(q, k, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, scale):
+    """scores[b,h,l,s] = scale * sum_d q[b,l,h*hd+d] * k[b,s,h*hd+d]  -> [nbatch, heads, L, Sp], Sp = S rounded up to 4.
+
+    q / k are [nbatch, L|S, ld] activations (possibly packed side by side: offsets q_off / k_off inside a row)."""
+    Sp = (S + 3) // 4 * 4
+    sp = GemmSpec(L, S, hd, nbatch, heads, View(q_off, q_ld, False, L * q_ld, hd), View(k_off, k_ld, True, S * k_ld, hd),
+                  View(0, Sp, False, heads * L * Sp, L * Sp), (nbatch, heads, L, Sp), scale)
+    return Gemm.apply(q, k, None, sp)
+
+
+def attention_apply(p, v, nbatch, heads, L, S, hd, v_ld, v_off):
+    """out[b,l,h*hd+d] = sum_s p[b,h,l,s] * v[b,s,h*hd+d]  -> [nbatch, L, heads*hd]."""
+    Sp = p.shape[-1]
+    E = heads * hd
+    sp = GemmSpec(L, hd, S, nbatch, heads, View(0, Sp, False, heads * L * Sp, L * Sp),
+                  View(v_off, v_ld, False, S * v_ld, hd), View(0, E, False, L * E, hd), (nbatch, L, E), 1.0)
+    return Gemm.apply(p, v, None, sp)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# elementwise / broadcast
+# ---------------------------------------------------------------------------------------------------------
+class ColSum(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x)
+        ctx.rows = x.shape[0]
+        out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+        _chk(_L().ix_colsum_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "ix_colsum_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return BcastRows.apply(g, ctx.rows)
+
+
+class BcastRows(Function):
+    @staticmethod
+    def forward(ctx, v, rows):
+        v = _req(v)
+        out = torch.empty(rows, v.numel(), device=v.device, dtype=torch.float32)
+        _chk(_L().ix_bcast_rows_f32(v.data_ptr(), out.data_ptr(), rows, v.numel(), _stream()), "ix_bcast_rows_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ColSum.apply(g), None
+
+
+class Axpby(Function):
+    """alpha*a + beta*b (same shapes)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = _req(a), _req(b)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        ctx.alpha, ctx.beta = alpha, beta
+        out = torch.empty_like(a)
+        _chk(_L().ix_axpby_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), alpha, beta, _stream()),
+             "ix_axpby_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = g if ctx.alpha == 1.0 else Scale.apply(g, ctx.alpha)
+        gb = g if ctx.beta == 1.0 else Scale.apply(g, ctx.beta)
+        return (ga if ctx.needs_input_grad[0] else None), (gb if ctx.needs_input_grad[1] else None), None, None
+
+
+def add(a, b):
+    return Axpby.apply(a, b, 1.0, 1.0)
+
+
+class Scale(Function):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        x = _req(x)
+        ctx.alpha = alpha
+        out = torch.empty_like(x)
+        _chk(_L().ix_scale_f32(x.data_ptr(), out.data_ptr(), x.numel(), alpha, _stream()), "ix_scale_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return Scale.apply(g, ctx.alpha), None
+
+
+class AddRowVec(Function):
+    """a [R, C] + v [C] broadcast over rows (learned query / position tables shared by all frames)."""
+
+    @staticmethod
+    def forward(ctx, a, v):
+        a, v = _req(a), _req(v)
+        C = v.numel()
+        assert a.shape[-1] * 0 == 0 and a.numel() % C == 0
+        out = torch.empty_like(a)
+        _chk(_L().ix_add_rowvec_f32(a.data_ptr(), v.data_ptr(), out.data_ptr(), a.numel() // C, C, _stream()),
+             "ix_add_rowvec_f32")
+        ctx.vshape = tuple(v.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gv = None
+        if ctx.needs_input_grad[1]:
+            C = _numel(ctx.vshape)
+            gv = ColSum.apply(g.reshape(-1, C)).reshape(ctx.vshape)
+        return g, gv
+
+
+class Dot(Function):
+    """sum(a*b) -> 0-d tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a), _req(b)
+        ctx.save_for_backward(a, b)
+        out = torch.empty((), device=a.device, dtype=torch.float32)
+        _chk(_L().ix_dot_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ix_dot_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return ScaleDev.apply(b, g), ScaleDev.apply(a, g)
+
+
+class ScaleDev(Function):
+    """x * s with s a 0-d device tensor."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x, s = _req(x), _req(s)
+        ctx.save_for_backward(x, s)
+        out = torch.empty_like(x)
+        _chk(_L().ix_scale_dev_f32(x.data_ptr(), s.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ix_scale_dev_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        return ScaleDev.apply(g, s), Dot.apply(g, x)
+
+
+def l2_norm(x):
+    """torch.norm(x): sqrt(sum x^2).  The 1-element sqrt stays a torch scalar op (plumbing)."""
+    return torch.sqrt(Dot.apply(x, x))
+
+
+class Relu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x)
+        out = torch.empty_like(x)
+        _chk(_L().ix_relu_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ix_relu_f32")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ReluBwd.apply(g, y)
+
+
+class ReluBwd(Function):
+    """dy * [y > 0]; linear in dy, piecewise constant in y."""
+
+    @staticmethod
+    def forward(ctx, dy, y):
+        dy, y = _req(dy), _req(y)
+        ctx.save_for_backward(y)
+        out = torch.empty_like(dy)
+        _chk(_L().ix_relu_bwd_f32(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), _stream()), "ix_relu_bwd_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        (y,) = ctx.saved_tensors
+        return ReluBwd.apply(G, y), None
+
+
+class Gelu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x)
+        ctx.save_for_backward(x)
+        out = torch.empty_like(x)
+        _chk(_L().ix_gelu_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ix_gelu_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return GeluBwd.apply(g, x)
+
+
+class GeluBwd(Function):
+    @staticmethod
+    def forward(ctx, dy, x):
+        dy, x = _req(dy), _req(x)
+        ctx.save_for_backward(dy, x)
+        out = torch.empty_like(dy)
+        _chk(_L().ix_gelu_bwd_f32(dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.numel(), _stream()), "ix_gelu_bwd_f32")
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, G):
+        dy, x = ctx.saved_tensors
+        G = _req(G)
+        gdy, gx = torch.empty_like(dy), torch.empty_like(x)
+        _chk(_L().ix_gelu_bwd_bwd_f32(G.data_ptr(), dy.data_ptr(), x.data_ptr(), gdy.data_ptr(), gx.data_ptr(),
+                                      dy.numel(), _stream()), "ix_gelu_bwd_bwd_f32")
+        return gdy, gx
+
+
+class Sigmoid(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x)
+        out = torch.empty_like(x)
+        _chk(_L().ix_sigmoid_f32(x.data_ptr(), out.data_ptr(), x.numel(), _stream()), "ix_sigmoid_f32")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return SigmoidBwd.apply(g, y)
+
+
+class SigmoidBwd(Function):
+    @staticmethod
+    def forward(ctx, dy, y):
+        dy, y = _req(dy), _req(y)
+        ctx.save_for_backward(dy, y)
+        out = torch.empty_like(dy)
+        _chk(_L().ix_sigmoid_bwd_f32(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), _stream()),
+             "ix_sigmoid_bwd_f32")
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, G):
+        dy, y = ctx.saved_tensors
+        G = _req(G)
+        gdy, gy = torch.empty_like(dy), torch.empty_like(y)
+        _chk(_L().ix_sigmoid_bwd_bwd_f32(G.data_ptr(), dy.data_ptr(), y.data_ptr(), gdy.data_ptr(), gy.data_ptr(),
+                                         dy.numel(), _stream()), "ix_sigmoid_bwd_bwd_f32")
+        return gdy, gy
+
+
+# dropout: the mask is a pure function of (seed, element index), so the same Function is its own adjoint
+_seed_state = {"base": 0x5EED, "counter": 0}
+
+
+def manual_seed(seed):
+    _seed_state["base"] = int(seed) & 0xFFFFFFFF
+    _seed_state["counter"] = 0
+
+
+def _next_seed():
+    _seed_state["counter"] += 1
+    return ((_seed_state["base"] << 32) ^ (_seed_state["counter"] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _req(x)
+        ctx.p, ctx.seed = p, seed
+        out = torch.empty_like(x)
+        _chk(_L().ix_dropout_f32(x.data_ptr(), out.data_ptr(), x.numel(), p, seed, _stream()), "ix_dropout_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Dropout.apply(g, ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return _Dropout.apply(x, float(p), _next_seed())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# FrozenBatchNorm2d affine (+ residual, + ReLU), NHWC
+# ---------------------------------------------------------------------------------------------------------
+def bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
+    C = weight.numel()
+    scale = torch.empty(C, device=weight.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    _chk(_L().ix_bn_fold_f32(_req(weight).data_ptr(), _req(bias).data_ptr(), _req(running_mean).data_ptr(),
+                             _req(running_var).data_ptr(), scale.data_ptr(), shift.data_ptr(), C, eps, _stream()),
+         "ix_bn_fold_f32")
+    return scale, shift
+
+
+def _channel_affine(x, scale, shift, residual, relu):
+    out = torch.empty_like(x)
+    _chk(_L().ix_channel_affine_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr() if shift is not None else None,
+                                    residual.data_ptr() if residual is not None else None, out.data_ptr(), x.numel(),
+                                    scale.numel(), 1 if relu else 0, _stream()), "ix_channel_affine_f32")
+    return out
+
+
+class ChannelScale(Function):
+    """x * scale[c] (channel = last dim); scale is a constant buffer."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _req(x)
+        ctx.save_for_backward(scale)
+        return _channel_affine(x, scale, None, None, False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return ChannelScale.apply(g, scale), None
+
+
+class BnAct(Function):
+    """y = [relu](x*scale[c] + shift[c] (+ residual)) on NHWC activations (FrozenBatchNorm2d folded)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        x = _req(x)
+        if residual is not None:
+            residual = _req(residual)
+        y = _channel_affine(x, scale, shift, residual, relu)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, y = ctx.saved_tensors
+        if ctx.relu:
+            g = ReluBwd.apply(g, y)
+        gx = ChannelScale.apply(g, scale) if ctx.needs_input_grad[0] else None
+        gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return gx, None, None, gres, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution pieces (NHWC)
+# ---------------------------------------------------------------------------------------------------------
+ConvGeom = namedtuple("ConvGeom", "n H W C KH KW stride pad dil OH OW Kp")
+
+
+def conv_geom(n, H, W, C, KH, KW, stride, pad, dil):
+    OH = (H + 2 * pad - dil * (KH - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+    K = KH * KW * C
+    return ConvGeom(n, H, W, C, KH, KW, stride, pad, dil, OH, OW, (K + 3) // 4 * 4)
+
+
+def _im2col(x, g, strides):
+    cols = torch.empty(g.n * g.OH * g.OW, g.Kp, device=x.device, dtype=torch.float32)
+    sxn, sxh, sxw, sxc = strides
+    _chk(_L().ix_im2col_f32(x.data_ptr(), cols.data_ptr(), g.n, g.H, g.W, g.C, sxn, sxh, sxw, sxc, g.KH, g.KW, g.stride,
+                            g.pad, g.dil, g.Kp, _stream()), "ix_im2col_f32")
+    return cols
+
+
+def im2col_any_layout(x_nchw_or_nhwc, g, channels_last):
+    """Non-differentiable patch extraction for the frozen stem; accepts the NCHW input frames directly."""
+    x = _req(x_nchw_or_nhwc)
+    if channels_last:
+        strides = (g.H * g.W * g.C, g.W * g.C, g.C, 1)
+    else:
+        strides = (g.C * g.H * g.W, g.W, 1, g.H * g.W)
+    return _im2col(x, g, strides)
+
+
+class Im2Col(Function):
+    @staticmethod
+    def forward(ctx, x, g):
+        x = _req(x)
+        ctx.g = g
+        return _im2col(x, g, (g.H * g.W * g.C, g.W * g.C, g.C, 1))
+
+    @staticmethod
+    def backward(ctx, dcols):
+        return Col2Im.apply(dcols, ctx.g), None
+
+
+class Col2Im(Function):
+    @staticmethod
+    def forward(ctx, cols, g):
+        cols = _req(cols)
+        ctx.g = g
+        dx = torch.empty(g.n, g.H, g.W, g.C, device=cols.device, dtype=torch.float32)
+        _chk(_L().ix_col2im_f32(cols.data_ptr(), dx.data_ptr(), g.n, g.H, g.W, g.C, g.KH, g.KW, g.stride, g.pad, g.dil,
+                                g.Kp, _stream()), "ix_col2im_f32")
+        return dx
+
+    @staticmethod
+    def backward(ctx, G):
+        return Im2Col.apply(G, ctx.g), None
+
+
+def maxpool_nhwc(x, k, stride, pad):
+    x = _req(x)
+    n, H, W, C = x.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty(n, OH, OW, C, device=x.device, dtype=torch.float32)
+    _chk(_L().ix_maxpool_nhwc_f32(x.data_ptr(), y.data_ptr(), n, H, W, C, k, stride, pad, _stream()), "ix_maxpool_nhwc_f32")
+    return y
+
+
+def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
+    """x [n,H,W,Cin] NHWC, weight [Cout,Cin,KH,KW] (reference layout) -> [n,OH,OW,Cout]."""
+    n, H, W, C = x.shape
+    Cout, Cin, KH, KW = weight.shape
+    assert Cin == C
+    if KH == 1 and KW == 1 and stride == 1 and pad == 0:
+        return linear(x, weight.reshape(Cout, Cin))
+    g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
+    cols = Im2Col.apply(x, g)
+    w2 = weight.permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin)   # (kh, kw, cin) fastest = patch-matrix column order
+    return linear(cols, w2).reshape(n, g.OH, g.OW, Cout)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# softmax / LayerNorm
+# ---------------------------------------------------------------------------------------------------------
+class Softmax(Function):
+    """softmax over the first `length` entries of the last dim (row pitch = last dim size); optional uint8
+    key-padding mask [nmask, length] with `rows_per_mask` consecutive rows sharing one mask row."""
+
+    @staticmethod
+    def forward(ctx, x, length, mask, rows_per_mask):
+        x = _req(x)
+        ld = x.shape[-1]
+        rows = x.numel() // ld
+        y = torch.empty_like(x) if ld == length else torch.zeros_like(x)
+        _chk(_L().ix_softmax_fwd_f32(x.data_ptr(), y.data_ptr(), rows, length, ld,
+                                     mask.data_ptr() if mask is not None else None, rows_per_mask,
+                                     mask.shape[-1] if mask is not None else 0, _stream()), "ix_softmax_fwd_f32")
+        ctx.length = length
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return SoftmaxBwd.apply(y, g, ctx.length), None, None, None
+
+
+class SoftmaxBwd(Function):
+    @staticmethod
+    def forward(ctx, y, dy, length):
+        y, dy = _req(y), _req(dy)
+        ld = y.shape[-1]
+        dx = torch.empty_like(y) if ld == length else torch.zeros_like(y)
+        _chk(_L().ix_softmax_bwd_f32(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel() // ld, length, ld, _stream()),
+             "ix_softmax_bwd_f32")
+        ctx.length = length
+        ctx.save_for_backward(y, dy)
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, G):
+        y, dy = ctx.saved_tensors
+        G = _req(G)
+        ld = y.shape[-1]
+        alloc = torch.empty_like if ld == ctx.length else torch.zeros_like
+        gy, gdy = alloc(y), alloc(y)
+        _chk(_L().ix_softmax_bwd_bwd_f32(G.data_ptr(), y.data_ptr(), dy.data_ptr(), gy.data_ptr(), gdy.data_ptr(),
+                                         y.numel() // ld, ctx.length, ld, _stream()), "ix_softmax_bwd_bwd_f32")
+        return gy, gdy, None
+
+
+class LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _req(x), _req(gamma), _req(beta)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _chk(_L().ix_layernorm_fwd_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), rows, D, eps, _stream()), "ix_layernorm_fwd_f32")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = LayerNormBwd.apply(g, x, gamma, mean, rstd)
+        return dx, dgamma, dbeta, None
+
+
+class LayerNormBwd(Function):
+    """(dy, x, gamma) -> (dx, dgamma, dbeta); mean/rstd are recomputable statistics of x (handled analytically)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, gamma, mean, rstd):
+        dy = _req(dy)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(D, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty_like(dgamma)
+        _chk(_L().ix_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, _stream()),
+             "ix_layernorm_bwd_f32")
+        ctx.save_for_backward(dy, x, gamma, mean, rstd)
+        return dx, dgamma, dbeta
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, Gx, Gg, Gb):
+        dy, x, gamma, mean, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        Gx = _req(Gx) if Gx is not None else None
+        Gg = _req(Gg) if Gg is not None else None
+        Gb = _req(Gb) if Gb is not None else None
+        gdy, gx = torch.empty_like(x), torch.empty_like(x)
+        ggamma = torch.empty(D, device=x.device, dtype=torch.float32)
+        _chk(_L().ix_layernorm_bwd_bwd_f32(Gx.data_ptr() if Gx is not None else None,
+                                           Gg.data_ptr() if Gg is not None else None,
+                                           Gb.data_ptr() if Gb is not None else None, dy.data_ptr(), x.data_ptr(),
+                                           gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gdy.data_ptr(),
+                                           gx.data_ptr(), ggamma.data_ptr(), rows, D, _stream()),
+             "ix_layernorm_bwd_bwd_f32")
+        return gdy, gx, ggamma, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNorm.apply(x, gamma, beta, eps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# criterion kernels
+# ---------------------------------------------------------------------------------------------------------
+def match_cost(logits, boxes, tgt_ids, tgt_boxes, w_class, w_bbox, w_giou):
+    """Hungarian cost matrix [rows, T] (no grad)."""
+    logits, boxes, tgt_boxes = _req(logits.detach()), _req(boxes.detach()), _req(tgt_boxes)
+    rows, C = logits.shape
+    T = tgt_ids.numel()
+    cost = torch.empty(rows, T, device=logits.device, dtype=torch.float32)
+    tgt_ids = tgt_ids.contiguous()
+    assert tgt_ids.dtype == torch.int64 and tgt_ids.is_cuda
+    _chk(_L().ix_match_cost_f32(logits.data_ptr(), boxes.data_ptr(), tgt_ids.data_ptr(), tgt_boxes.data_ptr(),
+                                cost.data_ptr(), rows, C, T, w_class, w_bbox, w_giou, _stream()), "ix_match_cost_f32")
+    return cost
+
+
+def lsap(cost_cpu):
+    """Host rectangular assignment on a CPU float32 [nr, nc] tensor -> (rows int64[k], cols int64[k])."""
+    cost_cpu = cost_cpu.contiguous()
+    assert not cost_cpu.is_cuda and cost_cpu.dtype == torch.float32
+    nr, nc = cost_cpu.shape
+    k = min(nr, nc)
+    r = torch.empty(k, dtype=torch.int64)
+    c = torch.empty(k, dtype=torch.int64)
+    _chk(_L().ix_lsap_f32(cost_cpu.data_ptr(), nr, nc, r.data_ptr(), c.data_ptr()), "ix_lsap_f32")
+    return r, c
+
+
+class WeightedCE(Function):
+    """F.cross_entropy(logits [R,C], target [R], weight [C]) with mean reduction; also returns per-row argmax."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight):
+        logits, weight = _req(logits), _req(weight)
+        R, C = logits.shape
+        lse = torch.empty(R, device=logits.device, dtype=torch.float32)
+        argmax = torch.empty(R, device=logits.device, dtype=torch.int64)
+        sums = torch.empty(2, device=logits.device, dtype=torch.float32)
+        target = target.contiguous()
+        _chk(_L().ix_weighted_ce_fwd_f32(logits.data_ptr(), target.data_ptr(), weight.data_ptr(), lse.data_ptr(),
+                                         argmax.data_ptr(), sums.data_ptr(), R, C, _stream()), "ix_weighted_ce_fwd_f32")
+        ctx.save_for_backward(logits, target, weight, lse, sums)
+        ctx.mark_non_differentiable(argmax)
+        return sums[0] / sums[1], argmax
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _):
+        logits, target, weight, lse, sums = ctx.saved_tensors
+        R, C = logits.shape
+        d = torch.empty_like(logits)
+        g = g.contiguous()
+        _chk(_L().ix_weighted_ce_bwd_f32(logits.data_ptr(), target.data_ptr(), weight.data_ptr(), lse.data_ptr(),
+                                         sums.data_ptr(), g.data_ptr(), d.data_ptr(), R, C, _stream()),
+             "ix_weighted_ce_bwd_f32")
+        return d, None, None
+
+
+class BoxLoss(Function):
+    """Sums of L1 and (1 - GIoU) over matched (prediction row, target box) pairs -> tensor [2]."""
+
+    @staticmethod
+    def forward(ctx, pred, src_idx, tgt):
+        pred, tgt = _req(pred), _req(tgt)
+        out = torch.empty(2, device=pred.device, dtype=torch.float32)
+        src_idx = src_idx.contiguous()
+        _chk(_L().ix_box_loss_fwd_f32(pred.data_ptr(), src_idx.data_ptr(), tgt.data_ptr(), out.data_ptr(),
+                                      src_idx.numel(), _stream()), "ix_box_loss_fwd_f32")
+        ctx.save_for_backward(pred, src_idx, tgt)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        pred, src_idx, tgt = ctx.saved_tensors
+        d = torch.empty_like(pred)
+        g = g.contiguous()
+        _chk(_L().ix_box_loss_bwd_f32(pred.data_ptr(), src_idx.data_ptr(), tgt.data_ptr(), g.data_ptr(), d.data_ptr(),
+                                      pred.shape[0], src_idx.numel(), _stream()), "ix_box_loss_bwd_f32")
+        return d, None, None
+
+
+def sine_position(mask_u8, num_pos_feats=128, temperature=10000.0, scale=6.283185307179586):
+    """mask uint8 [n,h,w] (1 = padded) -> [n, h*w, 2*num_pos_feats] token-major position embedding."""
+    n, h, w = mask_u8.shape
+    pos = torch.empty(n, h * w, 2 * num_pos_feats, device=mask_u8.device, dtype=torch.float32)
+    _chk(_L().ix_sine_pos_f32(mask_u8.data_ptr(), pos.data_ptr(), n, h, w, num_pos_feats, temperature, scale, _stream()),
+         "ix_sine_pos_f32")
+    return pos
+
+
+def mask_nearest(mask_u8, h, w):
+    n, H, W = mask_u8.shape
+    out = torch.empty(n, h, w, device=mask_u8.device, dtype=torch.uint8)
+    _chk(_L().ix_mask_nearest_u8(mask_u8.data_ptr(), out.data_ptr(), n, H, W, h, w, _stream()), "ix_mask_nearest_u8")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# MAML fast weights and the outer step
+# ---------------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def _size_array(tensors):
+    arr = (ctypes.c_int64 * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.numel() if t is not None else 0
+    return arr
+
+
+class ClippedSGD(Function):
+    """fast_i = p_i - clamp(lr*g_i, +-clip) for all tensors in one multi-tensor launch set.
+
+    apply(lr, clip, n, p_1..p_n, g_1..g_n) -> (fast_1..fast_n).  g_i may be None (tensor passes through)."""
+
+    @staticmethod
+    def forward(ctx, lr, clip, n, *tensors):
+        ps, gs = tensors[:n], tensors[n:]
+        idx = [i for i in range(n) if gs[i] is not None]
+        pc = [_req(ps[i]) for i in idx]
+        gc = [_req(gs[i]) for i in idx]
+        outs = [torch.empty_like(p) for p in pc]
+        if idx:
+            _chk(_L().ix_sgd_clip_multi_f32(_ptr_array(pc), _ptr_array(gc), _ptr_array(outs), _size_array(pc), len(pc),
+                                            lr, clip, _stream()), "ix_sgd_clip_multi_f32")
+        ctx.lr, ctx.clip, ctx.n, ctx.idx = lr, clip, n, idx
+        ctx.save_for_backward(*gc)
+        res = list(ps)
+        for j, i in enumerate(idx):
+            res[i] = outs[j]
+        # pass-through tensors must not alias the inputs for autograd
+        return tuple(r if i in set(idx) else r.view_as(r) for i, r in enumerate(res))
+
+    @staticmethod
+    def backward(ctx, *G):
+        gs = ctx.saved_tensors
+        n, idx = ctx.n, ctx.idx
+        grad_p = [G[i] if ctx.needs_input_grad[3 + i] else None for i in range(n)]
+        grad_g = [None] * n
+        need = [j for j, i in enumerate(idx) if ctx.needs_input_grad[3 + n + i] and G[i] is not None]
+        if need:
+            res = _ClippedSGDBwd.apply(ctx.lr, ctx.clip, len(need), *([G[idx[j]] for j in need] + [gs[j] for j in need]))
+            for j, r in zip(need, res):
+                grad_g[idx[j]] = r
+        return (None, None, None) + tuple(grad_p) + tuple(grad_g)
+
+
+class _ClippedSGDBwd(Function):
+    """out_i = -lr * G_i * [|lr*g_i| <= clip]."""
+
+    @staticmethod
+    def forward(ctx, lr, clip, n, *tensors):
+        Gs = [_req(t) for t in tensors[:n]]
+        gs = [_req(t) for t in tensors[n:]]
+        outs = [torch.empty_like(t) for t in Gs]
+        _chk(_L().ix_sgd_clip_bwd_multi_f32(_ptr_array(Gs), _ptr_array(gs), _ptr_array(outs), _size_array(Gs), n, lr,
+                                            clip, _stream()), "ix_sgd_clip_bwd_multi_f32")
+        ctx.lr, ctx.clip, ctx.n = lr, clip, n
+        ctx.save_for_backward(*gs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *GG):
+        # linear in G (the indicator is piecewise constant in g)
+        gs = ctx.saved_tensors
+        n = ctx.n
+        res = _ClippedSGDBwd.apply(ctx.lr, ctx.clip, n, *(list(GG) + list(gs)))
+        return (None, None, None) + tuple(res) + (None,) * n
+
+
+def sumsq_accum(x_flat, out_scalar):
+    _chk(_L().ix_sumsq_accum_f32(x_flat.data_ptr(), x_flat.numel(), out_scalar.data_ptr(), _stream()), "ix_sumsq_accum_f32")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq=None, max_norm=0.0, zero_grad=False):
+    _chk(_L().ix_adam_step_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                               step, sumsq.data_ptr() if sumsq is not None else None, max_norm, 1 if zero_grad else 0,
+                               _stream()), "ix_adam_step_f32")

@@ -1,0 +1,105 @@
+"""Outer (meta) optimisation step and multi-GPU episode sharding.
+
+reference engine/interactron_trainer.py:93-111: after ``model(data)`` has accumulated gradients, the trainer runs
+``clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP)`` and steps two Adams (detector lr 1e-5, fusion lr 1e-4).
+The reference's multi-GPU story is ``nn.DataParallel`` (interactron_trainer.py:44-46); here it is one process per
+GPU: every rank runs the episodes ``rank::world_size`` of the global batch, all parameters and their gradients live
+in two flat fp32 buffers, and ONE RCCL all-reduce (SUM, matching the reference's un-normalised accumulation over
+the batch) of the flat gradient buffer over xGMI precedes the clip + Adam, which run identically on every rank as
+two fused HIP launches (``ix_sumsq_accum_f32`` + ``ix_adam_step_f32``).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the flat buffer (float4 loads stay legal)
+
+
+def shard_batch(data, rank, world_size):
+    """Episodes ``rank::world_size`` of a collated batch (reference collate layout, utils/storage_utils.py:53-64)."""
+    if world_size == 1:
+        return data
+    idx = list(range(rank, data["frames"].shape[0], world_size))
+    out = {}
+    for k, v in data.items():
+        if torch.is_tensor(v):
+            out[k] = v[idx]
+        elif isinstance(v, (list, tuple)):
+            out[k] = [v[i] for i in idx]
+        else:
+            out[k] = v
+    return out
+
+
+def init_distributed(backend=None):
+    """(rank, local_rank, world_size) from the torchrun environment; initialises the process group when needed."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank,
+                                world_size=world)
+    return rank, local, world
+
+
+class FlatBuffers:
+    """Re-homes the trainable parameters of ``groups`` (list of parameter lists) into one flat buffer and gives every
+    parameter a persistent ``.grad`` view into a second flat buffer.  Pure tensor plumbing: works on any device."""
+
+    def __init__(self, groups):
+        self.groups = [[p for p in g if p.requires_grad] for g in groups]
+        offs, total = [], 0
+        self.segments = []
+        for g in self.groups:
+            start = total
+            for p in g:
+                offs.append(total)
+                total += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.segments.append((start, total))
+        params = [p for g in self.groups for p in g]
+        dev = params[0].device
+        self.params = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(total, device=dev, dtype=torch.float32)
+        for p, o in zip(params, offs):
+            n = p.numel()
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            if p.grad is not None:
+                self.grads[o:o + n].copy_(p.grad.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+
+    def all_reduce_grads(self):
+        """The path's single data-path collective: SUM of the flat meta-gradient buffer over all ranks."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+
+
+class FlatOuterStep:
+    """clip_grad_norm_(all, max_norm) + Adam(detector) + Adam(fusion) on the flat buffers (HIP kernels)."""
+
+    def __init__(self, model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8):
+        groups = [list(model.detector.parameters())]
+        self.lrs = [detector_lr]
+        if hasattr(model, "fusion"):
+            groups.append(list(model.fusion.parameters()))
+            self.lrs.append(fusion_lr)
+        self.flat = FlatBuffers(groups)
+        self.m = torch.zeros_like(self.flat.params)
+        self.v = torch.zeros_like(self.flat.params)
+        self.sumsq = torch.zeros((), device=self.flat.params.device, dtype=torch.float32)
+        self.max_norm, self.betas, self.eps, self.t = max_norm, betas, eps, 0
+
+    def step(self):
+        from . import hipops as ops
+        f = self.flat
+        f.all_reduce_grads()
+        self.t += 1
+        self.sumsq.zero_()
+        ops.sumsq_accum(f.grads, self.sumsq)
+        for (a, b), lr in zip(f.segments, self.lrs):
+            ops.adam_step(f.params[a:b], f.grads[a:b], self.m[a:b], self.v[a:b], lr, self.betas[0], self.betas[1],
+                          self.eps, self.t, self.sumsq, self.max_norm, zero_grad=True)
+        return torch.sqrt(self.sumsq)

@@ -1,0 +1,349 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against float64 torch CPU references, including the
+first- and second-order derivatives the MAML meta-gradient needs.  Needs a real MI355X: ``pytest -m gpu``.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from interactron_amd import hipops
+    hipops._L()   # fails loudly if the library is missing
+    return hipops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape) * 7919)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol=2e-4, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-6) if b.numel() else 1.0
+    err = float((a - b).abs().max()) if b.numel() else 0.0
+    assert err <= tol * scale + 1e-7, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def check_op(hip_fn, ref_fn, inputs, requires=None, tol=2e-4, second_order=True, name="op"):
+    """Compare forward, vector-Jacobian products and the gradient of a random functional of those products."""
+    requires = requires or [True] * len(inputs)
+    xr = [x.clone().double().requires_grad_(r) for x, r in zip(inputs, requires)]
+    xh = [x.clone().float().cuda().requires_grad_(r) for x, r in zip(inputs, requires)]
+    yr, yh = ref_fn(*xr), hip_fn(*xh)
+    close(yh, yr, tol, name + " forward")
+    gy = rnd(*yr.shape, seed=11) if yr.dim() else torch.tensor(0.7)
+    gyr, gyh = gy.double().requires_grad_(True), gy.float().cuda().requires_grad_(True)
+    ir = [x for x, r in zip(xr, requires) if r]
+    ih = [x for x, r in zip(xh, requires) if r]
+    gr = torch.autograd.grad(yr, ir, gyr, create_graph=True)
+    gh = torch.autograd.grad(yh, ih, gyh, create_graph=True)
+    for i, (a, b) in enumerate(zip(gh, gr)):
+        close(a, b, tol, "%s grad[%d]" % (name, i))
+    if not second_order:
+        return
+    ws = [rnd(*g.shape, seed=23 + i) for i, g in enumerate(gr)]
+    sr = sum((g * w.double()).sum() for g, w in zip(gr, ws))
+    sh = sum((g * w.float().cuda()).sum() for g, w in zip(gh, ws))
+    if not sr.requires_grad:
+        return
+    g2r = torch.autograd.grad(sr, ir + [gyr], allow_unused=True)
+    g2h = torch.autograd.grad(sh, ih + [gyh], allow_unused=True)
+    for i, (a, b) in enumerate(zip(g2h, g2r)):
+        if b is None:
+            assert a is None or float(a.abs().max()) < 1e-6, "%s second-order[%d] should be zero" % (name, i)
+            continue
+        assert a is not None, "%s second-order[%d] missing" % (name, i)
+        close(a, b, tol * 2, "%s second-order[%d]" % (name, i))
+
+
+@pytest.mark.parametrize("R,K,N", [(1805, 256, 2048), (250, 256, 1236), (250, 512, 1), (37, 147, 64), (64, 20, 4),
+                                   (2060, 512, 512), (130, 1496, 512), (5, 8, 3)])
+def test_linear(ops, R, K, N):
+    check_op(lambda x, w, b: ops.linear(x, w, b), lambda x, w, b: F.linear(x, w, b),
+             [rnd(R, K), rnd(N, K, scale=K ** -0.5), rnd(N)], name="linear %dx%dx%d" % (R, K, N))
+
+
+def test_linear_large_tile_and_splitk(ops):
+    # 128x128 tile path (many tiles) and the split-K path (small output, long K)
+    check_op(lambda x, w: ops.linear(x, w), lambda x, w: F.linear(x, w), [rnd(2100, 320), rnd(2048, 320, scale=0.05)],
+             second_order=False, name="linear big")
+    check_op(lambda a, b: ops.matmul_nn(a, b), lambda a, b: a @ b, [rnd(96, 4000, scale=0.02), rnd(4000, 72)],
+             name="matmul split-k")
+
+
+@pytest.mark.parametrize("n,H,L,S,hd", [(5, 8, 361, 361, 32), (2, 8, 50, 361, 32), (1, 8, 300, 300, 64), (2, 4, 7, 30, 16)])
+def test_attention_gemms(ops, n, H, L, S, hd):
+    E = H * hd
+    scale = 1.0 / math.sqrt(hd)
+
+    def ref_scores(q, k):
+        return torch.einsum("blhd,bshd->bhls", q.view(n, L, H, hd), k.view(n, S, H, hd)) * scale
+
+    def hip_scores(q, k):
+        return ops.attention_scores(q, k, n, H, L, S, hd, E, E, 0, 0, scale)[..., :S]
+
+    check_op(hip_scores, ref_scores, [rnd(n, L, E), rnd(n, S, E)], name="scores")
+
+    Sp = (S + 3) // 4 * 4
+
+    def ref_apply(p, v):
+        return torch.einsum("bhls,bshd->blhd", p[..., :S], v.view(n, S, H, hd)).reshape(n, L, E)
+
+    def hip_apply(p, v):
+        return ops.attention_apply(p, v, n, H, L, S, hd, E, 0)
+
+    p = torch.zeros(n, H, L, Sp)
+    p[..., :S] = rnd(n, H, L, S).softmax(-1)
+    xr = [p.double().requires_grad_(True), rnd(n, S, E).double().requires_grad_(True)]
+    xh = [x.detach().float().cuda().requires_grad_(True) for x in xr]
+    yr, yh = ref_apply(*xr), hip_apply(*xh)
+    close(yh, yr, 2e-4, "apply fwd")
+    gy = rnd(n, L, E, seed=5)
+    gr = torch.autograd.grad(yr, xr, gy.double())
+    gh = torch.autograd.grad(yh, xh, gy.cuda())
+    close(gh[0][..., :S], gr[0][..., :S], 2e-4, "apply dP")
+    close(gh[1], gr[1], 2e-4, "apply dV")
+
+
+def test_packed_qk_projection_offsets(ops):
+    n, H, L, hd = 2, 8, 19, 32
+    E = H * hd
+    qk = rnd(n, L, 2 * E)
+
+    def ref(t):
+        q, k = t[..., :E], t[..., E:]
+        return torch.einsum("blhd,bshd->bhls", q.reshape(n, L, H, hd), k.reshape(n, L, H, hd))
+
+    check_op(lambda t: ops.attention_scores(t, t, n, H, L, L, hd, 2 * E, 2 * E, 0, E, 1.0)[..., :L], ref, [qk],
+             name="packed qk")
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(64, 32, 3, 1, 1, 1, 19), (32, 64, 3, 2, 1, 1, 20),
+                                                           (64, 64, 3, 1, 2, 2, 11), (128, 256, 1, 2, 0, 1, 15),
+                                                           (256, 64, 1, 1, 0, 1, 9)])
+def test_conv2d_nhwc(ops, cin, cout, k, stride, pad, dil, hw):
+    def ref(x, w):
+        return F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil).permute(0, 2, 3, 1)
+
+    check_op(lambda x, w: ops.conv2d_nhwc(x, w, stride, pad, dil), ref,
+             [rnd(2, hw, hw + 1, cin), rnd(cout, cin, k, k, scale=(cin * k * k) ** -0.5)], name="conv")
+
+
+def test_stem_conv_and_maxpool(ops):
+    x = rnd(2, 3, 37, 41)
+    w = rnd(64, 3, 7, 7, scale=0.1)
+    g = ops.conv_geom(2, 37, 41, 3, 7, 7, 2, 3, 1)
+    cols = ops.im2col_any_layout(x.cuda(), g, channels_last=False)
+    w2 = F.pad(w.permute(0, 2, 3, 1).reshape(64, -1), (0, g.Kp - 147)).cuda()
+    y = ops.linear(cols, w2).reshape(2, g.OH, g.OW, 64)
+    ref = F.conv2d(x, w, None, 2, 3)
+    close(y.permute(0, 3, 1, 2), ref, 2e-4, "stem conv")
+    mp = ops.maxpool_nhwc(y, 3, 2, 1)
+    close(mp.permute(0, 3, 1, 2), F.max_pool2d(ref, 3, 2, 1), 2e-4, "maxpool")
+
+
+def test_bn_act(ops):
+    C = 64
+    w, b, rm, rv = rnd(C).abs() + 0.5, rnd(C), rnd(C), rnd(C).abs() + 0.5
+    scale_h, shift_h = ops.bn_fold(w.cuda(), b.cuda(), rm.cuda(), rv.cuda())
+    scale = (w.double() * (rv.double() + 1e-5).rsqrt())
+    shift = b.double() - rm.double() * scale
+    close(scale_h, scale, 1e-5, "bn scale")
+    close(shift_h, shift, 1e-5, "bn shift")
+    for relu in (False, True):
+        check_op(lambda x, r: ops.BnAct.apply(x, scale_h, shift_h, r, relu),
+                 lambda x, r: (F.relu(x * scale + shift + r) if relu else x * scale + shift + r),
+                 [rnd(3, 5, 7, C), rnd(3, 5, 7, C)], name="bn_act relu=%s" % relu)
+    check_op(lambda x: ops.BnAct.apply(x, scale_h, shift_h, None, True), lambda x: F.relu(x * scale + shift),
+             [rnd(3, 5, 7, C)], name="bn_act nores")
+
+
+def test_elementwise(ops):
+    x = rnd(1000, 33)
+    check_op(lambda a: ops.Relu.apply(a), F.relu, [x], name="relu")
+    check_op(lambda a: ops.Gelu.apply(a), F.gelu, [x], name="gelu")
+    check_op(lambda a: ops.Sigmoid.apply(a), torch.sigmoid, [x], name="sigmoid")
+    check_op(lambda a, b: ops.add(a, b), lambda a, b: a + b, [x, rnd(1000, 33, seed=3)], name="add")
+    check_op(lambda a, v: ops.AddRowVec.apply(a, v), lambda a, v: a + v, [x, rnd(33)], name="add_rowvec")
+    check_op(lambda a: ops.l2_norm(a), lambda a: torch.norm(a), [rnd(1, 5, 50, 1)], name="l2_norm")
+    check_op(lambda a: ops.Scale.apply(a, 0.37), lambda a: a * 0.37, [x], name="scale")
+    check_op(lambda a: ops.ColSum.apply(a), lambda a: a.sum(0), [x], name="colsum")
+
+
+def test_dropout_is_scaled_mask_and_self_adjoint(ops):
+    x = torch.ones(400000).cuda().requires_grad_(True)
+    y = ops._Dropout.apply(x, 0.1, 1234567)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3
+    close(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9), 1e-6, "dropout scale")
+    (g,) = torch.autograd.grad(y, x, torch.ones_like(y))
+    assert torch.equal(g, y.detach())      # same mask in backward
+    y2 = ops._Dropout.apply(x, 0.1, 7654321)
+    assert not torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("rows,length,ld", [(40, 50, 52), (80, 361, 364), (16, 2060, 2060), (9, 2500, 2500), (6, 30, 32)])
+def test_softmax(ops, rows, length, ld):
+    x = torch.zeros(rows, ld)
+    x[:, :length] = rnd(rows, length, scale=2.0)
+    check_op(lambda t: ops.Softmax.apply(t, length, None, 0)[:, :length], lambda t: t[:, :length].softmax(-1), [x],
+             name="softmax")
+
+
+def test_softmax_key_padding_mask(ops):
+    n, H, L, S = 2, 4, 7, 30
+    x = rnd(n, H, L, 32)
+    mask = torch.zeros(n, S, dtype=torch.uint8)
+    mask[1, 25:] = 1
+    add = torch.zeros(n, 1, 1, S).masked_fill(mask.bool().view(n, 1, 1, S), float("-inf"))
+    check_op(lambda t: ops.Softmax.apply(t, S, mask.cuda(), H * L)[..., :S],
+             lambda t: (t[..., :S] + add.double()).softmax(-1), [x], name="softmax mask")
+
+
+@pytest.mark.parametrize("rows,D", [(1805, 256), (2060, 512), (250, 256), (3, 100)])
+def test_layer_norm(ops, rows, D):
+    check_op(lambda x, g, b: ops.layer_norm(x, g, b), lambda x, g, b: F.layer_norm(x, (D,), g, b, 1e-5),
+             [rnd(rows, D, scale=2.0) + 0.3, rnd(D) * 0.1 + 1.0, rnd(D) * 0.1], tol=5e-4, name="layer_norm")
+
+
+def test_weighted_ce(ops):
+    R, C = 250, 1236
+    logits = rnd(R, C, scale=2.0)
+    target = torch.randint(0, C, (R,), generator=torch.Generator().manual_seed(3))
+    target[::3] = C - 1
+    w = torch.ones(C)
+    w[-1] = 0.1
+    xh = logits.cuda().requires_grad_(True)
+    loss, argmax = ops.WeightedCE.apply(xh, target.cuda(), w.cuda())
+    xr = logits.double().requires_grad_(True)
+    ref = F.cross_entropy(xr, target, w.double())
+    close(loss, ref, 1e-5, "ce")
+    assert torch.equal(argmax.cpu(), logits.argmax(-1))
+    (gh,) = torch.autograd.grad(loss * 1.7, xh)
+    (gr,) = torch.autograd.grad(ref * 1.7, xr)
+    close(gh, gr, 1e-4, "ce grad")
+
+
+def test_box_loss_and_match_cost(ops):
+    from oracle import criterion as oc
+    from interactron_amd.synthetic import hash_uniform
+    P, T = 250, 9
+    pb = torch.from_numpy(np.concatenate([hash_uniform("t/c", 2 * P, 0.2, 0.8).reshape(P, 2),
+                                          hash_uniform("t/wh", 2 * P, 0.05, 0.5).reshape(P, 2)], 1).astype(np.float32))
+    tb = torch.from_numpy(np.concatenate([hash_uniform("t/tc", 2 * T, 0.3, 0.7).reshape(T, 2),
+                                          hash_uniform("t/twh", 2 * T, 0.05, 0.35).reshape(T, 2)], 1).astype(np.float32))
+    idx = torch.tensor([3, 77, 120, 5, 249, 0, 18, 19, 200])
+    xh = pb.cuda().requires_grad_(True)
+    out = ops.BoxLoss.apply(xh, idx.cuda(), tb.cuda())
+    xr = pb.double().requires_grad_(True)
+    src = xr[idx]
+    l1 = (src - tb.double()).abs().sum()
+    gl = (1 - torch.diag(oc.pairwise_giou(oc.cxcywh_to_xyxy(src), oc.cxcywh_to_xyxy(tb.double())))).sum()
+    close(out, torch.stack([l1, gl]), 1e-5, "box loss")
+    (gh,) = torch.autograd.grad((out * torch.tensor([2.0, 5.0]).cuda()).sum(), xh)
+    (gr,) = torch.autograd.grad(2 * l1 + 5 * gl, xr)
+    close(gh, gr, 1e-4, "box loss grad")
+    logits = rnd(P, 1236, scale=2.0)
+    ids = torch.randint(1, 1235, (T,), generator=torch.Generator().manual_seed(1))
+    cost = ops.match_cost(logits.cuda(), pb.cuda(), ids.cuda(), tb.cuda(), 1.0, 5.0, 2.0)
+    ref = oc.matching_cost(logits.view(5, 50, -1), pb.view(5, 50, 4), ids, tb)
+    close(cost, ref, 1e-5, "match cost")
+
+
+def test_sine_position_and_mask_resize(ops):
+    from oracle import detector as od
+    m = torch.zeros(2, 19, 23, dtype=torch.bool)
+    m[0, 15:, :] = True
+    m[1, :, 12:] = True
+    pos = ops.sine_position(m.to(torch.uint8).cuda())
+    ref = od.sine_position(m).permute(0, 2, 3, 1).reshape(2, 19 * 23, 256)
+    close(pos, ref, 2e-5, "sine pos")
+    big = torch.zeros(2, 300, 301, dtype=torch.uint8)
+    big[0, 250:, :] = 1
+    big[1, :, 100:] = 1
+    small = ops.mask_nearest(big.cuda(), 19, 19)
+    assert torch.equal(small.cpu().bool(), od.downsample_mask(big.bool(), (19, 19)))
+
+
+def test_clipped_sgd_first_and_second_order(ops):
+    ps = [rnd(1000), rnd(37, 3), rnd(4096)]
+    gs = [rnd(1000, seed=1) * 12, None, rnd(4096, seed=2) * 12]
+    lr, clip = 1e-3, 0.01
+
+    def run(p, g, dev, dt):
+        p = [t.clone().to(dev, dt).requires_grad_(True) for t in p]
+        g = [None if t is None else t.clone().to(dev, dt).requires_grad_(True) for t in g]
+        if dev == "cuda":
+            out = ops.ClippedSGD.apply(lr, clip, 3, *(p + g))
+        else:
+            out = [a if b is None else a - torch.clip(lr * b, -clip, clip) for a, b in zip(p, g)]
+        s = sum((o * rnd(*o.shape, seed=9).to(dev, dt)).sum() for o in out)
+        grads = torch.autograd.grad(s, p + [t for t in g if t is not None])
+        return out, grads
+
+    oh, gh = run(ps, gs, "cuda", torch.float32)
+    orf, gr = run(ps, gs, "cpu", torch.float64)
+    for a, b in zip(oh, orf):
+        close(a, b, 1e-6, "sgd out")
+    for a, b in zip(gh, gr):
+        close(a, b, 1e-6, "sgd grad")
+
+
+def test_lsap_matches_scipy(ops):
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(0)
+    for trial in range(200):
+        nr, nc = int(rng.integers(1, 60)), int(rng.integers(1, 12))
+        c = rng.standard_normal((nr, nc)).astype(np.float32)
+        if trial % 2 and nc > 1:
+            c[:, 1] = c[:, 0]
+        r, cc = ops.lsap(torch.from_numpy(c))
+        sr, sc = linear_sum_assignment(c)
+        assert np.array_equal(sr, r.numpy()) and np.array_equal(sc, cc.numpy())
+
+
+def test_adam_with_folded_grad_clip(ops):
+    n = 10007
+    p, g = rnd(n), rnd(n, seed=4) * 3
+    ref_p = torch.nn.Parameter(p.clone().double())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    ph, m, v = p.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    gh = torch.zeros(n + 1).cuda()[:n]
+    for step in (1, 2, 3):
+        ref_p.grad = g.clone().double() * step
+        torch.nn.utils.clip_grad_norm_([ref_p], 1.0)
+        opt.step()
+        gh.copy_(g.cuda() * step)
+        ss = torch.zeros((), device="cuda")
+        ops.sumsq_accum(gh, ss)
+        ops.adam_step(ph, gh, m, v, 1e-3, 0.9, 0.999, 1e-8, step, ss, 1.0, zero_grad=True)
+        close(ph, ref_p.data, 1e-5, "adam step %d" % step)
+        assert float(gh.abs().max()) == 0.0
+
+
+def test_mha_module_matches_oracle(ops):
+    from interactron_amd.nn import MultiheadAttention
+    from oracle.detector import multihead_attention
+    E, H, n, L, S = 256, 8, 2, 7, 30
+    mha = MultiheadAttention(E, H, 0.0)
+    sd = {"x." + k: v.detach().clone() for k, v in mha.state_dict().items()}
+    mha = mha.cuda()
+    q, k, v = rnd(n, L, E), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
+    kpm = torch.zeros(n, S, dtype=torch.bool)
+    kpm[1, 25:] = True
+    out = mha(q.cuda(), k.cuda(), v.cuda(), kpm.cuda())
+    ref = multihead_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), sd, "x.", H, kpm).transpose(0, 1)
+    close(out, ref, 2e-4, "mha")
+    out2 = mha(k.cuda(), k.cuda(), v.cuda(), kpm.cuda(), qk_same=True)
+    ref2 = multihead_attention(k.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), sd, "x.", H, kpm).transpose(0, 1)
+    close(out2, ref2, 2e-4, "mha packed")
