@@ -112,8 +112,9 @@ class _Adaptive(_EpisodeModel):
         try:
             with torch.enable_grad():
                 dtheta, grads, _ = self._adapt(img, mask, create_graph=False)
-            with torch.no_grad():
+                # stays in grad mode: set_parameters only swaps tensors that require grad (reference meta_utils.py:76)
                 set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+            with torch.no_grad():
                 post = self.detector(NestedTensor(img[0:1], mask[0:1]))
         finally:
             set_parameters(self.detector, self._theta)

@@ -120,8 +120,12 @@ def test_g13_g16_meta_train_step_and_outer_update(golden):
     step = FlatOuterStep(m, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
     total = step.step()
     assert abs(float(total) - T["g16"]["total_norm"]) <= 5e-3 * T["g16"]["total_norm"]
+    ref_grads = {"detector." + k: v for k, v in T["g13"]["detector_grads"].items()}
+    ref_grads.update({"fusion." + k: v for k, v in T["g13"]["fusion_grads"].items()})
     for k, v in m.named_parameters():
         rec = T["g16"]["delta"][k]
+        if ref_grads[k] is not None and ref_grads[k]["norm"] < 1e-6:
+            continue   # rounding-noise gradient (attention key bias): Adam normalises noise to +-lr, nothing to compare
         dn = float((v.detach() - before[k]).double().norm())
         assert abs(dn - rec["norm"]) <= 2e-2 * max(rec["norm"], 1e-9) + 1e-9, (k, dn, rec["norm"])
 
