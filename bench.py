@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the Interactron per-episode hot path on MI355X (contract: see the task description / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 300] [--episodes 2]
+
+One *step* = one outer (meta-train) step of ``configs/interactron.yaml`` on this rank's batch of synthetic 5-frame
+episodes: ``model(data)`` (reference models/interactron.py:61-151 -- 3 detector forwards, GPT fusion, learned-loss
+gradient with create_graph, clipped-SGD inner step, second-order backward, first-order detector backward) followed
+by the trainer's update (reference engine/interactron_trainer.py:93-111 -- here: ONE RCCL all-reduce of the flat
+meta-gradient buffer, clip_grad_norm_ and both Adams as fused HIP launches).  Nothing is skipped inside the timed
+region; inputs are resident in HBM when it starts.
+
+Multi-GPU: one process per GPU (torchrun env), every rank runs its own ``--episodes`` episodes (weak scaling), the
+only collective is the meta-gradient all-reduce.
+
+Output: ONE JSON line on rank 0 with frames/sec (= 5 * episodes * ranks * steps / seconds), a ``roofline`` object for
+the dominant kernel (the MFMA contraction kernel behind every Linear / conv / attention product) and a
+``cpu_baseline`` object (the CPU oracle, oracle/episode.py, timed on this box's host cores on one episode).
+"""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def model_cfg(size, queries):
+    # stride-16 backbone: h = w = ceil(size / 16) after the stem/maxpool/strided stages (19 at 300, 50 at 800)
+    h = size
+    for k, s, p in ((7, 2, 3), (3, 2, 1), (3, 2, 1), (3, 2, 1)):
+        h = (h + 2 * p - k) // s + 1
+    tokens = h * h
+    return dict(TYPE="interactron", WEIGHTS="procedural", NUM_CLASSES=1235, SET_COST_CLASS=1.0, SET_COST_BBOX=5.0,
+                SET_COST_GIOU=2.0, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=5 * (tokens + queries) + 5,
+                IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
+                ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries), tokens
+
+
+def to_gpu(data, dev):
+    out = dict(data)
+    out["frames"], out["masks"] = data["frames"].to(dev), data["masks"].to(dev)
+    out["category_ids"] = [[t.to(dev) for t in ep] for ep in data["category_ids"]]
+    out["boxes"] = [[t.to(dev) for t in ep] for ep in data["boxes"]]
+    return out
+
+
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes expose 256 logical
+    CPUs behind a 16-CPU cgroup quota; running 256 threads against that quota throttles the oracle ~100x."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(cfg, size):
+    """The CPU oracle (a from-scratch PyTorch-CPU restatement of the reference path, pinned to fixtures captured from
+    the imported reference) on ONE synthetic episode of the same workload, all host cores."""
+    import torch
+    from interactron_amd.synthetic import procedural_state_dict, synthetic_episodes
+    from oracle import detector as od, episode as oe, fusion as of
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+    fus = {k[len("fusion."):]: v for k, v in
+           procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, "gpt").items()}).items()}
+    data = synthetic_episodes(1, height=size, width=size, tag="bench-r0")
+    random.seed(0)
+    t0 = time.perf_counter()
+    oe.interactron_forward(det, fus, data, cfg, {}, "gpt")
+    dt = time.perf_counter() - t0
+    return {"value": 5.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 meta-train episode (5 frames, %dx%d, fp32) through oracle/episode.py:interactron_forward, "
+                      "no warm-up, %.1f s" % (size, size, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=300, help="frame height = width (300 = reference data, 800 = north-star)")
+    ap.add_argument("--queries", type=int, default=50)
+    ap.add_argument("--episodes", type=int, default=2, help="episodes per GPU per step (reference: 16 per batch / 8 GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from interactron_amd import Config, build_model
+    from interactron_amd import _lib
+    from interactron_amd.synthetic import load_procedural, synthetic_episodes
+    from interactron_amd.trainer import FlatOuterStep, init_distributed
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    cfg, tokens = model_cfg(args.size, args.queries)
+    model = build_model(Config(**cfg))
+    load_procedural(model.fusion, "fusion.")
+    model = model.to(dev).train()
+    outer = FlatOuterStep(model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
+    data = to_gpu(synthetic_episodes(args.episodes, height=args.size, width=args.size, tag="bench-r%d" % rank), dev)
+    random.seed(1234 + rank)
+
+    def step():
+        model(data)
+        outer.step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.ix_gemm_stats(None, None, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    flops, launches = ctypes.c_double(), ctypes.c_int64()
+    lib.ix_gemm_stats(ctypes.byref(flops), ctypes.byref(launches), 1)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roofline = None
+    if not args.no_roofline:
+        # HIP-event pair around every launch of the contraction kernel on its own stream, one extra step of the same
+        # workload (kept out of the timed region so the events do not perturb `value`).
+        lib.ix_gemm_prof_enable(1)
+        lib.ix_gemm_stats(None, None, 1)
+        step()
+        torch.cuda.synchronize()
+        ms, pairs = ctypes.c_double(), ctypes.c_int64()
+        if args.gemm_csv and rank == 0:
+            lib.ix_gemm_prof_dump(args.gemm_csv.encode())
+        lib.ix_gemm_prof_read(ctypes.byref(ms), ctypes.byref(pairs))
+        pf, pl = ctypes.c_double(), ctypes.c_int64()
+        lib.ix_gemm_stats(ctypes.byref(pf), ctypes.byref(pl), 1)
+        lib.ix_gemm_prof_enable(0)
+        achieved = pf.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": int(pl.value), "gflop_per_step": pf.value / 1e9,
+                    "avg_launch_us": ms.value * 1e3 / max(1, pairs.value), "kernel_ms_per_step": ms.value}
+
+    if rank == 0:
+        frames = 5.0 * args.episodes * world * args.steps
+        line = {
+            "metric": "frames/sec (5-frame episodes)", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs/interactron.yaml meta-train step (interactron.forward + all-reduce + clip + 2x Adam), "
+                                   "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode"
+                                   % (args.episodes, args.size, args.size, args.queries, cfg["BLOCK_SIZE"]),
+                       "episodes_per_gpu": args.episodes, "frame_size": args.size, "parallelism": "dp%d" % world},
+            "gemm_gflop_per_step": flops.value / 1e9 / args.steps, "gemm_launches_per_step": launches.value / args.steps,
+            "roofline": roofline,
+            "cpu_baseline": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.size)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

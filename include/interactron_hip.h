@@ -10,7 +10,7 @@
  *     (or int64 / uint8 where stated) owned by the caller; the library never allocates or frees device memory;
  *   - all work is enqueued on `stream` (pass torch.cuda.current_stream().cuda_stream); no internal syncs;
  *   - return 0 on success, negative on error; ix_last_error() returns a thread-local message;
- *   - re-entrant, no global mutable state.
+ *   - compute entry points are re-entrant; the only global mutable state is the ix_gemm_stats/prof counters.
  */
 #ifndef INTERACTRON_HIP_H
 #define INTERACTRON_HIP_H
@@ -38,6 +38,14 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
                 int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo,
                 int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, float alpha, int tile_hint,
                 int split_k_hint, ix_stream_t stream);
+
+/* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
+ * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
+ * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */
+int ix_gemm_stats(double* flops, int64_t* launches, int reset);
+int ix_gemm_prof_enable(int on);
+int ix_gemm_prof_read(double* total_ms, int64_t* pairs);
+int ix_gemm_prof_dump(const char* path_host); /* per-launch CSV (shape, tile, split, ms); call before ix_gemm_prof_read */
 
 /* ---- convolution gather / scatter (NHWC) -- torchvision resnet50 convs, backbone.py:88-90 ------------------- */
 int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,

@@ -15,9 +15,12 @@
 // Two-level batch index b = bo*batch_inner + bi with independent (outer, inner) element strides per operand:
 // that is how a [n, T, heads*hd] activation is consumed per (frame, head) without a permute.
 //
-// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN in {128x128, 64x64}, BK = 16; each wave owns a
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM x BN x BK in {128x128x32, 64x64x64}; each wave owns a
 // (BM/2 x BN/2) sub-tile as TM x TN accumulators of 32x32.  LDS holds the tiles k-major ([k][m], [k][n]) so an
-// MFMA operand fetch is one conflict-free ds_read_b32 per lane (lane l reads row l>>5, column l&31).
+// MFMA operand fetch is one conflict-free ds_read_b32 per lane (lane l reads row l>>5, column l&31).  One K step
+// is >= 2048 MFMA cycles per wave, i.e. longer than an HBM round trip, so the register-staged prefetch of the next
+// K tile (issued before the MFMA block, written to the other LDS buffer after it) is fully hidden; two workgroups
+// per CU overlap each other's barriers.
 // Global loads are 16-byte vectors along the contiguous dimension when alignment allows, scalar otherwise.
 // Split-K (atomic f32 accumulation into a zeroed C) fills the chip for the weight-gradient shapes
 // (small M x N, K = tokens).
@@ -41,8 +44,6 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-constexpr int BK = 16;
-
 // XCD-aware, bijective remap: consecutive logical tiles land on the same XCD (same L2).
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7;
@@ -50,26 +51,40 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// LDS row pitch (floats) of a k-major [BK][BT] operand image.  Operands whose k is contiguous in HBM are written
+// transposed with ds_write_b32: an odd pitch keeps that at <= 2-way bank conflicts (free for writes); operands whose
+// m/n is contiguous are written as float4 and need a 16-byte aligned pitch.
 template <int BT, bool KC>
+struct Pitch {
+    static constexpr int value = KC ? BT + 1 : BT + 4;
+};
+
+template <int BT, int BK, bool KC>
 struct TileLoader {
     // BT x BK tile of an operand; KC = k is the contiguous dimension in global memory.
     static constexpr int NV = BT * BK / 4 / 256;  // float4 per thread
+    static constexpr int P = Pitch<BT, KC>::value;
+    static constexpr int CPR = BK / 4;            // KC: float4 chunks per tile row
+    static constexpr int Q = BT / 4;              // !KC: float4 chunks per k-row
     float4 v[NV];
+
+    __device__ __forceinline__ void coords(int i, int& tr, int& kr) const {
+        const int tid = threadIdx.x;
+        if (KC) {
+            tr = tid / CPR + (256 / CPR) * i;
+            kr = (tid % CPR) * 4;
+        } else {
+            tr = (tid % Q) * 4;
+            kr = tid / Q + (256 / Q) * i;
+        }
+    }
 
     __device__ __forceinline__ void load(const float* __restrict__ base, int64_t ld, int t0, int k0, int tmax, int kmax,
                                          bool vec) {
-        const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             int tr, kr;  // tile row (m or n) / k of the first of 4 contiguous elements
-            if (KC) {
-                tr = (tid >> 2) + 64 * i;
-                kr = (tid & 3) * 4;
-            } else {
-                constexpr int Q = BT / 4;
-                tr = (tid % Q) * 4;
-                kr = tid / Q + (256 / Q) * i;
-            }
+            coords(i, tr, kr);
             const int gt = t0 + tr, gk = k0 + kr;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KC) {
@@ -101,30 +116,28 @@ struct TileLoader {
         }
     }
 
-    // LDS image is k-major: s[k][t], row pitch BT + 4 floats.
+    // LDS image is k-major: s[k][t], row pitch P floats.
     __device__ __forceinline__ void store(float* __restrict__ s) const {
-        const int tid = threadIdx.x;
-        constexpr int P = BT + 4;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+            int tr, kr;
+            coords(i, tr, kr);
             if (KC) {
-                const int tr = (tid >> 2) + 64 * i, kr = (tid & 3) * 4;
                 s[(kr + 0) * P + tr] = v[i].x;
                 s[(kr + 1) * P + tr] = v[i].y;
                 s[(kr + 2) * P + tr] = v[i].z;
                 s[(kr + 3) * P + tr] = v[i].w;
             } else {
-                constexpr int Q = BT / 4;
-                const int tr = (tid % Q) * 4, kr = tid / Q + (256 / Q) * i;
                 *reinterpret_cast<float4*>(&s[kr * P + tr]) = v[i];
             }
         }
     }
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs p) {
-    constexpr int PA = BM + 4, PB = BN + 4;
+// 2 blocks per CU (launch bound 2 waves / SIMD): the second block's MFMAs cover this block's barrier + LDS refill.
+template <int BM, int BN, int BK, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
+    constexpr int PA = Pitch<BM, A_KC>::value, PB = Pitch<BN, B_KC>::value;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float As[2][BK * PA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * PB];
@@ -143,8 +156,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    TileLoader<BM, A_KC> la;
-    TileLoader<BN, B_KC> lb;
+    TileLoader<BM, BK, A_KC> la;
+    TileLoader<BN, BK, B_KC> lb;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -224,19 +237,91 @@ __global__ void zero_strided_kernel(float* C, int M, int N, int64_t ldc, int64_t
         c[(i / N) * ldc + (i % N)] = 0.f;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static void launch_cfg(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, true>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, true>), grid, dim3(256), 0, stream, a);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, true, false>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, true, false>), grid, dim3(256), 0, stream, a);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, true>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, true>), grid, dim3(256), 0, stream, a);
     else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, false, false>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, false>), grid, dim3(256), 0, stream, a);
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- launch statistics (bench.py's roofline object) ----------------------------------------------------------
+// Always on: executed FLOPs (2*M*N*K*batch) and launch count of the contraction kernel.  Optional (ix_gemm_prof_enable):
+// a hipEvent pair around every contraction launch on its own stream, summed by ix_gemm_prof_read after a sync --
+// that is the "average launch duration measured with HIP events" the roofline fraction is computed from.
+#include <vector>
+static double g_flops = 0.0;
+static int64_t g_launches = 0;
+static bool g_prof_on = false;
+static std::vector<hipEvent_t> g_ev;
+static size_t g_ev_used = 0;
+struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; };
+static std::vector<ProfRec> g_rec;
+
+extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
+    if (flops) *flops = g_flops;
+    if (launches) *launches = g_launches;
+    if (reset) { g_flops = 0.0; g_launches = 0; }
+    return IX_OK;
+}
+
+extern "C" int ix_gemm_prof_enable(int on) {
+    g_prof_on = on != 0;
+    g_ev_used = 0;
+    g_rec.clear();
+    return IX_OK;
+}
+
+// Writes one CSV line per profiled launch (shape, tile, split, milliseconds) -- tuning aid, host path.
+extern "C" int ix_gemm_prof_dump(const char* path) {
+    FILE* f = fopen(path, "w");
+    IX_CHECK_ARG(f != nullptr, "ix_gemm_prof_dump: cannot open %s", path);
+    fprintf(f, "M,N,K,batch,a_kc,b_kc,tile,split,ms\n");
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        const ProfRec& r = g_rec[i / 2];
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%.6f\n", r.M, r.N, r.K, r.nbatch, r.a_kc, r.b_kc, r.bm, r.split, t);
+    }
+    fclose(f);
+    return IX_OK;
+}
+
+// Sums the elapsed time of all recorded event pairs (blocks until they have completed); host pointers.
+extern "C" int ix_gemm_prof_read(double* total_ms, int64_t* pairs) {
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_ev_used; i += 2) {
+        if (hipEventSynchronize(g_ev[i + 1]) != hipSuccess) {
+            ix_set_error("ix_gemm_prof_read: hipEventSynchronize failed");
+            return IX_ERR_LAUNCH;
+        }
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (pairs) *pairs = (int64_t)(g_ev_used / 2);
+    g_ev_used = 0;
+    g_rec.clear();
+    return IX_OK;
+}
+
+static inline void prof_mark(hipStream_t stream) {
+    if (!g_prof_on) return;
+    if (g_ev_used == g_ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_ev.push_back(e);
+    }
+    hipEventRecord(g_ev[g_ev_used++], stream);
+}
 
 extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
@@ -261,25 +346,28 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     a.a_vec = sa ? 1 : 0;
     a.b_vec = sb ? 1 : 0;
 
-    // tile selection: 128x128 when it already fills the chip, else 64x64 (more workgroups for skinny shapes)
+    // tile selection: 128x128x32 when that already fills the chip, else 64x64x64 (more workgroups for skinny shapes;
+    // the deep K step keeps >= 2048 MFMA cycles per wave behind every HBM round trip)
     const int64_t t128 = (int64_t)ix_div_up(M, 128) * ix_div_up(N, 128) * nbatch;
-    int bm = (t128 >= 192) ? 128 : 64;
+    int bm = (t128 >= 200) ? 128 : 64;
     if (tile_hint == 64 || tile_hint == 128) bm = tile_hint;
+    const int bk = bm == 128 ? 32 : 64;
     a.tiles_m = ix_div_up(M, bm);
     a.tiles_n = ix_div_up(N, bm);
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n * nbatch;
+    // split-K: aim at >= 2 workgroups per CU, every split keeping at least two K steps
     int split = 1;
     if (split_k_hint > 0) {
         split = split_k_hint;
-    } else if (tiles < 128 && K >= 512) {
-        split = (int)((256 + tiles - 1) / tiles);
-        const int maxs = K / 128;
+    } else if (tiles < 384 && K >= 4 * bk) {
+        split = (int)((512 + tiles - 1) / tiles);
+        const int maxs = K / (2 * bk);
         if (split > maxs) split = maxs;
         if (split > 32) split = 32;
         if (split < 1) split = 1;
     }
-    int kps = ix_div_up(ix_div_up(K, split), BK) * BK;
-    if (kps < BK) kps = BK;
+    int kps = ix_div_up(ix_div_up(K, split), bk) * bk;
+    if (kps < bk) kps = bk;
     split = K > 0 ? ix_div_up(K, kps) : 1;
     a.split_k = split;
     a.k_per_split = kps;
@@ -288,10 +376,15 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
         hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, C, M, N, ldc, sCo, sCi, batch_inner);
     }
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
+    g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+    g_launches += 1;
+    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, bm, split});
+    prof_mark(stream);
     if (bm == 128)
-        launch_cfg<128, 128>(a, a_kcontig, b_kcontig, grid, stream);
+        launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else
-        launch_cfg<64, 64>(a, a_kcontig, b_kcontig, grid, stream);
+        launch_cfg<64, 64, 64>(a, a_kcontig, b_kcontig, grid, stream);
+    prof_mark(stream);
     IX_CHECK_LAUNCH("ix_gemm_f32");
     return IX_OK;
 }

@@ -3,6 +3,8 @@ against (a) the golden fixtures captured from the imported reference and (b) the
 
 Tolerances (fp32 kernels, f32-in MFMA = exact fmaf chains, different summation order than the CPU):
   forward tensors   atol 1e-3 * max|ref| (+1e-4)            gradients: per-tensor L2 norm within 5e-3 relative
+  (G13 second-order gradients: + 3x the reference's own float32 rounding error on that tensor, measured against the
+  float64 oracle by tests/golden/make_f64_noise.py -- e.g. 0.56 % on the scalar fusion.loss_decoder.layers.2.bias)
 ``pytest -m gpu`` on a real MI355X.
 """
 import random
@@ -97,6 +99,7 @@ def test_g11_g12_predict_and_next_action(golden, interactron_model, episode1):
 
 def test_g13_g16_meta_train_step_and_outer_update(golden):
     T = golden("golden_train.pt")
+    F64 = golden("golden_train_f64.pt")   # exact (float64 oracle) norms: bounds the reference's own float32 noise
     m = make("interactron")
     data = to_gpu(synthetic_episodes(2, tag="golden"))
     data["initial_image_path"] = ["golden/ep0", "golden/ep0"]
@@ -109,9 +112,11 @@ def test_g13_g16_meta_train_step_and_outer_update(golden):
     for k, v in T["g13"]["losses"].items():
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), (k, float(losses[k]), float(v))
     for k, p in m.detector.named_parameters():
-        check_grad(T["g13"]["detector_grads"][k], p.grad, rel=5e-3, what="g13/detector." + k)
+        check_grad(T["g13"]["detector_grads"][k], p.grad, rel=5e-3, what="g13/detector." + k,
+                   norm64=F64["detector_grads"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(T["g13"]["fusion_grads"][k], p.grad, rel=5e-3, what="g13/fusion." + k)
+        check_grad(T["g13"]["fusion_grads"][k], p.grad, rel=5e-3, what="g13/fusion." + k,
+                   norm64=F64["fusion_grads"].get(k))
     labels = {k: v.get_label(data["actions"][0][:4].tolist()) for k, v in m.path_storage.items()}
     assert labels == T["g13"]["path_labels"]
     # G16: clip_grad_norm_(all, 1.0) + Adam(detector, 1e-5) + Adam(fusion, 1e-4) as one fused flat-buffer step
@@ -140,8 +145,9 @@ def test_config1_detr(golden, episode1):
     _, losses = m(episode1)
     for k, v in O["detr_forward"]["losses"].items():
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
+    F64 = golden("golden_train_f64.pt")["configs"]["detr_forward"]["grads"]
     for k, p in m.model.named_parameters():
-        check_grad(O["detr_forward"]["grads"][k], p.grad, rel=5e-3, what="detr/" + k)
+        check_grad(O["detr_forward"]["grads"][k], p.grad, rel=5e-3, what="detr/" + k, norm64=F64.get(k))
 
 
 def test_config2_multiframe(golden, episode1):
@@ -156,10 +162,13 @@ def test_config2_multiframe(golden, episode1):
         check_record(rec, preds[k], atol=rec_tol(rec), rtol=1e-3, what="mf/" + k)
     for k, v in O["multiframe_forward"]["losses"].items():
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
+    F64 = golden("golden_train_f64.pt")["configs"]["multiframe_forward"]
     for k, p in m.detector.named_parameters():
-        check_grad(O["multiframe_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="mf/detector." + k)
+        check_grad(O["multiframe_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="mf/detector." + k,
+                   norm64=F64["detector_grads"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(O["multiframe_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="mf/fusion." + k)
+        check_grad(O["multiframe_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="mf/fusion." + k,
+                   norm64=F64["fusion_grads"].get(k))
 
 
 def test_config3_interactron_random(golden, episode1):
@@ -173,10 +182,13 @@ def test_config3_interactron_random(golden, episode1):
     preds, losses = m(episode1)
     for k, v in O["random_forward"]["losses"].items():
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
+    F64 = golden("golden_train_f64.pt")["configs"]["random_forward"]
     for k, p in m.detector.named_parameters():
-        check_grad(O["random_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="rand/detector." + k)
+        check_grad(O["random_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="rand/detector." + k,
+                   norm64=F64["detector_grads"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(O["random_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="rand/fusion." + k)
+        check_grad(O["random_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="rand/fusion." + k,
+                   norm64=F64["fusion_grads"].get(k))
 
 
 def test_oracle_parity_fresh_inputs_small_resolution():
