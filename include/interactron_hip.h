@@ -29,15 +29,16 @@ const char* ix_last_error(void);
 /* ---- contractions ------------------------------------------------------------------------------------------
  * C[b] (MxN, row-major, ldc) = alpha * A[b] (MxK) * B[b] (KxN) (+ bias[n]); b = bo*batch_inner + bi.
  * a_kcontig: A(m,k)=A[m*lda+k] else A[k*lda+m]; b_kcontig: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
- * tile_hint in {0,64,128}, split_k_hint 0 = auto.  f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32).
+ * bias_stride_outer: element stride of bias per OUTER batch index (0 = one bias shared by all batches; N = a bias per
+ * episode for episode-batched fast weights).  tile_hint in {0,64,128}, split_k_hint 0 = auto.  f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces: nn.Linear / F.linear in models/detr_models/transformer.py:148-232, models/gpt.py:39-78,
  * models/transformer.py:49-60, models/detr_models/detr.py:69-72,299-311; torch.bmm inside nn.MultiheadAttention
  * and `q @ k.transpose` / `att @ v` in models/gpt.py:48-53; conv2d of torchvision resnet50 + input_proj
  * (models/detr_models/backbone.py:88-90, detr.py:40,68) after ix_im2col_f32; and all their autograd derivatives. */
 int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int a_kcontig,
                 int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo,
-                int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, float alpha, int tile_hint,
-                int split_k_hint, ix_stream_t stream);
+                int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride_outer, float alpha,
+                int tile_hint, int split_k_hint, ix_stream_t stream);
 
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
@@ -78,12 +79,15 @@ int ix_sigmoid_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix
 int ix_sigmoid_bwd_bwd_f32(const float* G, const float* dy, const float* y, float* grad_dy, float* grad_y, int64_t n,
                            ix_stream_t stream);
 int ix_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
-int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, ix_stream_t stream);
-int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, ix_stream_t stream);
-int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, ix_stream_t stream);
+/* grouped forms: a/out [groups, rows, C], v [groups, C] (groups = episodes processed together; 1 = plain) */
+int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
+int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
+int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
 int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
 
-/* ---- wavefront-reduction kernels: softmax (transformer.py MHA, gpt.py:50) and LayerNorm --------------------- */
+/* ---- wavefront-reduction kernels: softmax (transformer.py MHA, gpt.py:50) and LayerNorm ---------------------
+ * LayerNorm: x [groups, rows, D]; gamma/beta (and dgamma/dbeta/grad_gamma, Gg/Gb) [groups, D]; groups = 1 is the plain
+ * op, groups > 1 = per-episode LayerNorm weights of the episode-batched MAML fast weights. */
 int ix_softmax_fwd_f32(const float* x, float* y, int64_t rows, int len, int64_t ld, const uint8_t* mask,
                        int rows_per_mask, int64_t mask_ld, ix_stream_t stream);
 int ix_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows, int len, int64_t ld,
@@ -91,12 +95,12 @@ int ix_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows,
 int ix_softmax_bwd_bwd_f32(const float* G, const float* y, const float* dy, float* grad_y, float* grad_dy,
                            int64_t rows, int len, int64_t ld, ix_stream_t stream);
 int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
-                         int64_t rows, int D, float eps, ix_stream_t stream);
+                         int64_t rows, int D, float eps, int groups, ix_stream_t stream);
 int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                         float* dx, float* dgamma, float* dbeta, int64_t rows, int D, ix_stream_t stream);
+                         float* dx, float* dgamma, float* dbeta, int64_t rows, int D, int groups, ix_stream_t stream);
 int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy, const float* x,
                              const float* gamma, const float* mean, const float* rstd, float* grad_dy, float* grad_x,
-                             float* grad_gamma, int64_t rows, int D, ix_stream_t stream);
+                             float* grad_gamma, int64_t rows, int D, int groups, ix_stream_t stream);
 
 /* ---- set criterion ---------------------------------------------------------------------------------------
  * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the

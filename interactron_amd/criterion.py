@@ -17,7 +17,9 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
+    def cost_matrices(self, outputs, targets):
+        """Per-image cost matrices [Q, N_i] as CPU tensors (reference matcher.py:54-73): one kernel builds the whole
+        [bs*Q, sum(N_i)] matrix, one D2H copy -- the reference's own host hand-over point."""
         bs, num_queries = outputs["pred_logits"].shape[:2]
         logits = outputs["pred_logits"].flatten(0, 1)
         boxes = outputs["pred_boxes"].flatten(0, 1)
@@ -25,12 +27,15 @@ class HungarianMatcher(nn.Module):
         tgt_bbox = torch.cat([v["boxes"] for v in targets])
         sizes = [len(v["boxes"]) for v in targets]
         if tgt_ids.numel() == 0:
-            empty = torch.empty(0, dtype=torch.int64)
-            return [(empty.clone(), empty.clone()) for _ in sizes]
-        # one kernel builds the whole [bs*Q, sum(N_i)] cost matrix; one D2H copy; LSAP per image on the host
+            return [torch.empty(num_queries, 0) for _ in sizes]
         C = ops.match_cost(logits, boxes, tgt_ids, tgt_bbox, float(self.cost_class), float(self.cost_bbox),
                            float(self.cost_giou)).view(bs, num_queries, -1).cpu()
-        return [ops.lsap(c[i]) for i, c in enumerate(C.split(sizes, -1))]
+        return [c[i].contiguous() for i, c in enumerate(C.split(sizes, -1))]
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        empty = torch.empty(0, dtype=torch.int64)
+        return [ops.lsap(c) if c.shape[1] else (empty.clone(), empty.clone()) for c in self.cost_matrices(outputs, targets)]
 
 
 def build_matcher(args):

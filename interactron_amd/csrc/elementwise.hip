@@ -194,31 +194,38 @@ extern "C" int ix_dropout_f32(const float* x, float* out, int64_t n, float p, ui
 // ---- row-vector broadcast and column reductions ----------------------------------------------------------
 __global__ void add_rowvec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ o,
                                   int64_t n, int C) {
+    // blockIdx.y = group: a/o advance by n, v by C
+    a += (int64_t)blockIdx.y * n;
+    o += (int64_t)blockIdx.y * n;
+    v += (int64_t)blockIdx.y * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) o[k] = a[k] + v[k % C];
 }
 
 // out[r, c] = a[r, c] + v[c]   (a may be null: pure broadcast of v over R rows)
-extern "C" int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, hipStream_t stream) {
+extern "C" int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, int groups,
+                                 hipStream_t stream) {
     const int64_t n = rows * C;
-    if (n <= 0) return IX_OK;
-    IX_CHECK_ARG(a && v && out, "ix_add_rowvec_f32: null pointer");
-    hipLaunchKernelGGL(add_rowvec_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, a, v, out, n, C);
+    if (n <= 0 || groups <= 0) return IX_OK;
+    IX_CHECK_ARG(a && v && out && groups <= 65535, "ix_add_rowvec_f32: bad args");
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(ix_grid_1d(n, EW_BLOCK), groups), dim3(EW_BLOCK), 0, stream, a, v, out, n, C);
     IX_CHECK_LAUNCH("ix_add_rowvec_f32");
     return IX_OK;
 }
 
 __global__ void bcast_rows_kernel(const float* __restrict__ v, float* __restrict__ o, int64_t n, int C) {
+    o += (int64_t)blockIdx.y * n;
+    v += (int64_t)blockIdx.y * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) o[k] = v[k % C];
 }
 
 // out[r, c] = v[c]  -- the adjoint of ix_colsum_f32
-extern "C" int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, hipStream_t stream) {
+extern "C" int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, int groups, hipStream_t stream) {
     const int64_t n = rows * C;
-    if (n <= 0) return IX_OK;
-    IX_CHECK_ARG(v && out, "ix_bcast_rows_f32: null pointer");
-    hipLaunchKernelGGL(bcast_rows_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, v, out, n, C);
+    if (n <= 0 || groups <= 0) return IX_OK;
+    IX_CHECK_ARG(v && out && groups <= 65535, "ix_bcast_rows_f32: bad args");
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(ix_grid_1d(n, EW_BLOCK), groups), dim3(EW_BLOCK), 0, stream, v, out, n, C);
     IX_CHECK_LAUNCH("ix_bcast_rows_f32");
     return IX_OK;
 }
@@ -229,6 +236,8 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
                               int rows_per_block) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    x += (int64_t)blockIdx.z * rows * C;   // blockIdx.z = group
+    out += (int64_t)blockIdx.z * C;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f;
@@ -236,16 +245,16 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
     unsafeAtomicAdd(&out[c], s);
 }
 
-// out[c] = sum_r x[r, c]
-extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, hipStream_t stream) {
-    IX_CHECK_ARG(out && C >= 0, "ix_colsum_f32: bad args");
-    if (C == 0) return IX_OK;
-    hipMemsetAsync(out, 0, sizeof(float) * C, stream);
+// out[g, c] = sum_r x[g, r, c]
+extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, hipStream_t stream) {
+    IX_CHECK_ARG(out && C >= 0 && groups >= 0 && groups <= 65535, "ix_colsum_f32: bad args");
+    if (C == 0 || groups == 0) return IX_OK;
+    hipMemsetAsync(out, 0, sizeof(float) * C * groups, stream);
     if (rows <= 0) return IX_OK;
     IX_CHECK_ARG(x, "ix_colsum_f32: null input");
     int rpb = 64;
     while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
-    dim3 grid(ix_div_up(C, 256), (unsigned)((rows + rpb - 1) / rpb));
+    dim3 grid(ix_div_up(C, 256), (unsigned)((rows + rpb - 1) / rpb), groups);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
     IX_CHECK_LAUNCH("ix_colsum_f32");
     return IX_OK;

@@ -36,6 +36,7 @@ struct GemmArgs {
     int M, N, K;
     int64_t lda, ldb, ldc;
     int64_t sAo, sAi, sBo, sBi, sCo, sCi;
+    int64_t sBias;
     int batch_inner;
     int split_k;
     int k_per_split;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
     const float* B = p.B + bo * p.sBo + bi * p.sBi;
     float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
     const int kbeg = ks * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
@@ -205,14 +207,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    const bool add_bias = p.bias != nullptr && ks == 0;
+    const bool add_bias = bias != nullptr && ks == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn + j * 32 + lcol;
             if (col >= p.N) continue;
-            const float bv = add_bias ? p.bias[col] : 0.f;
+            const float bv = add_bias ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
@@ -326,7 +328,8 @@ static inline void prof_mark(hipStream_t stream) {
 extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
                            int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
-                           int64_t sCi, float alpha, int tile_hint, int split_k_hint, hipStream_t stream) {
+                           int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
+                           hipStream_t stream) {
     IX_CHECK_ARG(A && B && C, "ix_gemm_f32: null operand");
     IX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 1, "ix_gemm_f32: bad dims");
     const int nbatch = batch_outer * batch_inner;
@@ -338,6 +341,7 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi;
     a.batch_inner = batch_inner;
+    a.sBias = bias_stride_outer;
     a.alpha = alpha;
     const bool sa = (sAo % 4 == 0) && (sAi % 4 == 0) && (lda % 4 == 0) && aligned16(A);
     const bool sb = (sBo % 4 == 0) && (sBi % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
@@ -346,26 +350,49 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     a.a_vec = sa ? 1 : 0;
     a.b_vec = sb ? 1 : 0;
 
-    // tile selection: 128x128x32 when that already fills the chip, else 64x64x64 (more workgroups for skinny shapes;
-    // the deep K step keeps >= 2048 MFMA cycles per wave behind every HBM round trip)
-    const int64_t t128 = (int64_t)ix_div_up(M, 128) * ix_div_up(N, 128) * nbatch;
-    int bm = (t128 >= 200) ? 128 : 64;
-    if (tile_hint == 64 || tile_hint == 128) bm = tile_hint;
+    // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
+    // shared resource: a CU that receives n workgroups spends n * ksteps * step_cycles on MFMAs, while the fixed
+    // prologue/epilogue latencies of its (up to two) co-resident workgroups overlap.  Split-K adds a zero-fill launch
+    // and s atomic passes over C.  This replaces "fill the chip" thresholds, which lose up to 2x to wave quantisation
+    // (e.g. 540 workgroups on 512 resident slots).
+    int bm = 64, split = 1;
+    {
+        double best = 1e300;
+        const int cand_tiles[2] = {128, 64};
+        const int cand_split[12] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
+        for (int ti = 0; ti < 2; ++ti) {
+            const int t = cand_tiles[ti];
+            if (tile_hint != 0 && tile_hint != t) continue;
+            const int bk = t == 128 ? 32 : 64;
+            const double step_cycles = t == 128 ? 4096.0 : 2048.0 * 1.15;  // 64x64 tiles pull 2x the L2 bytes per flop
+            const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
+            for (int si = 0; si < 12; ++si) {
+                int sp = cand_split[si];
+                if (split_k_hint > 0) sp = split_k_hint;
+                if (sp > 1 && K < 2 * bk * sp) break;
+                int kps = ix_div_up(ix_div_up(K, sp), bk) * bk;
+                if (kps < bk) kps = bk;
+                const int real_split = K > 0 ? ix_div_up(K, kps) : 1;
+                const int ksteps = ix_div_up(kps, bk);
+                const int64_t blocks = tl * real_split;
+                const int64_t per_cu = (blocks + 255) / 256;
+                double cost = (double)per_cu * ksteps * step_cycles + (double)((per_cu + 1) / 2) * 7000.0;
+                if (real_split > 1) {
+                    const double cbytes = 4.0 * (double)M * (double)N * (double)nbatch;
+                    cost += 6000.0 + cbytes / 2048.0 + cbytes * real_split / 1024.0;  // zero-fill launch + fill + atomics
+                }
+                if (cost < best) {
+                    best = cost;
+                    bm = t;
+                    split = real_split;
+                }
+                if (split_k_hint > 0) break;
+            }
+        }
+    }
     const int bk = bm == 128 ? 32 : 64;
     a.tiles_m = ix_div_up(M, bm);
     a.tiles_n = ix_div_up(N, bm);
-    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n * nbatch;
-    // split-K: aim at >= 2 workgroups per CU, every split keeping at least two K steps
-    int split = 1;
-    if (split_k_hint > 0) {
-        split = split_k_hint;
-    } else if (tiles < 384 && K >= 4 * bk) {
-        split = (int)((512 + tiles - 1) / tiles);
-        const int maxs = K / (2 * bk);
-        if (split > maxs) split = maxs;
-        if (split > 32) split = 32;
-        if (split < 1) split = 1;
-    }
     int kps = ix_div_up(ix_div_up(K, split), bk) * bk;
     if (kps < bk) kps = bk;
     split = K > 0 ? ix_div_up(K, kps) : 1;

@@ -175,6 +175,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
+    {   // blockIdx.y = group (episode): activations advance by rows*D, the affine by D
+        const int64_t go = (int64_t)blockIdx.y * rows;
+        x += go * D; y += go * D; mean += go; rstd += go;
+        gamma += (int64_t)blockIdx.y * D; beta += (int64_t)blockIdx.y * D;
+    }
     const float* xr = x + row * D;
     float v[NREG];
     float s = 0.f;
@@ -206,11 +211,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 extern "C" int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                    float* rstd, int64_t rows, int D, float eps, hipStream_t stream) {
-    if (rows <= 0) return IX_OK;
-    IX_CHECK_ARG(x && gamma && beta && y && mean && rstd, "ix_layernorm_fwd_f32: null pointer");
+                                    float* rstd, int64_t rows, int D, float eps, int groups, hipStream_t stream) {
+    if (rows <= 0 || groups <= 0) return IX_OK;
+    IX_CHECK_ARG(x && gamma && beta && y && mean && rstd && groups <= 65535, "ix_layernorm_fwd_f32: bad args");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_fwd_f32: D=%d unsupported (1..1024)", D);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), groups), block(256);
 #define LN(N) hipLaunchKernelGGL(ln_fwd_kernel<N>, grid, block, 0, stream, x, gamma, beta, y, mean, rstd, rows, D, eps)
     if (D <= 256) LN(4);
     else if (D <= 512) LN(8);
@@ -231,6 +236,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
     __shared__ float sb[ROWS_PER_BLOCK][64 * NREG];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {   // blockIdx.y = group
+        const int64_t go = (int64_t)blockIdx.y * rows;
+        dy += go * D; x += go * D; dx += go * D; mean += go; rstd += go;
+        gamma += (int64_t)blockIdx.y * D; dgamma += (int64_t)blockIdx.y * D; dbeta += (int64_t)blockIdx.y * D;
+    }
     float ag[NREG], ab[NREG];
 #pragma unroll
     for (int i = 0; i < NREG; ++i) ag[i] = ab[i] = 0.f;
@@ -280,15 +290,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                                     const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
-                                    hipStream_t stream) {
-    IX_CHECK_ARG(dgamma && dbeta, "ix_layernorm_bwd_f32: null dgamma/dbeta");
+                                    int groups, hipStream_t stream) {
+    IX_CHECK_ARG(dgamma && dbeta && groups >= 1 && groups <= 65535, "ix_layernorm_bwd_f32: bad dgamma/dbeta/groups");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_f32: D=%d unsupported (1..1024)", D);
-    hipMemsetAsync(dgamma, 0, sizeof(float) * D, stream);
-    hipMemsetAsync(dbeta, 0, sizeof(float) * D, stream);
+    hipMemsetAsync(dgamma, 0, sizeof(float) * D * groups, stream);
+    hipMemsetAsync(dbeta, 0, sizeof(float) * D * groups, stream);
     if (rows <= 0) return IX_OK;
     IX_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ix_layernorm_bwd_f32: null pointer");
     const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups))), block(256);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups)), groups), block(256);
 #define LNB(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups)
     if (D <= 256) LNB(4);
     else if (D <= 512) LNB(8);
@@ -315,6 +325,14 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
                                                          int64_t rows, int D, int row_groups) {
     __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {   // blockIdx.y = group
+        const int64_t go = (int64_t)blockIdx.y * rows;
+        if (Gx) Gx += go * D;
+        if (Gg) Gg += (int64_t)blockIdx.y * D;
+        if (Gb) Gb += (int64_t)blockIdx.y * D;
+        dy += go * D; x += go * D; grad_dy += go * D; grad_x += go * D; mean += go; rstd += go;
+        gamma += (int64_t)blockIdx.y * D; grad_gamma += (int64_t)blockIdx.y * D;
+    }
     float ag[NREG];
 #pragma unroll
     for (int i = 0; i < NREG; ++i) ag[i] = 0.f;
@@ -388,14 +406,14 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
 extern "C" int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy,
                                         const float* x, const float* gamma, const float* mean, const float* rstd,
                                         float* grad_dy, float* grad_x, float* grad_gamma, int64_t rows, int D,
-                                        hipStream_t stream) {
-    IX_CHECK_ARG(grad_gamma, "ix_layernorm_bwd_bwd_f32: null grad_gamma");
+                                        int groups, hipStream_t stream) {
+    IX_CHECK_ARG(grad_gamma && groups >= 1 && groups <= 65535, "ix_layernorm_bwd_bwd_f32: bad grad_gamma/groups");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_bwd_f32: D=%d unsupported (1..1024)", D);
-    hipMemsetAsync(grad_gamma, 0, sizeof(float) * D, stream);
+    hipMemsetAsync(grad_gamma, 0, sizeof(float) * D * groups, stream);
     if (rows <= 0) return IX_OK;
     IX_CHECK_ARG(dy && x && gamma && mean && rstd && grad_dy && grad_x, "ix_layernorm_bwd_bwd_f32: null pointer");
     const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups))), block(256);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups)), groups), block(256);
 #define LNBB(N) hipLaunchKernelGGL(ln_bwd_bwd_kernel<N>, grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups)
     if (D <= 256) LNBB(4);
     else if (D <= 512) LNBB(8);

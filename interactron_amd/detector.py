@@ -172,12 +172,14 @@ class TransformerDecoderLayer(nn.Module):
         self.dropout3 = Dropout(dropout)
 
     def forward(self, tgt, memory, memory_key, memory_key_padding_mask, query_pos):
-        """tgt [n,Q,E]; memory_key = memory + pos (shared by all layers); query_pos [Q*E] broadcast over frames."""
+        """tgt [n,Q,E]; memory_key = memory + pos (shared by all layers); query_pos [Q*E] broadcast over frames, or
+        [episodes, Q*E] (one learned query table per episode's fast weights, frames grouped by episode)."""
         n, Q, E = tgt.shape
-        qk = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos).reshape(n, Q, E)
+        groups = query_pos.shape[0] if query_pos.dim() == 2 else 1
+        qk = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
         a = self.self_attn(qk, qk, tgt, None, qk_same=True)
         tgt = self.norm1(ops.add(tgt, self.dropout1(a)))
-        q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos).reshape(n, Q, E)
+        q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
         c = self.multihead_attn(q, memory_key, memory, memory_key_padding_mask)
         tgt = self.norm2(ops.add(tgt, self.dropout2(c)))
         f = self.linear2(self.dropout(ops.Relu.apply(self.linear1(tgt))))
@@ -224,10 +226,11 @@ class Transformer(nn.Module):
 
     def forward(self, src, mask, query_embed, pos):
         n, hw, E = src.shape
-        Q = query_embed.shape[0]
+        Q = query_embed.shape[-2]
         memory = self.encoder(src, mask, pos)
         tgt = torch.zeros(n, Q, E, device=src.device, dtype=torch.float32)
-        hs = self.decoder(tgt, memory, mask, pos, query_embed.reshape(Q * E))
+        qe = query_embed.reshape(Q * E) if query_embed.dim() == 2 else query_embed.reshape(-1, Q * E)
+        hs = self.decoder(tgt, memory, mask, pos, qe)
         return hs, memory
 
 

@@ -87,6 +87,7 @@ class _Adaptive(_EpisodeModel):
     """Shared body of interactron / interactron_random: learned-loss inner step + meta-gradient."""
 
     use_policy = False
+    fusion_batched = True
 
     def _second_order_targets(self):
         """Leaves that keep a .grad from the supervisor backward: fusion parameters and the detector parameters that
@@ -120,7 +121,91 @@ class _Adaptive(_EpisodeModel):
             set_parameters(self.detector, self._theta)
         return {k: v.unsqueeze(0) for k, v in post.items()}
 
+    # Episodes of a batch are independent given theta (reference interactron.py:84 loops over them one by one).  On
+    # MI355X a single 5-frame episode leaves most of the 256 CUs idle (M = 250 decoder rows, 1805 encoder rows), so the
+    # episodes of a chunk are run TOGETHER: every adapted tensor gets a leading episode dim ([E, ...] fast weights),
+    # every Linear / conv / LayerNorm over them becomes ONE batched launch in which episode e's rows meet episode e's
+    # weights, and theta's gradient is the sum over that dim -- the same numbers as the sequential loop, E x fewer
+    # launches.  EPISODE_CHUNK (config key, default 8; 0 = the sequential reference loop) bounds E.
     def forward(self, data, train=True):
+        chunk = int(getattr(self.config, "EPISODE_CHUNK", 8))
+        if chunk <= 0:
+            return self._forward_sequential(data)
+        if not self.fusion_batched:
+            chunk = 1   # the decoder-style fusion is only defined for one sequence at a time (new_transformer.py)
+        b, s, c, w, h = data["frames"].shape
+        img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
+        det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
+        self._theta = theta = get_parameters(self.detector)
+        targets2 = self._second_order_targets()
+        lr = self.config.ADAPTIVE_LR
+        try:
+            for e0 in range(0, b, chunk):
+                E = min(chunk, b - e0)
+                ep = range(e0, e0 + E)
+                labels = [_labels(data, t) for t in ep]
+                frames, masks = img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)
+                # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
+                dtheta = [ops.BcastRows.apply(p.detach().reshape(-1), E).reshape((E,) + tuple(p.shape)).requires_grad_(True)
+                          for p in theta]
+                set_parameters(self.detector, dtheta)
+                pre = self.detector(NestedTensor(frames, masks))
+                pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
+                fusion_out = self.fusion(pre)
+                loss_map = fusion_out["loss"].reshape(E, -1)
+                learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
+                grads = torch.autograd.grad(learned, dtheta, create_graph=True, retain_graph=True, allow_unused=True)
+                set_parameters(self.detector, sgd_step(dtheta, grads, lr))
+                post = self.detector(NestedTensor(frames, masks))
+                actions_out = fusion_out["actions"].reshape(E, 4, 4)
+                total = None
+                for i, t in enumerate(ep):
+                    post_t = {k: post[k][i * s:(i + 1) * s] for k in ("pred_logits", "pred_boxes")}
+                    sup = self.criterion(post_t, labels[i], background_c=0.1)
+                    if self.use_policy:
+                        first = {k: v[[0]] for k, v in post_t.items()}
+                        gt = _weighted(self.criterion(first, [labels[i][0]], background_c=0.1))
+                        store = self.path_storage.setdefault(data["initial_image_path"][t], PathStorage())
+                        actions = data["actions"][t][:4].tolist()
+                        store.add_path(actions, torch.mean(gt).item())
+                        best = torch.tensor(store.get_label(actions), dtype=torch.long, device=gt.device)
+                        weight = torch.ones(4, device=gt.device)
+                        sup["loss_path"], _ = ops.WeightedCE.apply(actions_out[i], best, weight)
+                        sup["policy_reward"] = gt
+                    sup_losses.append({k: v.detach() for k, v in sup.items()})
+                    tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
+                    total = tl if total is None else total + tl
+                torch.autograd.backward(total, inputs=targets2)
+
+                # first-order detector update through the adapted weights (reference interactron.py:126-134); the
+                # expansion of theta is differentiable, its backward sums the per-episode gradients into theta.grad
+                attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
+                fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
+                del grads, dtheta, fusion_out, pre, post, sup, total, tl, loss_map, learned, actions_out
+                set_parameters(self.detector, fast1)
+                ridx = [random.randint(0, 4) for _ in ep]
+                sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
+                post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
+                total = None
+                for i, t in enumerate(ep):
+                    post_t = {k: post1[k][i:i + 1] for k in ("pred_logits", "pred_boxes")}
+                    dl = self.criterion(post_t, labels[i][ridx[i]:ridx[i] + 1], background_c=0.1)
+                    det_losses.append({k: v.detach() for k, v in dl.items()})
+                    total = _weighted(dl) if total is None else total + _weighted(dl)
+                    logits_out.append(post_t["pred_logits"].detach())
+                    boxes_out.append(post_t["pred_boxes"].detach())
+                total.backward()
+                del attached, fast1, post1, total
+        finally:
+            set_parameters(self.detector, theta)
+        predictions = {"pred_logits": torch.stack(logits_out, dim=0), "pred_boxes": torch.stack(boxes_out, dim=0)}
+        losses = _mean_losses(det_losses, "loss_detector")
+        losses.update(_mean_losses(sup_losses, "loss_supervisor"))
+        return predictions, losses
+
+    def _forward_sequential(self, data):
+        """The reference's own task-by-task schedule (kept for EPISODE_CHUNK: 0 and as the cross-check of the
+        episode-batched path in tests)."""
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
@@ -194,6 +279,7 @@ class interactron(_Adaptive):
 
 class interactron_random(_Adaptive):
     use_policy = False
+    fusion_batched = False
 
     def __init__(self, config):
         super().__init__()

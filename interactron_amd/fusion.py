@@ -90,7 +90,7 @@ class GPT(nn.Module):
         b, t, d = seq.shape
         assert t <= self.block_size, "Cannot forward, model block size is exhausted."
         pe = self.seq_pos_embed[:, :t, :].reshape(t * d)
-        x = self.drop(ops.AddRowVec.apply(seq.reshape(b, t * d), pe).reshape(b, t, d))
+        x = self.drop(ops.AddRowVec.apply(seq.reshape(b, t * d), pe, 1).reshape(b, t, d))
         x = self.blocks(x)
         return self.head(self.ln_f(x))
 

@@ -70,7 +70,7 @@ def _run_gemm(a, b, bias, sp):
                           out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
                           sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
                           sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
-                          sp.alpha, 0, 0, _stream())
+                          sp.N if (bias is not None and bias.dim() == 2) else 0, sp.alpha, 0, 0, _stream())
     _chk(rc, "ix_gemm_f32")
     return out
 
@@ -83,6 +83,10 @@ class Gemm(Function):
         a, b = _req(a, "gemm A"), _req(b, "gemm B")
         ctx.sp = sp
         ctx.has_bias = bias is not None
+        ctx.bias_groups = bias.shape[0] if (bias is not None and bias.dim() == 2) else 0
+        if bias is not None:
+            bias = _req(bias, "gemm bias")
+            assert bias.numel() == (sp.bo if ctx.bias_groups else 1) * sp.N, (tuple(bias.shape), sp.bo, sp.N)
         ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
         ctx.save_for_backward(a, b)
         return _run_gemm(a, b, bias, sp)
@@ -112,12 +116,22 @@ class Gemm(Function):
                              View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
                 db = Gemm.apply(dc, a, None, s)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = ColSum.apply(dc.reshape(-1, sp.N))
+            dbias = ColSum.apply(dc.reshape(ctx.bias_groups, -1, sp.N) if ctx.bias_groups else dc.reshape(-1, sp.N))
         return da, db, dbias, None
 
 
 def linear(x, weight, bias=None):
-    """y[..., o] = sum_i x[..., i] * weight[o, i] + bias[o]   (nn.Linear semantics)."""
+    """y[..., o] = sum_i x[..., i] * weight[o, i] + bias[o]   (nn.Linear semantics).
+
+    Episode-batched form: weight [E, N, K] (+ bias [E, N]) holds one set of MAML fast weights per episode and the
+    leading dim of x is E * (rows per episode); episode e's rows meet episode e's weights in ONE batched launch."""
+    if weight.dim() == 3:
+        E, N, K = weight.shape
+        assert x.shape[-1] == K and x.numel() % (E * K) == 0, (tuple(x.shape), tuple(weight.shape))
+        R = x.numel() // (E * K)
+        sp = GemmSpec(R, N, K, E, 1, View(0, K, False, R * K, 0), View(0, K, True, N * K, 0), View(0, N, False, R * N, 0),
+                      tuple(x.shape[:-1]) + (N,), 1.0)
+        return Gemm.apply(x, weight, bias, sp)
     K = x.shape[-1]
     N = weight.shape[0]
     R = x.numel() // K
@@ -158,12 +172,19 @@ def attention_apply(p, v, nbatch, heads, L, S, hd, v_ld, v_off):
 # elementwise / broadcast
 # ---------------------------------------------------------------------------------------------------------
 class ColSum(Function):
+    """[rows, C] -> [C], or grouped [G, rows, C] -> [G, C]."""
+
     @staticmethod
     def forward(ctx, x):
         x = _req(x)
-        ctx.rows = x.shape[0]
-        out = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
-        _chk(_L().ix_colsum_f32(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "ix_colsum_f32")
+        if x.dim() == 3:
+            G, rows, C = x.shape
+            out = torch.empty(G, C, device=x.device, dtype=torch.float32)
+        else:
+            (rows, C), G = x.shape, 1
+            out = torch.empty(C, device=x.device, dtype=torch.float32)
+        ctx.rows = rows
+        _chk(_L().ix_colsum_f32(x.data_ptr(), out.data_ptr(), rows, C, G, _stream()), "ix_colsum_f32")
         return out
 
     @staticmethod
@@ -172,11 +193,18 @@ class ColSum(Function):
 
 
 class BcastRows(Function):
+    """[C] -> [rows, C], or grouped [G, C] -> [G, rows, C]."""
+
     @staticmethod
     def forward(ctx, v, rows):
         v = _req(v)
-        out = torch.empty(rows, v.numel(), device=v.device, dtype=torch.float32)
-        _chk(_L().ix_bcast_rows_f32(v.data_ptr(), out.data_ptr(), rows, v.numel(), _stream()), "ix_bcast_rows_f32")
+        if v.dim() == 2:
+            G, C = v.shape
+            out = torch.empty(G, rows, C, device=v.device, dtype=torch.float32)
+        else:
+            G, C = 1, v.numel()
+            out = torch.empty(rows, C, device=v.device, dtype=torch.float32)
+        _chk(_L().ix_bcast_rows_f32(v.data_ptr(), out.data_ptr(), rows, C, G, _stream()), "ix_bcast_rows_f32")
         return out
 
     @staticmethod
@@ -226,23 +254,25 @@ class AddRowVec(Function):
     """a [R, C] + v [C] broadcast over rows (learned query / position tables shared by all frames)."""
 
     @staticmethod
-    def forward(ctx, a, v):
+    def forward(ctx, a, v, groups=1):
+        """groups > 1: v is [groups, C] (one vector per episode) and a is [groups, rows, C] flattened any way."""
         a, v = _req(a), _req(v)
-        C = v.numel()
-        assert a.shape[-1] * 0 == 0 and a.numel() % C == 0
+        C = v.numel() // groups
+        assert a.numel() % (C * groups) == 0
         out = torch.empty_like(a)
-        _chk(_L().ix_add_rowvec_f32(a.data_ptr(), v.data_ptr(), out.data_ptr(), a.numel() // C, C, _stream()),
-             "ix_add_rowvec_f32")
-        ctx.vshape = tuple(v.shape)
+        _chk(_L().ix_add_rowvec_f32(a.data_ptr(), v.data_ptr(), out.data_ptr(), a.numel() // (C * groups), C, groups,
+                                    _stream()), "ix_add_rowvec_f32")
+        ctx.vshape, ctx.groups = tuple(v.shape), groups
         return out
 
     @staticmethod
     def backward(ctx, g):
         gv = None
         if ctx.needs_input_grad[1]:
-            C = _numel(ctx.vshape)
-            gv = ColSum.apply(g.reshape(-1, C)).reshape(ctx.vshape)
-        return g, gv
+            C = _numel(ctx.vshape) // ctx.groups
+            gg = g.reshape(ctx.groups, -1, C) if ctx.groups > 1 else g.reshape(-1, C)
+            gv = ColSum.apply(gg).reshape(ctx.vshape)
+        return g, gv, None
 
 
 class Dot(Function):
@@ -551,6 +581,16 @@ def maxpool_nhwc(x, k, stride, pad):
 def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
     """x [n,H,W,Cin] NHWC, weight [Cout,Cin,KH,KW] (reference layout) -> [n,OH,OW,Cout]."""
     n, H, W, C = x.shape
+    if weight.dim() == 5:   # episode-batched fast weights [E, Cout, Cin, KH, KW]; frames of episode e are x[e*n/E:(e+1)*n/E]
+        E, Cout, Cin, KH, KW = weight.shape
+        assert Cin == C and n % E == 0
+        if KH == 1 and KW == 1 and stride == 1 and pad == 0:
+            return linear(x, weight.reshape(E, Cout, Cin))
+        g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
+        cols = Im2Col.apply(x, g)
+        w2 = weight.permute(0, 1, 3, 4, 2).reshape(E, Cout, KH * KW * Cin)
+        assert g.Kp == KH * KW * Cin, "episode-batched convs need KH*KW*Cin % 4 == 0"
+        return linear(cols.reshape(E, -1, g.Kp), w2).reshape(n, g.OH, g.OW, Cout)
     Cout, Cin, KH, KW = weight.shape
     assert Cin == C
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
@@ -617,12 +657,14 @@ class LayerNorm(Function):
     def forward(ctx, x, gamma, beta, eps):
         x, gamma, beta = _req(x), _req(gamma), _req(beta)
         D = x.shape[-1]
+        G = gamma.shape[0] if gamma.dim() == 2 else 1      # per-episode affine [G, D]: x is [G * rows, D]
         rows = x.numel() // D
+        assert rows % G == 0
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         _chk(_L().ix_layernorm_fwd_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
-                                       rstd.data_ptr(), rows, D, eps, _stream()), "ix_layernorm_fwd_f32")
+                                       rstd.data_ptr(), rows // G, D, eps, G, _stream()), "ix_layernorm_fwd_f32")
         ctx.save_for_backward(x, gamma, mean, rstd)
         return y
 
@@ -640,12 +682,13 @@ class LayerNormBwd(Function):
     def forward(ctx, dy, x, gamma, mean, rstd):
         dy = _req(dy)
         D = x.shape[-1]
+        G = gamma.shape[0] if gamma.dim() == 2 else 1
         rows = x.numel() // D
         dx = torch.empty_like(x)
-        dgamma = torch.empty(D, device=x.device, dtype=torch.float32)
+        dgamma = torch.empty_like(gamma)
         dbeta = torch.empty_like(dgamma)
         _chk(_L().ix_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                       dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, _stream()),
+                                       dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows // G, D, G, _stream()),
              "ix_layernorm_bwd_f32")
         ctx.save_for_backward(dy, x, gamma, mean, rstd)
         return dx, dgamma, dbeta
@@ -655,17 +698,18 @@ class LayerNormBwd(Function):
     def backward(ctx, Gx, Gg, Gb):
         dy, x, gamma, mean, rstd = ctx.saved_tensors
         D = x.shape[-1]
+        G = gamma.shape[0] if gamma.dim() == 2 else 1
         rows = x.numel() // D
         Gx = _req(Gx) if Gx is not None else None
         Gg = _req(Gg) if Gg is not None else None
         Gb = _req(Gb) if Gb is not None else None
         gdy, gx = torch.empty_like(x), torch.empty_like(x)
-        ggamma = torch.empty(D, device=x.device, dtype=torch.float32)
+        ggamma = torch.empty_like(gamma)
         _chk(_L().ix_layernorm_bwd_bwd_f32(Gx.data_ptr() if Gx is not None else None,
                                            Gg.data_ptr() if Gg is not None else None,
                                            Gb.data_ptr() if Gb is not None else None, dy.data_ptr(), x.data_ptr(),
                                            gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gdy.data_ptr(),
-                                           gx.data_ptr(), ggamma.data_ptr(), rows, D, _stream()),
+                                           gx.data_ptr(), ggamma.data_ptr(), rows // G, D, G, _stream()),
              "ix_layernorm_bwd_bwd_f32")
         return gdy, gx, ggamma, None, None
 

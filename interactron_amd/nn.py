@@ -65,7 +65,8 @@ class PointwiseConv2d(nn.Module):
         self.bias = _uniform((cout,), b)
 
     def forward(self, x):
-        return ops.linear(x, self.weight.reshape(self.weight.shape[0], self.weight.shape[1]), self.bias)
+        w = self.weight   # [out, in, 1, 1], or [E, out, in, 1, 1] for episode-batched fast weights
+        return ops.linear(x, w.reshape(w.shape[:-2]), self.bias)
 
 
 class MultiheadAttention(nn.Module):
