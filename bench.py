@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 
 
-def model_cfg(size, queries):
+def model_cfg(size, queries, chunk=8):
     # stride-16 backbone: h = w = ceil(size / 16) after the stem/maxpool/strided stages (19 at 300, 50 at 800)
     h = size
     for k, s, p in ((7, 2, 3), (3, 2, 1), (3, 2, 1), (3, 2, 1)):
@@ -41,7 +41,7 @@ def model_cfg(size, queries):
     return dict(TYPE="interactron", WEIGHTS="procedural", NUM_CLASSES=1235, SET_COST_CLASS=1.0, SET_COST_BBOX=5.0,
                 SET_COST_GIOU=2.0, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=5 * (tokens + queries) + 5,
                 IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
-                ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries), tokens
+                ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries, EPISODE_CHUNK=chunk), tokens
 
 
 def to_gpu(data, dev):
@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=300, help="frame height = width (300 = reference data, 800 = north-star)")
     ap.add_argument("--queries", type=int, default=50)
-    ap.add_argument("--episodes", type=int, default=2, help="episodes per GPU per step (reference: 16 per batch / 8 GPUs)")
+    ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
+    ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -120,7 +121,7 @@ def main():
     dev = torch.device("cuda", local)
     lib = _lib.load()
 
-    cfg, tokens = model_cfg(args.size, args.queries)
+    cfg, tokens = model_cfg(args.size, args.queries, args.chunk)
     model = build_model(Config(**cfg))
     load_procedural(model.fusion, "fusion.")
     model = model.to(dev).train()

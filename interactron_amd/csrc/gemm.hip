@@ -129,7 +129,16 @@ struct TileLoader {
                 s[(kr + 2) * P + tr] = v[i].z;
                 s[(kr + 3) * P + tr] = v[i].w;
             } else {
-                *reinterpret_cast<float4*>(&s[kr * P + tr]) = v[i];
+                // two 8-byte stores, not one ds_write_b128: a 16-byte store wants an aligned VGPR quad, and hipcc then
+                // recycles half of the in-flight load destinations as address temporaries, which drags the
+                // s_waitcnt vmcnt(0) of the prefetch in FRONT of the MFMA block (measured: -20 % on [K][N] operands)
+                // (volatile: hipcc would fuse the pair back into one ds_write_b128)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 lo, hi;
+                lo.x = v[i].x; lo.y = v[i].y; hi.x = v[i].z; hi.y = v[i].w;
+                typedef __attribute__((address_space(3))) volatile f32x2 lds_f32x2;
+                *(lds_f32x2*)(&s[kr * P + tr]) = lo;
+                *(lds_f32x2*)(&s[kr * P + tr + 2]) = hi;
             }
         }
     }
@@ -146,7 +155,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = p.tiles_m * p.tiles_n;
     const int tile = xcd_swizzle(blockIdx.x, nwg);
-    const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+    // Grouped tile order: the ~64 workgroups resident on one XCD cover an (up to) 8 x 8 patch of output tiles instead
+    // of a 1 x 64 strip, so per K step they pull 16 operand tiles through that XCD's L2 instead of 65.
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int m0 = (first_m + (tile % group_size) % gm) * BM, n0 = ((tile % group_size) / gm) * BN;
     const int zb = blockIdx.y;            // batch
     const int ks = blockIdx.z;            // k split
     const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
@@ -186,19 +201,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
         }
         const float* as = As[cur];
         const float* bs = Bs[cur];
+        // operand fragments are fetched one k-pair ahead of the MFMAs that consume them (separate registers), so the
+        // ds_read latency hides behind the 64-cycle matrix instructions instead of stalling every 4 of them
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = as[lrow * PA + wm + i * 32 + lcol];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bs[lrow * PB + wn + j * 32 + lcol];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const int kr = kk * 2 + lrow;
-            float a[TM], b[TN];
+            const int c = kk & 1, n = c ^ 1;
+            if (kk + 1 < BK / 2) {
+                const int kr = (kk + 1) * 2 + lrow;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[kr * PA + wm + i * 32 + lcol];
+                for (int i = 0; i < TM; ++i) a[n][i] = as[kr * PA + wm + i * 32 + lcol];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[kr * PB + wn + j * 32 + lcol];
+                for (int j = 0; j < TN; ++j) b[n][j] = bs[kr * PB + wn + j * 32 + lcol];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][i], b[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nk) {
             la.store(As[cur ^ 1]);

@@ -126,9 +126,9 @@ class _Adaptive(_EpisodeModel):
     # episodes of a chunk are run TOGETHER: every adapted tensor gets a leading episode dim ([E, ...] fast weights),
     # every Linear / conv / LayerNorm over them becomes ONE batched launch in which episode e's rows meet episode e's
     # weights, and theta's gradient is the sum over that dim -- the same numbers as the sequential loop, E x fewer
-    # launches.  EPISODE_CHUNK (config key, default 8; 0 = the sequential reference loop) bounds E.
+    # launches.  EPISODE_CHUNK (config key, default 16 = the reference BATCH_SIZE; 0 = the sequential reference loop) bounds E.
     def forward(self, data, train=True):
-        chunk = int(getattr(self.config, "EPISODE_CHUNK", 8))
+        chunk = int(getattr(self.config, "EPISODE_CHUNK", 16))
         if chunk <= 0:
             return self._forward_sequential(data)
         if not self.fusion_batched:

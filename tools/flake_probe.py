@@ -1,5 +1,5 @@
 import os, sys, random, hashlib
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.test_parity_gpu import make, to_gpu
 from interactron_amd.synthetic import synthetic_episodes

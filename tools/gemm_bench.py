@@ -2,7 +2,7 @@
 M,N,K,batch,a_kc,b_kc,count per step of 2 episodes).  Prints per-shape time / TFLOP/s and the count-weighted total.
 Usage (GPU box): python tools/gemm_bench.py [top_n] [tile_hint] [split_hint]"""
 import csv, ctypes, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from interactron_amd import _lib
 
@@ -10,8 +10,9 @@ lib = _lib.load()
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 tile_hint = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 split_hint = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+shape_file = sys.argv[4] if len(sys.argv) > 4 else "gemm_shapes_p300_e8.csv"
 shapes = [tuple(int(r[k]) for k in ("M", "N", "K", "batch", "a_kc", "b_kc", "count"))
-          for r in csv.DictReader(open(os.path.join(os.path.dirname(__file__), "gemm_shapes_p300.csv")))]
+          for r in csv.DictReader(open(os.path.join(os.path.dirname(__file__), shape_file)))]
 shapes.sort(key=lambda s: -2.0 * s[0] * s[1] * s[2] * s[3] * s[6])
 stream = torch.cuda.current_stream().cuda_stream
 tot_ms = tot_fl = 0.0
@@ -29,7 +30,7 @@ for i, (M, N, K, b, akc, bkc, cnt) in enumerate(shapes):
         assert rc == 0
     for _ in range(3):
         run()
-    reps = 20
+    reps = 10 if 2.0 * M * N * K * b > 5e9 else 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

@@ -1,6 +1,6 @@
 """Sweep tile/split hints of ix_gemm_f32 per shape: empirical best vs the library's own choice (hint 0/0)."""
 import csv, os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from interactron_amd import _lib
 lib = _lib.load()

@@ -1,6 +1,6 @@
 """Feasibility probe: capture detector forward+backward (custom ctypes HIP launches + autograd) into a HIP graph."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from interactron_amd import Config, build_model, NestedTensor

@@ -1,7 +1,7 @@
 """Host-side profile of one meta-train step (torch.profiler): which ops are launched how often, and host time.
 Usage (GPU box): python tools/host_profile.py [size] [episodes]"""
 import os, random, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from interactron_amd import Config, build_model
