@@ -30,7 +30,8 @@ const char* ix_last_error(void);
  * C[b] (MxN, row-major, ldc) = alpha * A[b] (MxK) * B[b] (KxN) (+ bias[n]); b = bo*batch_inner + bi.
  * a_kcontig: A(m,k)=A[m*lda+k] else A[k*lda+m]; b_kcontig: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
  * bias_stride_outer: element stride of bias per OUTER batch index (0 = one bias shared by all batches; N = a bias per
- * episode for episode-batched fast weights).  tile_hint in {0,64,128}, split_k_hint 0 = auto.  f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32).
+ * episode for episode-batched fast weights).  tile_hint in {0,64,128,1128 (= 128 on the bf16x6 kernel)},
+ * split_k_hint 0 = auto.  f32-in/f32-acc MFMA (v_mfma_f32_32x32x2_f32).
  * Replaces: nn.Linear / F.linear in models/detr_models/transformer.py:148-232, models/gpt.py:39-78,
  * models/transformer.py:49-60, models/detr_models/detr.py:69-72,299-311; torch.bmm inside nn.MultiheadAttention
  * and `q @ k.transpose` / `att @ v` in models/gpt.py:48-53; conv2d of torchvision resnet50 + input_proj
@@ -43,6 +44,7 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
  * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */
+int ix_gemm_set_mode(int mode); /* 0: fp32 MFMA only; 1: 128x128 tiles on the bf16x6 (3-way bf16 split) kernel */
 int ix_gemm_stats(double* flops, int64_t* launches, int reset);
 int ix_gemm_prof_enable(int on);
 int ix_gemm_prof_read(double* total_ms, int64_t* pairs);

@@ -37,6 +37,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldc;
     int64_t sAo, sAi, sBo, sBi, sCo, sCi;
     int64_t sBias;
+    int64_t extA, extB;   // elements addressable from one batch slice's base pointer (buffer bounds, bf16x6 kernel)
     int batch_inner;
     int split_k;
     int k_per_split;
@@ -257,6 +258,250 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores ("bf16x6"): every fp32 operand element is split EXACTLY into three bf16 values
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (3 x 8 = 24 significant bits)
+// on its way from the staging registers into LDS (three bf16 planes per operand), and a k-slice of 16 is the six
+// products  h.h + (h.m + m.h) + (h.l + m.m + l.h)  on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped
+// terms are below 2^-24 relative.  That is fp32-grade accuracy (fewer roundings than the k-ordered fmaf chain of
+// v_mfma_f32_32x32x2_f32: one per 16 products instead of one per product) at 6/16 of the fp32-MFMA cycle cost.
+// LDS image: [plane][row][k] with 80-byte rows (32 bf16 + 16 B pad), so an operand fragment is one conflict-free
+// ds_read_b128 per lane (lane l: row l&31, k = 8*(l>>5) .. +8).
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+constexpr int X6_BT = 128, X6_BK = 32, X6_ROWB = 80, X6_PLANE = X6_BT * X6_ROWB;
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), a in the low half
+    f32x2v v;
+    v.x = a;
+    v.y = b;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// (x0, x1) -> packed bf16 pairs of the three planes
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16(s0, s1);
+}
+
+template <bool KC>
+struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 planes in LDS
+    float4 v[4];
+
+    // Branch-free: raw buffer loads (out-of-range bytes read as 0, so tiles past the K range or past the last row are
+    // safe to request), tile rows clamped / surplus rows left as don't-care (they only feed C rows/cols that are never
+    // stored), k >= kmax zeroed by selects.  No branches means hipcc's waitcnt pass can count the three ring stages
+    // exactly (s_waitcnt vmcnt(16)) instead of draining the whole ring at every conversion.
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int t0, int k0, int tmax, int kmax, int tid) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off;
+            if (KC)     // 4 consecutive k of tile row tr: a wave instruction reads 8 rows x 128 B
+                off = min(t0 + (tid >> 3) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
+            else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
+                off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
+            const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off * 4, 0, 0));
+            v[i] = make_float4(f.x, f.y, f.z, f.w);   // untouched until store(): nothing here may wait for the data
+        }
+    }
+
+    // k0 / kmax of the tile held in v[]: elements with k >= kmax are zeroed here (selects), not at load time
+    __device__ __forceinline__ void store(unsigned char* __restrict__ planes, int tid, int k0, int kmax) const {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) u32x2 lds_u2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e0, e1, e2, e3;
+            int row;
+            if (KC) {
+                row = (tid >> 3) + 32 * i;
+                e0 = v[i].x; e1 = v[i].y; e2 = v[i].z; e3 = v[i].w;
+            } else {    // row i of this thread's 4x4 (k x row) register block
+                row = (tid >> 3) * 4 + i;
+                e0 = i == 0 ? v[0].x : i == 1 ? v[0].y : i == 2 ? v[0].z : v[0].w;
+                e1 = i == 0 ? v[1].x : i == 1 ? v[1].y : i == 2 ? v[1].z : v[1].w;
+                e2 = i == 0 ? v[2].x : i == 1 ? v[2].y : i == 2 ? v[2].z : v[2].w;
+                e3 = i == 0 ? v[3].x : i == 1 ? v[3].y : i == 2 ? v[3].z : v[3].w;
+            }
+            const int gk = k0 + (tid & 7) * 4;
+            e0 = gk + 0 < kmax ? e0 : 0.f;
+            e1 = gk + 1 < kmax ? e1 : 0.f;
+            e2 = gk + 2 < kmax ? e2 : 0.f;
+            e3 = gk + 3 < kmax ? e3 : 0.f;
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(e0, e1, h0, m0, l0);
+            split3(e2, e3, h1, m1, l1);
+            unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
+            u32x2 ph, pm, pl;
+            ph.x = h0; ph.y = h1; pm.x = m0; pm.y = m1; pl.x = l0; pl.y = l1;
+            *(lds_u2*)(dst) = ph;
+            *(lds_u2*)(dst + X6_PLANE) = pm;
+            *(lds_u2*)(dst + 2 * X6_PLANE) = pl;
+        }
+    }
+};
+
+// Wave-specialised workgroup of 8 waves (one workgroup per CU, two waves per SIMD): waves 4-7 are PRODUCERS -- they
+// stream the fp32 operand tiles from HBM through a 3-deep register ring (loads issued three K steps ahead), split them
+// into bf16 planes on the VALU and write the LDS image of tile t+1 -- while waves 0-3 are CONSUMERS that only issue
+// ds_read_b128 + MFMA on tile t.  Each SIMD therefore runs one VALU-bound and one MFMA-bound wave side by side (the
+// two pipes are independent), the LDS image is double-buffered (2 x 60 KB) and there is ONE barrier per K step.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
+    constexpr int BM = X6_BT, BN = X6_BT, BK = X6_BK;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][6 * X6_PLANE];   // per buffer: A planes h,m,l, B planes h,m,l
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = xcd_swizzle(blockIdx.x, nwg);
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int m0 = (first_m + (tile % group_size) % gm) * BM, n0 = ((tile % group_size) / gm) * BN;
+    const int zb = blockIdx.y, ks = blockIdx.z;
+    const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
+    const float* A = p.A + bo * p.sAo + bi * p.sAi;
+    const float* B = p.B + bo * p.sBo + bi * p.sBi;
+    const int kbeg = ks * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    if (wave >= 4) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(p.extA * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(p.extB * 4), 0x00020000);
+        const int lda = (int)p.lda, ldb = (int)p.ldb;
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int pt = tid - 256;
+        SplitLoader<A_KC> a0, a1, a2;   // K tile j lives in ring stage j % 3
+        SplitLoader<B_KC> b0, b1, b2;
+        // (tiles past nk are requested and stored too: they read as zeros / land in the idle LDS buffer)
+        // sched_barriers pin the order [convert+store the oldest stage] -> [refill it]: the wait in front of a conversion
+        // is then a counted vmcnt(16) (two younger stages stay in flight) instead of a drain
+#define X6_LD(SA, SB, T)                                          \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    SA.load(rA, lda, m0, kbeg + (T) * BK, p.M, kend, pt);         \
+    SB.load(rB, ldb, n0, kbeg + (T) * BK, p.N, kend, pt);         \
+    __builtin_amdgcn_sched_barrier(0);
+#define X6_ST(SA, SB, T)                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    SA.store(lds[(T) & 1], pt, kbeg + (T) * BK, kend);                     \
+    SB.store(lds[(T) & 1] + 3 * X6_PLANE, pt, kbeg + (T) * BK, kend);      \
+    __builtin_amdgcn_sched_barrier(0);
+        X6_LD(a0, b0, 0)
+        X6_LD(a1, b1, 1)
+        X6_LD(a2, b2, 2)
+        X6_ST(a0, b0, 0)
+        X6_LD(a0, b0, 3)
+        __syncthreads();   // tile 0 is visible
+        for (int kt = 0; kt < nk; kt += 3) {
+            X6_ST(a1, b1, kt + 1)
+            X6_LD(a1, b1, kt + 4)
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            X6_ST(a2, b2, kt + 2)
+            X6_LD(a2, b2, kt + 5)
+            __syncthreads();
+            if (kt + 2 >= nk) break;
+            X6_ST(a0, b0, kt + 3)
+            X6_LD(a0, b0, kt + 6)
+            __syncthreads();
+        }
+#undef X6_LD
+#undef X6_ST
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lrow = lane >> 5, lcol = lane & 31;
+
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char* ldsA = lds[kt & 1];
+        const unsigned char* ldsB = ldsA + 3 * X6_PLANE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {   // two k-slices of 16
+            bf16x8 af[2][3], bf[2][3];
+            const int koff = (s * 2 + lrow) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(ldsA + pl * X6_PLANE + (wm + i * 32 + lcol) * X6_ROWB + koff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(ldsB + pl * X6_PLANE + (wn + j * 32 + lcol) * X6_ROWB + koff);
+            // smallest terms first; consecutive MFMAs go to different accumulators
+#define X6_TERM(PA_, PB_)                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =       \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_], bf[j][PB_], acc[i][j], 0, 0, 0);
+            X6_TERM(2, 0)
+            X6_TERM(1, 1)
+            X6_TERM(0, 2)
+            X6_TERM(1, 0)
+            X6_TERM(0, 1)
+            X6_TERM(0, 0)
+#undef X6_TERM
+        }
+        __syncthreads();
+    }
+
+    const bool add_bias = bias != nullptr && ks == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + j * 32 + lcol;
+            if (col >= p.N) continue;
+            const float bv = add_bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                if (row < p.M) {
+                    const float v = p.alpha * acc[i][j][r] + bv;
+                    float* dst = C + (int64_t)row * p.ldc + col;
+                    if (p.split_k > 1)
+                        unsafeAtomicAdd(dst, v);
+                    else
+                        *dst = v;
+                }
+            }
+        }
+    }
+}
+
+static void launch_x6(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<true, true>), grid, dim3(512), 0, stream, a);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<true, false>), grid, dim3(512), 0, stream, a);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<false, true>), grid, dim3(512), 0, stream, a);
+    else
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<false, false>), grid, dim3(512), 0, stream, a);
+}
+
 __global__ void zero_strided_kernel(float* C, int M, int N, int64_t ldc, int64_t sCo, int64_t sCi, int batch_inner) {
     const int zb = blockIdx.y;
     float* c = C + (zb / batch_inner) * sCo + (zb % batch_inner) * sCi;
@@ -284,6 +529,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // a hipEvent pair around every contraction launch on its own stream, summed by ix_gemm_prof_read after a sync --
 // that is the "average launch duration measured with HIP events" the roofline fraction is computed from.
 #include <vector>
+static int g_x6 = 1;   // 1 (default): 128x128 tiles run on the bf16x6 kernel; 0: fp32 MFMA only (ix_gemm_set_mode)
 static double g_flops = 0.0;
 static int64_t g_launches = 0;
 static bool g_prof_on = false;
@@ -297,6 +543,14 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
     if (launches) *launches = g_launches;
     if (reset) { g_flops = 0.0; g_launches = 0; }
     return IX_OK;
+}
+
+// mode 0: every contraction on v_mfma_f32_32x32x2_f32; mode 1: 128x128 tiles on the bf16x6 kernel (fp32-grade accuracy
+// from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
+extern "C" int ix_gemm_set_mode(int mode) {
+    const int old = g_x6;
+    g_x6 = mode ? 1 : 0;
+    return old;
 }
 
 extern "C" int ix_gemm_prof_enable(int on) {
@@ -368,6 +622,8 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi;
     a.batch_inner = batch_inner;
     a.sBias = bias_stride_outer;
+    a.extA = a_kcontig ? (int64_t)(M - 1) * lda + K : (int64_t)(K - 1) * lda + M;
+    a.extB = b_kcontig ? (int64_t)(N - 1) * ldb + K : (int64_t)(K - 1) * ldb + N;
     a.alpha = alpha;
     const bool sa = (sAo % 4 == 0) && (sAi % 4 == 0) && (lda % 4 == 0) && aligned16(A);
     const bool sb = (sBo % 4 == 0) && (sBi % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
@@ -388,9 +644,10 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
         const int cand_split[12] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
         for (int ti = 0; ti < 2; ++ti) {
             const int t = cand_tiles[ti];
-            if (tile_hint != 0 && tile_hint != t) continue;
+            if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
             const int bk = t == 128 ? 32 : 64;
-            const double step_cycles = t == 128 ? 4096.0 : 2048.0 * 1.15;  // 64x64 tiles pull 2x the L2 bytes per flop
+            // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
+            const double step_cycles = t == 128 ? (g_x6 ? 2300.0 : 4096.0) : 2048.0 * 1.15;
             const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
             for (int si = 0; si < 12; ++si) {
                 int sp = cand_split[si];
@@ -433,7 +690,11 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     g_launches += 1;
     if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, bm, split});
     prof_mark(stream);
-    if (bm == 128)
+    // the bf16x6 kernel addresses its operands through 32-bit buffer offsets and 16-byte loads
+    const bool x6_ok = sa && sb && K > 0 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
+    if (bm == 128 && (g_x6 || tile_hint == 1128) && x6_ok)
+        launch_x6(a, a_kcontig, b_kcontig, grid, stream);
+    else if (bm == 128)
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else
         launch_cfg<64, 64, 64>(a, a_kcontig, b_kcontig, grid, stream);

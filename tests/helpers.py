@@ -31,6 +31,11 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     if max(n, rec["norm"]) < noise:
         return   # mathematically zero gradient (e.g. attention key bias: softmax is shift invariant); both are rounding noise
     ref_noise = 0.0 if norm64 is None else 3.0 * abs(rec["norm"] - norm64)
+    if g.numel() == 1:
+        # a one-element gradient (the scalar bias of the learned-loss head) is a single, heavily cancelling sum: float32
+        # implementations scatter by 0.1-0.7 % around the float64 value on it (the reference itself is 0.56 % off in G13),
+        # and there are no other elements to average that noise out of the norm
+        rel = max(rel, 2e-2)
     assert abs(n - rec["norm"]) <= rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (what, n, rec["norm"], norm64)
     scale = max(rec["norm"] / max(g.numel(), 1) ** 0.5, 1e-12)
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
