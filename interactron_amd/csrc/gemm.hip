@@ -576,6 +576,29 @@ extern "C" int ix_gemm_prof_dump(const char* path) {
     return IX_OK;
 }
 
+// Per kernel kind (index 0: fp32-MFMA kernel, 1: bf16x6 kernel): summed event time (ms), executed algorithmic FLOPs and
+// launch count of the profiled launches.  Host arrays of 2.  Call before ix_gemm_prof_read (which clears the records).
+extern "C" int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2) {
+    double ms[2] = {0, 0}, fl[2] = {0, 0};
+    int64_t n[2] = {0, 0};
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        const ProfRec& r = g_rec[i / 2];
+        const int k = r.bm == 1128 ? 1 : 0;
+        ms[k] += t;
+        fl[k] += 2.0 * r.M * (double)r.N * (double)r.K * (double)r.nbatch;
+        n[k] += 1;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (ms2) ms2[k] = ms[k];
+        if (flops2) flops2[k] = fl[k];
+        if (launches2) launches2[k] = n[k];
+    }
+    return IX_OK;
+}
+
 // Sums the elapsed time of all recorded event pairs (blocks until they have completed); host pointers.
 extern "C" int ix_gemm_prof_read(double* total_ms, int64_t* pairs) {
     double ms = 0.0;
@@ -622,8 +645,6 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi;
     a.batch_inner = batch_inner;
     a.sBias = bias_stride_outer;
-    a.extA = a_kcontig ? (int64_t)(M - 1) * lda + K : (int64_t)(K - 1) * lda + M;
-    a.extB = b_kcontig ? (int64_t)(N - 1) * ldb + K : (int64_t)(K - 1) * ldb + N;
     a.alpha = alpha;
     const bool sa = (sAo % 4 == 0) && (sAi % 4 == 0) && (lda % 4 == 0) && aligned16(A);
     const bool sb = (sBo % 4 == 0) && (sBi % 4 == 0) && (ldb % 4 == 0) && aligned16(B);
@@ -631,6 +652,13 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     // element-wise; the loader falls back per vector, so only base alignment matters here.
     a.a_vec = sa ? 1 : 0;
     a.b_vec = sb ? 1 : 0;
+    a.extA = a_kcontig ? (int64_t)(M - 1) * lda + K : (int64_t)(K - 1) * lda + M;
+    a.extB = b_kcontig ? (int64_t)(N - 1) * ldb + K : (int64_t)(K - 1) * ldb + N;
+    // bf16x6 kernel: 32-bit buffer offsets + 16-byte loads; its 3-stage ring and one-workgroup-per-CU residency only pay
+    // off once there are enough K steps to stream (attention's K = 32 / 64 products stay on the fp32 kernel, where a
+    // second resident workgroup hides the prologue)
+    const bool x6_ok = sa && sb && K >= 256 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
+    const bool want_x6 = x6_ok && (tile_hint == 1128 || (g_x6 && tile_hint != 128));
 
     // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
     // shared resource: a CU that receives n workgroups spends n * ksteps * step_cycles on MFMAs, while the fixed
@@ -647,7 +675,7 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
             if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
             const int bk = t == 128 ? 32 : 64;
             // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
-            const double step_cycles = t == 128 ? (g_x6 ? 2300.0 : 4096.0) : 2048.0 * 1.15;
+            const double step_cycles = t == 128 ? (want_x6 ? 2300.0 : 4096.0) : 2048.0 * 1.15;
             const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
             for (int si = 0; si < 12; ++si) {
                 int sp = cand_split[si];
@@ -688,11 +716,9 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
     g_launches += 1;
-    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, bm, split});
+    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, (bm == 128 && want_x6) ? 1128 : bm, split});
     prof_mark(stream);
-    // the bf16x6 kernel addresses its operands through 32-bit buffer offsets and 16-byte loads
-    const bool x6_ok = sa && sb && K > 0 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
-    if (bm == 128 && (g_x6 || tile_hint == 1128) && x6_ok)
+    if (bm == 128 && want_x6)
         launch_x6(a, a_kcontig, b_kcontig, grid, stream);
     else if (bm == 128)
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);

@@ -347,3 +347,61 @@ def test_mha_module_matches_oracle(ops):
     out2 = mha(k.cuda(), k.cuda(), v.cuda(), kpm.cuda(), qk_same=True)
     ref2 = multihead_attention(k.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), sd, "x.", H, kpm).transpose(0, 1)
     close(out2, ref2, 2e-4, "mha packed")
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_bf16x6_contraction_is_fp32_grade(ops, akc, bkc):
+    """The bf16x6 kernel (3-way bf16 split of fp32 operands, 6 bf16 MFMAs per k-slice) against float64, every operand
+    layout, ragged M/N/K, batch, bias and split-K: its error must stay at the level of the exact-fp32 MFMA kernel."""
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, b, split) in [(130, 77, 256, 2, 1), (300, 260, 1805, 2, 3), (1805, 512, 260, 1, 1)]:
+        a = (rnd(b, M, K, seed=1) * rnd(b, M, 1, seed=2).exp()).cuda()
+        w = rnd(b, K, N, seed=3).cuda()
+        bias = rnd(N, seed=4).cuda()
+        ref = (a.double() @ w.double() + bias.double())
+        scale = (a.double().abs() @ w.double().abs()) + 1e-30
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        errs = {}
+        for hint in (1128, 128):
+            C = torch.empty(b, M, N, device="cuda")
+            rc = lib.ix_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc,
+                                 K if akc else M, K if bkc else N, N, b, 1, M * K, 0, K * N, 0, M * N, 0, 0, 1.0, hint,
+                                 split, stream)
+            assert rc == 0, lib.ix_last_error()
+            errs[hint] = float(((C.double() - ref).abs() / scale).max())
+        assert errs[1128] <= 6e-7, (M, N, K, errs)               # ~ 4 ulp of fp32 relative to sum |a||b|
+        assert errs[1128] <= 2.0 * errs[128] + 1e-7, (M, N, K, errs)
+
+
+def test_episode_batched_linear_layernorm_rowvec(ops):
+    """Grouped forms used by the episode-batched fast weights: weight [E,N,K] + bias [E,N], LayerNorm affine [E,D],
+    per-episode row vector -- forward, first and second order against per-episode float64 references."""
+    E, R, K, N = 3, 37, 40, 24
+    x, w, b = rnd(E * R, K, seed=1), rnd(E, N, K, seed=2, scale=0.3), rnd(E, N, seed=3)
+    check_op(lambda x, w, b: ops.linear(x, w, b),
+             lambda x, w, b: torch.cat([F.linear(x[e * R:(e + 1) * R], w[e], b[e]) for e in range(E)]),
+             [x, w, b], name="batched linear")
+    D = 256
+    x, g, bt = rnd(E * R, D, seed=4), 1 + 0.1 * rnd(E, D, seed=5), 0.1 * rnd(E, D, seed=6)
+    check_op(lambda x, g, bt: ops.layer_norm(x, g, bt),
+             lambda x, g, bt: torch.cat([F.layer_norm(x[e * R:(e + 1) * R], (D,), g[e], bt[e]) for e in range(E)]),
+             [x, g, bt], name="batched layer_norm")
+    a, v = rnd(E * 5, 64, seed=7), rnd(E, 64, seed=8)
+    check_op(lambda a, v: ops.AddRowVec.apply(a, v, E),
+             lambda a, v: (a.reshape(E, 5, 64) + v[:, None, :]).reshape(E * 5, 64), [a, v], name="grouped add_rowvec")
+
+
+def test_episode_batched_conv(ops):
+    E, n, cin, cout = 2, 4, 8, 12
+    x = rnd(n, 9, 9, cin, seed=1)
+    for k, stride, pad, dil in [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (1, 1, 0, 1), (1, 2, 0, 1)]:
+        w = rnd(E, cout, cin, k, k, seed=2, scale=0.2)
+
+        def ref(x, w):
+            per = n // E
+            out = [F.conv2d(x[e * per:(e + 1) * per].permute(0, 3, 1, 2), w[e], None, stride, pad, dil) for e in range(E)]
+            return torch.cat(out).permute(0, 2, 3, 1)
+        check_op(lambda x, w: ops.conv2d_nhwc(x, w, stride, pad, dil), ref, [x, w], name="batched conv k%d s%d d%d" % (k, stride, dil))
