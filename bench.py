@@ -120,6 +120,7 @@ def main():
     rank, local, world = init_distributed()
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    local = local % torch.cuda.device_count()   # (IX_DIST_BACKEND=gloo smoke runs put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()

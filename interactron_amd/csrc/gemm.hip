@@ -290,9 +290,11 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     l = pack_bf16(s0, s1);
 }
 
-template <bool KC>
-struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 planes in LDS
-    float4 v[4];
+template <int BT, bool KC>
+struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
+    static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
+    static constexpr int PLANE = BT * X6_ROWB;
+    float4 v[NI];
 
     // Branch-free: raw buffer loads (out-of-range bytes read as 0, so tiles past the K range or past the last row are
     // safe to request), tile rows clamped / surplus rows left as don't-care (they only feed C rows/cols that are never
@@ -302,7 +304,7 @@ struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             int off;
             if (KC)     // 4 consecutive k of tile row tr: a wave instruction reads 8 rows x 128 B
                 off = min(t0 + (tid >> 3) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
@@ -317,8 +319,9 @@ struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 
     __device__ __forceinline__ void store(unsigned char* __restrict__ planes, int tid, int k0, int kmax) const {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) u32x2 lds_u2;
+        if (!KC && (tid >> 3) * 4 >= BT) return;   // narrow tiles: surplus row chunks were loaded as don't-care
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             float e0, e1, e2, e3;
             int row;
             if (KC) {
@@ -343,8 +346,8 @@ struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 
             u32x2 ph, pm, pl;
             ph.x = h0; ph.y = h1; pm.x = m0; pm.y = m1; pl.x = l0; pl.y = l1;
             *(lds_u2*)(dst) = ph;
-            *(lds_u2*)(dst + X6_PLANE) = pm;
-            *(lds_u2*)(dst + 2 * X6_PLANE) = pl;
+            *(lds_u2*)(dst + PLANE) = pm;
+            *(lds_u2*)(dst + 2 * PLANE) = pl;
         }
     }
 };
@@ -354,10 +357,14 @@ struct SplitLoader {   // 128 x 32 fp32 operand tile -> registers -> three bf16 
 // into bf16 planes on the VALU and write the LDS image of tile t+1 -- while waves 0-3 are CONSUMERS that only issue
 // ds_read_b128 + MFMA on tile t.  Each SIMD therefore runs one VALU-bound and one MFMA-bound wave side by side (the
 // two pipes are independent), the LDS image is double-buffered (2 x 60 KB) and there is ONE barrier per K step.
-template <bool A_KC, bool B_KC>
+// BN = 128, 64 or 32 output columns per workgroup (attention's P.V products have N = head dim = 64 / 32).
+template <int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
-    constexpr int BM = X6_BT, BN = X6_BT, BK = X6_BK;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][6 * X6_PLANE];   // per buffer: A planes h,m,l, B planes h,m,l
+    constexpr int BM = X6_BT, BK = X6_BK;
+    constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
+    // consumer wave grid: 2 x 2 waves of (64 x BN/2) for BN >= 64, 4 x 1 waves of (32 x 32) for BN = 32
+    constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];   // per buffer: A planes h,m,l, B planes h,m,l
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = p.tiles_m * p.tiles_n;
@@ -381,8 +388,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
         const int lda = (int)p.lda, ldb = (int)p.ldb;
         // ------------------------------------------------ producers ------------------------------------------------
         const int pt = tid - 256;
-        SplitLoader<A_KC> a0, a1, a2;   // K tile j lives in ring stage j % 3
-        SplitLoader<B_KC> b0, b1, b2;
+        SplitLoader<BM, A_KC> a0, a1, a2;   // K tile j lives in ring stage j % 3
+        SplitLoader<BN, B_KC> b0, b1, b2;
         // (tiles past nk are requested and stored too: they read as zeros / land in the idle LDS buffer)
         // sched_barriers pin the order [convert+store the oldest stage] -> [refill it]: the wait in front of a conversion
         // is then a counted vmcnt(16) (two younger stages stay in flight) instead of a drain
@@ -394,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
 #define X6_ST(SA, SB, T)                                                   \
     __builtin_amdgcn_sched_barrier(0);                                     \
     SA.store(lds[(T) & 1], pt, kbeg + (T) * BK, kend);                     \
-    SB.store(lds[(T) & 1] + 3 * X6_PLANE, pt, kbeg + (T) * BK, kend);      \
+    SB.store(lds[(T) & 1] + 3 * PLANE_A, pt, kbeg + (T) * BK, kend);       \
     __builtin_amdgcn_sched_barrier(0);
         X6_LD(a0, b0, 0)
         X6_LD(a1, b1, 1)
@@ -423,38 +430,38 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
     // ---------------------------------------------------- consumers ----------------------------------------------------
     float* C = p.C + bo * p.sCo + bi * p.sCi;
     const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
     const int lrow = lane >> 5, lcol = lane & 31;
 
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned char* ldsA = lds[kt & 1];
-        const unsigned char* ldsB = ldsA + 3 * X6_PLANE;
+        const unsigned char* ldsB = ldsA + 3 * PLANE_A;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {   // two k-slices of 16
-            bf16x8 af[2][3], bf[2][3];
+            bf16x8 af[TM][3], bf[TN][3];
             const int koff = (s * 2 + lrow) * 16;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(ldsA + pl * X6_PLANE + (wm + i * 32 + lcol) * X6_ROWB + koff);
+                    af[i][pl] = *reinterpret_cast<const bf16x8*>(ldsA + pl * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + koff);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(ldsB + pl * X6_PLANE + (wn + j * 32 + lcol) * X6_ROWB + koff);
+                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(ldsB + pl * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + koff);
             // smallest terms first; consecutive MFMAs go to different accumulators
-#define X6_TERM(PA_, PB_)                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =       \
+#define X6_TERM(PA_, PB_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =       \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_], bf[j][PB_], acc[i][j], 0, 0, 0);
             X6_TERM(2, 0)
             X6_TERM(1, 1)
@@ -469,9 +476,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
 
     const bool add_bias = bias != nullptr && ks == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn + j * 32 + lcol;
             if (col >= p.N) continue;
             const float bv = add_bias ? bias[col] : 0.f;
@@ -491,16 +498,27 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
     }
 }
 
-static void launch_x6(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
+template <int BN>
+static void launch_x6_bn(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<true, true>), grid, dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<BN, true, true>), grid, dim3(512), 0, stream, a);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<true, false>), grid, dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<BN, true, false>), grid, dim3(512), 0, stream, a);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<false, true>), grid, dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<BN, false, true>), grid, dim3(512), 0, stream, a);
     else
-        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<false, false>), grid, dim3(512), 0, stream, a);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_kernel<BN, false, false>), grid, dim3(512), 0, stream, a);
 }
+
+static void launch_x6(const GemmArgs& a, int bn, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
+    if (bn == 128)
+        launch_x6_bn<128>(a, a_kc, b_kc, grid, stream);
+    else if (bn == 64)
+        launch_x6_bn<64>(a, a_kc, b_kc, grid, stream);
+    else
+        launch_x6_bn<32>(a, a_kc, b_kc, grid, stream);
+}
+
 
 __global__ void zero_strided_kernel(float* C, int M, int N, int64_t ldc, int64_t sCo, int64_t sCi, int batch_inner) {
     const int zb = blockIdx.y;
@@ -702,8 +720,10 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
         }
     }
     const int bk = bm == 128 ? 32 : 64;
+    const bool use_x6 = bm == 128 && want_x6;
+    const int bn = use_x6 ? (N > 64 ? 128 : (N > 32 ? 64 : 32)) : bm;   // narrow bf16x6 tiles for N = head dim
     a.tiles_m = ix_div_up(M, bm);
-    a.tiles_n = ix_div_up(N, bm);
+    a.tiles_n = ix_div_up(N, bn);
     int kps = ix_div_up(ix_div_up(K, split), bk) * bk;
     if (kps < bk) kps = bk;
     split = K > 0 ? ix_div_up(K, kps) : 1;
@@ -716,10 +736,10 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
     g_launches += 1;
-    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, (bm == 128 && want_x6) ? 1128 : bm, split});
+    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
     prof_mark(stream);
-    if (bm == 128 && want_x6)
-        launch_x6(a, a_kcontig, b_kcontig, grid, stream);
+    if (use_x6)
+        launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);
     else if (bm == 128)
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else

@@ -16,6 +16,7 @@ that the reference computes and throws away is never formed.
 """
 import os
 import random
+import time
 
 import torch
 from torch import nn
@@ -83,8 +84,29 @@ class _EpisodeModel(nn.Module):
         self.logger = logger
 
 
+class _PhaseTimer:
+    """Optional per-phase wall-clock of one meta-train step (set ``model.phase_times = {}`` to enable): synchronises at
+    every phase boundary, so it is a diagnostic, never on in timed runs."""
+
+    def __init__(self, sink):
+        self.sink = sink
+        if sink is not None:
+            torch.cuda.synchronize()
+            self.t = time.perf_counter()
+
+    def mark(self, name):
+        if self.sink is None:
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        self.sink[name] = self.sink.get(name, 0.0) + (now - self.t) * 1e3
+        self.t = now
+
+
 class _Adaptive(_EpisodeModel):
     """Shared body of interactron / interactron_random: learned-loss inner step + meta-gradient."""
+
+    phase_times = None
 
     use_policy = False
     fusion_batched = True
@@ -141,6 +163,7 @@ class _Adaptive(_EpisodeModel):
         lr = self.config.ADAPTIVE_LR
         try:
             for e0 in range(0, b, chunk):
+                pt = _PhaseTimer(self.phase_times)
                 E = min(chunk, b - e0)
                 ep = range(e0, e0 + E)
                 labels = [_labels(data, t) for t in ep]
@@ -150,13 +173,17 @@ class _Adaptive(_EpisodeModel):
                           for p in theta]
                 set_parameters(self.detector, dtheta)
                 pre = self.detector(NestedTensor(frames, masks))
+                pt.mark("1 detector fwd (theta)")
                 pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
                 fusion_out = self.fusion(pre)
+                pt.mark("2 fusion fwd")
                 loss_map = fusion_out["loss"].reshape(E, -1)
                 learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
                 grads = torch.autograd.grad(learned, dtheta, create_graph=True, retain_graph=True, allow_unused=True)
+                pt.mark("3 learned-loss grad (create_graph)")
                 set_parameters(self.detector, sgd_step(dtheta, grads, lr))
                 post = self.detector(NestedTensor(frames, masks))
+                pt.mark("4 inner SGD + detector fwd (theta')")
                 actions_out = fusion_out["actions"].reshape(E, 4, 4)
                 total = None
                 for i, t in enumerate(ep):
@@ -175,7 +202,9 @@ class _Adaptive(_EpisodeModel):
                     sup_losses.append({k: v.detach() for k, v in sup.items()})
                     tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
                     total = tl if total is None else total + tl
+                pt.mark("5 criterion + matcher + path storage")
                 torch.autograd.backward(total, inputs=targets2)
+                pt.mark("6 second-order backward")
 
                 # first-order detector update through the adapted weights (reference interactron.py:126-134); the
                 # expansion of theta is differentiable, its backward sums the per-episode gradients into theta.grad
@@ -186,6 +215,7 @@ class _Adaptive(_EpisodeModel):
                 ridx = [random.randint(0, 4) for _ in ep]
                 sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
                 post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
+                pt.mark("7 first-order SGD + 1-frame fwd")
                 total = None
                 for i, t in enumerate(ep):
                     post_t = {k: post1[k][i:i + 1] for k in ("pred_logits", "pred_boxes")}
@@ -194,7 +224,9 @@ class _Adaptive(_EpisodeModel):
                     total = _weighted(dl) if total is None else total + _weighted(dl)
                     logits_out.append(post_t["pred_logits"].detach())
                     boxes_out.append(post_t["pred_boxes"].detach())
+                pt.mark("8 criterion (1 frame)")
                 total.backward()
+                pt.mark("9 first-order backward")
                 del attached, fast1, post1, total
         finally:
             set_parameters(self.detector, theta)
@@ -231,7 +263,9 @@ class _Adaptive(_EpisodeModel):
                     sup["policy_reward"] = gt
                 sup_losses.append({k: v.detach() for k, v in sup.items()})
                 total = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
+                pt.mark("5 criterion + matcher + path storage")
                 torch.autograd.backward(total, inputs=targets2)
+                pt.mark("6 second-order backward")
 
                 # first-order detector update through the adapted weights (reference interactron.py:126-134)
                 fast1 = sgd_step(theta, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)

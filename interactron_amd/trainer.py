@@ -40,8 +40,8 @@ def init_distributed(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank,
-                                world_size=world)
+        backend = backend or os.environ.get("IX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
 
 

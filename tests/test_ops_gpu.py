@@ -356,7 +356,8 @@ def test_bf16x6_contraction_is_fp32_grade(ops, akc, bkc):
     from interactron_amd import _lib
     lib = _lib.load()
     stream = torch.cuda.current_stream().cuda_stream
-    for (M, N, K, b, split) in [(130, 77, 256, 2, 1), (300, 260, 1805, 2, 3), (1805, 512, 260, 1, 1)]:
+    for (M, N, K, b, split) in [(130, 77, 256, 2, 1), (300, 260, 1805, 2, 3), (1805, 512, 260, 1, 1), (300, 64, 520, 2, 1),
+                                (361, 32, 361, 3, 1), (100, 20, 300, 2, 2)]:
         a = (rnd(b, M, K, seed=1) * rnd(b, M, 1, seed=2).exp()).cuda()
         w = rnd(b, K, N, seed=3).cuda()
         bias = rnd(N, seed=4).cuda()
