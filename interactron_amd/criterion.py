@@ -56,9 +56,12 @@ class SetCriterion(nn.Module):
         batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
         return batch_idx, torch.cat([src for (src, _) in indices])
 
-    def forward(self, outputs, targets, detector_out=None, background_c=0.1):
-        match_on = detector_out if detector_out is not None else outputs
-        indices = self.matcher({k: v for k, v in match_on.items() if k != "aux_outputs"}, targets)
+    def forward(self, outputs, targets, detector_out=None, background_c=0.1, indices=None):
+        """``indices``: optional precomputed matcher output for exactly these images (the episode-batched step runs the
+        matcher once over all episodes of a chunk: one cost kernel, one D2H, instead of one host sync per episode)."""
+        if indices is None:
+            match_on = detector_out if detector_out is not None else outputs
+            indices = self.matcher({k: v for k, v in match_on.items() if k != "aux_outputs"}, targets)
         logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
         dev = logits.device
         bs, Q, C = logits.shape

@@ -161,6 +161,7 @@ class _Adaptive(_EpisodeModel):
         self._theta = theta = get_parameters(self.detector)
         targets2 = self._second_order_targets()
         lr = self.config.ADAPTIVE_LR
+        actions_host = data["actions"].tolist() if self.use_policy else None   # one D2H up front
         try:
             for e0 in range(0, b, chunk):
                 pt = _PhaseTimer(self.phase_times)
@@ -185,16 +186,27 @@ class _Adaptive(_EpisodeModel):
                 post = self.detector(NestedTensor(frames, masks))
                 pt.mark("4 inner SGD + detector fwd (theta')")
                 actions_out = fusion_out["actions"].reshape(E, 4, 4)
+                # ONE matcher pass for the whole chunk (matching is per image, so the assignments are exactly those of
+                # per-episode calls): one cost kernel + one D2H instead of 2-3 host syncs per episode
+                post_lb = {k: post[k] for k in ("pred_logits", "pred_boxes")}
+                idx_all = self.criterion.matcher(post_lb, [lab for ep_labels in labels for lab in ep_labels])
+                sups, gts = [], []
+                for i, t in enumerate(ep):
+                    post_t = {k: v[i * s:(i + 1) * s] for k, v in post_lb.items()}
+                    idx = idx_all[i * s:(i + 1) * s]
+                    sups.append(self.criterion(post_t, labels[i], background_c=0.1, indices=idx))
+                    if self.use_policy:   # frame-0 loss = the reward PathStorage ranks action sequences by
+                        first = {k: v[[0]] for k, v in post_t.items()}
+                        gts.append(_weighted(self.criterion(first, [labels[i][0]], background_c=0.1, indices=idx[:1])))
+                rewards = torch.stack(gts).tolist() if self.use_policy else None   # one D2H for all episodes
                 total = None
                 for i, t in enumerate(ep):
-                    post_t = {k: post[k][i * s:(i + 1) * s] for k in ("pred_logits", "pred_boxes")}
-                    sup = self.criterion(post_t, labels[i], background_c=0.1)
+                    sup = sups[i]
                     if self.use_policy:
-                        first = {k: v[[0]] for k, v in post_t.items()}
-                        gt = _weighted(self.criterion(first, [labels[i][0]], background_c=0.1))
+                        gt = gts[i]
                         store = self.path_storage.setdefault(data["initial_image_path"][t], PathStorage())
-                        actions = data["actions"][t][:4].tolist()
-                        store.add_path(actions, torch.mean(gt).item())
+                        actions = actions_host[t][:4]
+                        store.add_path(actions, rewards[i])
                         best = torch.tensor(store.get_label(actions), dtype=torch.long, device=gt.device)
                         weight = torch.ones(4, device=gt.device)
                         sup["loss_path"], _ = ops.WeightedCE.apply(actions_out[i], best, weight)
@@ -210,16 +222,18 @@ class _Adaptive(_EpisodeModel):
                 # expansion of theta is differentiable, its backward sums the per-episode gradients into theta.grad
                 attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
                 fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
-                del grads, dtheta, fusion_out, pre, post, sup, total, tl, loss_map, learned, actions_out
+                del grads, dtheta, fusion_out, pre, post, post_lb, sups, gts, sup, total, tl, loss_map, learned, actions_out
                 set_parameters(self.detector, fast1)
                 ridx = [random.randint(0, 4) for _ in ep]
                 sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
                 post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
                 pt.mark("7 first-order SGD + 1-frame fwd")
                 total = None
+                post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
+                idx1 = self.criterion.matcher(post1_lb, [labels[i][ridx[i]] for i in range(E)])
                 for i, t in enumerate(ep):
-                    post_t = {k: post1[k][i:i + 1] for k in ("pred_logits", "pred_boxes")}
-                    dl = self.criterion(post_t, labels[i][ridx[i]:ridx[i] + 1], background_c=0.1)
+                    post_t = {k: v[i:i + 1] for k, v in post1_lb.items()}
+                    dl = self.criterion(post_t, labels[i][ridx[i]:ridx[i] + 1], background_c=0.1, indices=idx1[i:i + 1])
                     det_losses.append({k: v.detach() for k, v in dl.items()})
                     total = _weighted(dl) if total is None else total + _weighted(dl)
                     logits_out.append(post_t["pred_logits"].detach())
@@ -263,9 +277,7 @@ class _Adaptive(_EpisodeModel):
                     sup["policy_reward"] = gt
                 sup_losses.append({k: v.detach() for k, v in sup.items()})
                 total = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
-                pt.mark("5 criterion + matcher + path storage")
                 torch.autograd.backward(total, inputs=targets2)
-                pt.mark("6 second-order backward")
 
                 # first-order detector update through the adapted weights (reference interactron.py:126-134)
                 fast1 = sgd_step(theta, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)

@@ -4,8 +4,9 @@ With RNG-free (untrained) weights many of the 50 queries predict nearly the same
 (reference matcher.py:54-76) has near-ties: an O(1e-6) change of a cost entry flips which query is matched, and the
 gradient of tiny-norm tensors such as ``query_embed.weight`` moves by percents.  The assignment is therefore part of
 the fixture: this script runs the CPU oracle in float32 -- bit-identical to the imported reference, asserted below on
-the gradient norms of every scenario -- and stores, per criterion call, the indices scipy returned.  The GPU parity
-tests (tests/helpers.py:ReferenceMatching) check that the HIP path's own optimum costs the same as the recorded
+the gradient norms of every scenario -- and stores, per image (keyed by its ground truth), the assignments scipy
+returned for it (one per criterion call that saw the image).  The GPU parity
+tests (tests/helpers.py:ReferenceMatching) check that the HIP path's own optimum costs the same as the best recorded
 assignment to 1e-4 relative (i.e. that any difference is a tie, not an error) and then continue with the recorded one.
 
     python tests/golden/make_indices.py      # ~4 min on 8 cores; writes tests/golden/golden_indices.pt
@@ -26,11 +27,11 @@ from oracle import criterion as oc, episode as oe  # noqa: E402
 from tests.golden.make_f64_noise import CFG, weights  # noqa: E402
 
 
-def targets_key(targets):
+def image_key(t):
+    """Identifies one image's ground truth (labels + boxes); the same key is computed by tests/helpers.py."""
     h = hashlib.md5()
-    for t in targets:
-        h.update(t["labels"].detach().cpu().to(torch.int64).numpy().tobytes())
-        h.update(t["boxes"].detach().cpu().to(torch.float32).numpy().tobytes())
+    h.update(t["labels"].detach().cpu().to(torch.int64).numpy().tobytes())
+    h.update(t["boxes"].detach().cpu().to(torch.float32).numpy().tobytes())
     return h.hexdigest()
 
 
@@ -42,7 +43,8 @@ class Recorder:
     def __enter__(self):
         def spy(pred_logits, pred_boxes, targets, *a, **k):
             out = self.orig(pred_logits, pred_boxes, targets, *a, **k)
-            self.calls.setdefault(targets_key(targets), []).append([(r.clone(), c.clone()) for r, c in out])
+            for t, (r, c) in zip(targets, out):   # per image: every assignment the reference made for this ground truth
+                self.calls.setdefault(image_key(t), []).append((r.clone(), c.clone()))
             return out
         oc.hungarian_match = spy
         return self

@@ -42,30 +42,30 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     assert err <= 20 * rel * scale + ref_noise + 1e-9, (what, err, scale)
 
 
+def image_key(t):
+    """Identifies one image's ground truth (labels + boxes); same function as tests/golden/make_indices.py."""
+    import hashlib
+    h = hashlib.md5()
+    h.update(t["labels"].detach().cpu().to(torch.int64).numpy().tobytes())
+    h.update(t["boxes"].detach().cpu().to(torch.float32).numpy().tobytes())
+    return h.hexdigest()
+
+
 class ReferenceMatching:
     """Pins the Hungarian assignment of an end-to-end run to the one the reference made on the same inputs
-    (tests/golden/golden_indices.pt, recorded by tests/golden/make_indices.py).
+    (tests/golden/golden_indices.pt, recorded by tests/golden/make_indices.py: per image -- keyed by its ground truth --
+    every assignment the reference made for it, one per criterion call that saw the image).
 
     RNG-free weights make many queries predict nearly the same box, so the cost matrix has near-ties and float32
-    rounding noise decides which query is matched.  For every matcher call the HIP path's own optimum is computed as
-    usual; it must cost the same as the recorded assignment (both evaluated on the HIP cost matrix) to 1e-4 relative --
-    i.e. any difference is a tie, not an error -- and the recorded assignment is then returned so that the downstream
-    gradient comparison is about arithmetic, not about tie-breaking."""
+    rounding noise decides which query is matched.  For every image the HIP path's own optimum is computed as usual;
+    the recorded assignment that is cheapest under the HIP cost matrix must cost the same as that optimum to 1e-4
+    relative -- i.e. any difference is a tie, not an error -- and is then returned, so that the downstream gradient
+    comparison is about arithmetic, not about tie-breaking."""
 
     def __init__(self, recorded):
-        import hashlib
         self.recorded = recorded
-        self.seen = {}
         self.flips = 0
         self.calls = 0
-        self._md5 = hashlib.md5
-
-    def _key(self, targets):
-        h = self._md5()
-        for t in targets:
-            h.update(t["labels"].detach().cpu().to(torch.int64).numpy().tobytes())
-            h.update(t["boxes"].detach().cpu().to(torch.float32).numpy().tobytes())
-        return h.hexdigest()
 
     def __enter__(self):
         from interactron_amd import criterion as cr
@@ -76,22 +76,20 @@ class ReferenceMatching:
 
         @torch.no_grad()
         def forward(matcher, outputs, targets):
-            key = outer._key(targets)
-            n = outer.seen.get(key, 0)
-            outer.seen[key] = n + 1
-            assert key in outer.recorded and n < len(outer.recorded[key]), "matcher call without a recorded reference"
-            ref = outer.recorded[key][n]
             out = []
-            for c, (rr, rc) in zip(matcher.cost_matrices(outputs, targets), ref):
+            for c, t in zip(matcher.cost_matrices(outputs, targets), targets):
                 outer.calls += 1
+                cands = outer.recorded.get(image_key(t))
+                assert cands, "matcher saw an image without a recorded reference assignment"
                 if c.shape[1] == 0:
-                    out.append((rr, rc))
+                    out.append(cands[0])
                     continue
                 r, col = ops.lsap(c)
+                own = float(c[r, col].double().sum())
+                cost, (rr, rc) = min(((float(c[a, b].double().sum()), (a, b)) for a, b in cands), key=lambda x: x[0])
+                assert abs(cost - own) <= 1e-4 * max(1.0, abs(own)), \
+                    "assignment differs from the reference by more than a tie: %.7f vs %.7f" % (own, cost)
                 if not (torch.equal(r, rr) and torch.equal(col, rc)):
-                    own, theirs = float(c[r, col].double().sum()), float(c[rr, rc].double().sum())
-                    assert abs(theirs - own) <= 1e-4 * max(1.0, abs(own)), \
-                        "assignment differs from the reference by more than a tie: %.7f vs %.7f" % (own, theirs)
                     outer.flips += 1
                 out.append((rr, rc))
             return out
