@@ -6,9 +6,9 @@ All compute runs in the hand-written HIP kernels of ``interactron_amd/csrc`` rea
 ``include/interactron_hip.h``; importing the package is cheap, the kernel library is loaded on first use and there
 is no CPU fallback.
 """
-from .config import Config, build_model, get_config  # noqa: F401
+from .config import Config, build_evaluator, build_model, build_trainer, get_args, get_config  # noqa: F401
 
-__all__ = ["Config", "build_model", "get_config", "SetCriterion", "HungarianMatcher", "NestedTensor", "PathStorage",
+__all__ = ["Config", "build_model", "build_trainer", "build_evaluator", "get_config", "get_args", "SetCriterion", "HungarianMatcher", "NestedTensor", "PathStorage",
            "collate_fn", "manual_seed"]
 
 

@@ -53,3 +53,21 @@ def build_model(args):
     arg_check(args.TYPE, MODEL_TYPES, "model")
     from . import episode
     return getattr(episode, args.TYPE)(args)
+
+
+def build_trainer(model, args, evaluator=None):
+    """reference utils/config_utils.py:79-97 (the ``adaptive*`` types point at modules the reference does not ship)."""
+    arg_check(args.TRAINER.TYPE, ["direct_supervision", "interactron_random", "interactron"], "supervisor")
+    from . import engine
+    cls = {"direct_supervision": engine.DirectSupervisionTrainer, "interactron_random": engine.InteractronRandomTrainer,
+           "interactron": engine.InteractronTrainer}[args.TRAINER.TYPE]
+    return cls(model, args, evaluator=evaluator)
+
+
+def build_evaluator(model, args, load_checkpoint=False):
+    """reference utils/config_utils.py:100-113."""
+    arg_check(args.EVALUATOR.TYPE, ["random_policy_evaluator", "interactive_evaluator"], "evaluator")
+    from . import engine
+    cls = {"random_policy_evaluator": engine.RandomPolicyEvaluator,
+           "interactive_evaluator": engine.InteractiveEvaluator}[args.EVALUATOR.TYPE]
+    return cls(model, args, load_checkpoint=load_checkpoint)

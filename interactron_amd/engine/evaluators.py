@@ -1,0 +1,96 @@
+"""Evaluators with the reference's interface (engine/random_policy_evaluator.py, engine/interactive_evaluator.py):
+``Evaluator(model, config, load_checkpoint=False).evaluate(save_results=False) -> (AP50, AP, #tp, #fp, #fn)``; with
+``save_results=True`` the six AP numbers are printed and ``results.json`` is written under
+``EVALUATOR.OUTPUT_DIRECTORY/<timestamp>/``.  Image dumps (the reference draws boxes with PIL fonts) are left out.
+"""
+import json
+import os
+from datetime import datetime
+
+import torch
+from torch.utils.data.dataloader import DataLoader
+
+from ..datasets import InteractiveDataset, SequenceDataset, transform
+from ..storage import collate_fn
+from . import metrics
+
+
+def _to_device(data, device):
+    data["frames"] = data["frames"].to(device)
+    data["masks"] = data["masks"].to(device)
+    data["category_ids"] = [[j.to(device) for j in i] for i in data["category_ids"]]
+    data["boxes"] = [[j.to(device) for j in i] for i in data["boxes"]]
+    return data
+
+
+class _EvaluatorBase:
+    dataset_cls = SequenceDataset
+
+    def __init__(self, model, config, load_checkpoint=False, dataset=None):
+        self.model = model
+        if load_checkpoint:
+            self.model.load_state_dict(torch.load(config.EVALUATOR.CHECKPOINT, map_location=torch.device("cpu"))["model"],
+                                       strict=False)
+        self.test_dataset = dataset if dataset is not None else self.dataset_cls(
+            config.DATASET.TEST.IMAGE_ROOT, config.DATASET.TEST.ANNOTATION_ROOT, config.DATASET.TEST.MODE, transform=transform)
+        self.config = config
+        self.device = "cpu"
+        if torch.cuda.is_available():
+            self.device = torch.cuda.current_device()
+            self.model.to(self.device)
+        self.out_dir = config.EVALUATOR.OUTPUT_DIRECTORY + "/" + datetime.now().strftime("%m-%d-%Y-%H:%M:%S") + "/"
+
+    def _episodes(self):
+        """Yields (data, predictions) per evaluated batch."""
+        raise NotImplementedError
+
+    def evaluate(self, save_results=False):
+        detections = []
+        for data, predictions in self._episodes():
+            with torch.no_grad():
+                for b in range(predictions["pred_boxes"].shape[0]):   # frame 0 of every episode is scored
+                    detections += metrics.frame_detections(predictions["pred_logits"][b][0], predictions["pred_boxes"][b][0],
+                                                           data["boxes"][b][0], data["category_ids"][b][0],
+                                                           data["initial_image_path"][b])
+        n = {k: sum(1 for d in detections if d["type"] == k) for k in ("tp", "fp", "fn")}
+        if not save_results:
+            ap_50 = metrics.compute_ap(detections, nsamples=100, iou_thresholds=[0.5])
+            ap = metrics.compute_ap(detections, nsamples=100, iou_thresholds=list(metrics.np.arange(0.5, 1.0, 0.05)))
+            return ap_50, ap, n["tp"], n["fp"], n["fn"]
+        s = metrics.summarize(detections)
+        print("AP_50:", s["AP_50"], "AP_75", s["AP_75"], "AP", s["AP"], "AP_small", s["AP_small"], "AP_medium",
+              s["AP_medium"], "AP_large", s["AP_large"])
+        os.makedirs(self.out_dir, exist_ok=True)
+        with open(self.out_dir + "results.json", "w") as f:
+            json.dump({"AP_50": s["AP_50"], "detections": detections}, f)
+        return s
+
+
+class RandomPolicyEvaluator(_EvaluatorBase):
+    """Fixed test rollout (SequenceDataset test actions), ``model.predict`` on the 5 frames."""
+
+    dataset_cls = SequenceDataset
+
+    def _episodes(self):
+        cfg = self.config.EVALUATOR
+        self.model.eval()
+        loader = DataLoader(self.test_dataset, shuffle=False, pin_memory=True, batch_size=cfg.BATCH_SIZE,
+                            num_workers=cfg.NUM_WORKERS, collate_fn=collate_fn)
+        for data in loader:
+            data = _to_device(data, self.device)
+            yield data, self.model.predict(data)
+
+
+class InteractiveEvaluator(_EvaluatorBase):
+    """The learned policy picks the four moves (``model.get_next_action``), then ``model.predict`` on the rollout."""
+
+    dataset_cls = InteractiveDataset
+
+    def _episodes(self):
+        env = self.test_dataset
+        for _ in range(len(env)):
+            self.model.eval()
+            data = _to_device(env.reset(), self.device)
+            for _ in range(4):
+                data = _to_device(env.step(self.model.get_next_action(data)), self.device)
+            yield data, self.model.predict(data)

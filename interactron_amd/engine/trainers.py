@@ -1,0 +1,180 @@
+"""Training loops with the reference's interface (engine/interactron_trainer.py, interactron_random_trainer.py,
+direct_supervision_trainer.py): ``Trainer(model, config, evaluator=None).train()``.
+
+Same schedule as the reference: an evaluation first, then ``MAX_EPOCHS - 1`` epochs of [train epoch, test-loss epoch +
+evaluator, log], a uniform running average of the last ``SAVE_WINDOW`` epochs' ``state_dict`` saved as
+``{"model": ...}`` (``detector.pt``).  What differs is the MI355X-native update: instead of ``nn.DataParallel`` +
+``clip_grad_norm_`` + two ``torch.optim.Adam`` it is one process per GPU, every rank running the episodes
+``rank::world`` of a batch, ONE RCCL all-reduce of the flat gradient buffer and the fused clip + Adam kernels
+(``interactron_amd.trainer.FlatOuterStep``) -- numerically the same update (fixture G16).
+"""
+import math
+import os
+from datetime import datetime
+
+import numpy as np
+import torch
+from torch.utils.data.dataloader import DataLoader
+
+from ..datasets import SequenceDataset, train_transform, transform
+from ..storage import collate_fn
+from ..trainer import FlatOuterStep, init_distributed, shard_batch
+from .logging import TBLogger
+
+
+def _to_device(data, device):
+    data["frames"] = data["frames"].to(device)
+    data["masks"] = data["masks"].to(device)
+    data["category_ids"] = [[j.to(device) for j in i] for i in data["category_ids"]]
+    data["boxes"] = [[j.to(device) for j in i] for i in data["boxes"]]
+    return data
+
+
+class _TrainerBase:
+    fixed_lrs = None          # InteractronRandomTrainer hard-codes 1e-5 / 1e-4 (interactron_random_trainer.py:70-71)
+    pass_train_flag = False   # ... and calls model(data, train=is_train) (:91)
+
+    def __init__(self, model, config, evaluator=None, train_dataset=None, test_dataset=None):
+        self.model, self.config, self.evaluator = model, config, evaluator
+        self.rank, self.local_rank, self.world = init_distributed()
+        self.out_dir = os.path.join(config.TRAINER.OUTPUT_DIRECTORY, datetime.now().strftime("%m-%d-%Y:%H:%M:%S"))
+        os.makedirs(self.out_dir, exist_ok=True)
+        self.logger = TBLogger(os.path.join(self.out_dir, "logs"))
+        self.model.set_logger(self.logger)
+        self.checkpoint_path = os.path.join(self.out_dir, "detector.pt")
+        self.saved_checkpoints = None
+        d = config.DATASET
+        self.train_dataset = train_dataset if train_dataset is not None else SequenceDataset(
+            d.TRAIN.IMAGE_ROOT, d.TRAIN.ANNOTATION_ROOT, d.TRAIN.MODE, transform=train_transform)
+        self.test_dataset = test_dataset if test_dataset is not None else SequenceDataset(
+            d.TEST.IMAGE_ROOT, d.TEST.ANNOTATION_ROOT, d.TEST.MODE, transform=transform)
+        assert torch.cuda.is_available(), "interactron_amd trains on the HIP kernels only (no CPU path)"
+        torch.cuda.set_device(self.local_rank % torch.cuda.device_count())
+        self.device = torch.cuda.current_device()
+        self.model.to(self.device)
+
+    # ---- checkpoint averaging (reference :48-65) ----------------------------------------------------------
+    def record_checkpoint(self, w=1.0):
+        sd = self.model.state_dict()
+        if self.saved_checkpoints is None:
+            self.saved_checkpoints = {k: w * v for k, v in sd.items()}
+        else:
+            for k, v in sd.items():
+                self.saved_checkpoints[k] += w * v
+
+    def save_checkpoint(self):
+        sd = self.saved_checkpoints if self.saved_checkpoints is not None else self.model.state_dict()
+        if self.rank == 0:
+            torch.save({"model": sd}, self.checkpoint_path)
+
+    # ---- loss bookkeeping ------------------------------------------------------------------------------------
+    def _total_loss(self, losses):
+        det = losses["loss_detector_ce"] + 5 * losses["loss_detector_giou"] + 2 * losses["loss_detector_bbox"]
+        sup = losses["loss_supervisor_ce"] + 5 * losses["loss_supervisor_giou"] + 2 * losses["loss_supervisor_bbox"]
+        return det + sup
+
+    def _make_outer(self, cfg):
+        det_lr, fus_lr = self.fixed_lrs if self.fixed_lrs else (cfg.DETECTOR_LR, cfg.SUPERVISOR_LR)
+        return FlatOuterStep(self.model, detector_lr=det_lr, fusion_lr=fus_lr, max_norm=cfg.GRAD_NORM_CLIP)
+
+    def _base_lr(self, cfg):
+        return self.fixed_lrs[1] if self.fixed_lrs else cfg.SUPERVISOR_LR
+
+    def _tokens_per_batch(self, data):
+        return data["frames"].shape[0] * data["frames"].shape[1]
+
+    def train(self):
+        model, cfg = self.model, self.config.TRAINER
+        outer = self._make_outer(cfg)
+        model.train()
+        state = {"epoch": 0}
+
+        def run_epoch(split):
+            is_train = split == "train"
+            loader = DataLoader(self.train_dataset if is_train else self.test_dataset, shuffle=is_train, pin_memory=True,
+                                batch_size=cfg.BATCH_SIZE, num_workers=cfg.NUM_WORKERS, collate_fn=collate_fn)
+            tag = "Train" if is_train else "Test"
+            loss_list = []
+            for it, data in enumerate(loader):
+                data = _to_device(shard_batch(data, self.rank, self.world), self.device)
+                if data["frames"].shape[0] == 0:    # a short last batch can leave a rank without episodes: it still
+                    if is_train:                    # has to take part in the gradient all-reduce
+                        outer.step()
+                    continue
+                _, losses = model(data, train=is_train) if self.pass_train_flag else model(data)
+                for name, comp in losses.items():
+                    self.logger.add_value("{}/{}".format(tag, name), comp.mean())
+                total = self._total_loss(losses)
+                self.logger.add_value("{}/Total Loss".format(tag), total.mean())
+                loss_list.append(total.item())
+                if is_train:
+                    outer.step()   # all-reduce(SUM) of the flat grads + clip_grad_norm_ + Adam x2, grads zeroed
+                    lr = self._base_lr(cfg)
+                    if cfg.LR_DECAY:
+                        self.tokens += self._tokens_per_batch(data) * self.world
+                        if self.tokens < cfg.WARMUP_TOKENS:
+                            mult = float(self.tokens) / float(max(1, cfg.WARMUP_TOKENS))
+                        else:
+                            prog = float(self.tokens - cfg.WARMUP_TOKENS) / float(max(1, cfg.FINAL_TOKENS - cfg.WARMUP_TOKENS))
+                            mult = max(0.1, 0.5 * (1.0 + math.cos(math.pi * prog)))
+                        lr = lr * mult
+                        outer.lrs[-1] = lr          # the reference decays only the supervisor (fusion) optimiser
+                    self.logger.add_value("{}/LR".format(tag), lr)
+                    if self.rank == 0 and it % 10 == 0:
+                        print("epoch %d iter %d: train loss %.5f. lr %e" % (state["epoch"], it, float(np.mean(loss_list)), lr))
+            if not is_train:
+                return float(np.mean(loss_list)) if loss_list else float("nan")
+
+        def run_evaluation():
+            run_epoch("test")   # (the reference's test epoch also back-propagates inside model(); those grads are dropped)
+            outer.flat.grads.zero_()
+            if self.evaluator is None:
+                return None
+            m50, m, tps, fps, fns = self.evaluator.evaluate(save_results=False)
+            for k, v in (("TP", tps), ("FP", fps), ("FN", fns), ("mAP_50", m50), ("mAP", m)):
+                self.logger.add_value("Test/" + k, float(v))
+            return m
+
+        self.tokens = 0
+        run_evaluation()
+        self.logger.log_values()
+        for epoch in range(1, cfg.MAX_EPOCHS):
+            state["epoch"] = epoch
+            run_epoch("train")
+            if self.test_dataset is not None and self.evaluator is not None:
+                run_evaluation()
+            self.logger.log_values()
+            if self.test_dataset is not None and cfg.MAX_EPOCHS - epoch <= cfg.SAVE_WINDOW:
+                self.record_checkpoint(w=1 / cfg.SAVE_WINDOW)
+        self.save_checkpoint()
+
+
+class InteractronTrainer(_TrainerBase):
+    """reference engine/interactron_trainer.py:22-163."""
+
+
+class InteractronRandomTrainer(_TrainerBase):
+    """reference engine/interactron_random_trainer.py (fixed learning rates, ``model(data, train=...)``)."""
+
+    fixed_lrs = (1e-5, 1e-4)
+    pass_train_flag = True
+
+
+class DirectSupervisionTrainer(_TrainerBase):
+    """reference engine/direct_supervision_trainer.py: one Adam over ``LEARNING_RATE`` (configs 1 and 2), loss
+    1*CE + 5*L1 + 2*GIoU, LR schedule counted in batches."""
+
+    def _total_loss(self, losses):
+        return losses["loss_detector_ce"] + 5 * losses["loss_detector_bbox"] + 2 * losses["loss_detector_giou"]
+
+    def _make_outer(self, cfg):
+        # one optimiser over every trainable tensor (``detr`` holds its network as ``.model``, ``detr_multiframe`` as
+        # ``.detector`` + ``.fusion``)
+        return FlatOuterStep(self.model, max_norm=cfg.GRAD_NORM_CLIP, groups=[list(self.model.parameters())],
+                             lrs=[cfg.LEARNING_RATE])
+
+    def _base_lr(self, cfg):
+        return cfg.LEARNING_RATE
+
+    def _tokens_per_batch(self, data):
+        return data["frames"].shape[0]

@@ -80,12 +80,18 @@ class FlatBuffers:
 class FlatOuterStep:
     """clip_grad_norm_(all, max_norm) + Adam(detector) + Adam(fusion) on the flat buffers (HIP kernels)."""
 
-    def __init__(self, model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8):
-        groups = [list(model.detector.parameters())]
-        self.lrs = [detector_lr]
-        if hasattr(model, "fusion"):
-            groups.append(list(model.fusion.parameters()))
-            self.lrs.append(fusion_lr)
+    def __init__(self, model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8, groups=None,
+                 lrs=None):
+        """Default: Adam(detector, detector_lr) + Adam(fusion, fusion_lr) like the interactron trainers; ``groups`` /
+        ``lrs`` give explicit parameter lists and learning rates (direct-supervision trainer: one group)."""
+        if groups is not None:
+            self.lrs = list(lrs)
+        else:
+            groups = [list(model.detector.parameters())]
+            self.lrs = [detector_lr]
+            if hasattr(model, "fusion"):
+                groups.append(list(model.fusion.parameters()))
+                self.lrs.append(fusion_lr)
         self.flat = FlatBuffers(groups)
         self.m = torch.zeros_like(self.flat.params)
         self.v = torch.zeros_like(self.flat.params)

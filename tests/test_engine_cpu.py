@@ -1,0 +1,141 @@
+"""Host-side "next" rows: AP metric and matching against fixtures captured from the reference's own
+functions (G15, tests/golden/make_golden_eval.py), the dataset walk / transforms on a tiny synthetic dataset on disk,
+the scalar logger and the factories.  No GPU needed."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from interactron_amd import Config
+from interactron_amd.constants import ACTIONS
+from interactron_amd.datasets import InteractiveDataset, SequenceDataset, train_transform, transform
+from interactron_amd.engine import metrics
+from interactron_amd.storage import collate_fn
+
+
+def test_g15_ap_metric_matches_reference(golden):
+    G = golden("golden_eval.pt")
+    ious = list(np.arange(0.5, 1.0, 0.05))
+    for rec in G["ap"]:
+        d = rec["detections"]
+        assert metrics.compute_ap(list(d), 100, [0.5]) == pytest.approx(rec["ap50"], abs=1e-12)
+        assert metrics.compute_ap(list(d), 100, [0.75]) == pytest.approx(rec["ap75"], abs=1e-12)
+        assert metrics.compute_ap(list(d), 100, ious) == pytest.approx(rec["ap"], abs=1e-12)
+        assert metrics.compute_ap(list(d), 100, ious, 0.0, 32 ** 2 / 300 ** 2) == pytest.approx(rec["ap_small"], abs=1e-12)
+        assert metrics.compute_ap(list(d), 100, ious, 32 ** 2 / 300 ** 2, 96 ** 2 / 300 ** 2) == \
+            pytest.approx(rec["ap_medium"], abs=1e-12)
+        assert metrics.compute_cat_ap(list(d), 100, ious) == pytest.approx(rec["cat_ap"], abs=1e-12)
+        p, r = metrics.compute_pr(list(d), 100, 0.5)
+        assert p == pytest.approx(rec["pr"][0]) and r == pytest.approx(rec["pr"][1])
+        assert len(d) == len(rec["detections"])   # the caller's list is not consumed
+
+
+def test_g15_prediction_matching_matches_reference(golden):
+    for rec in golden("golden_eval.pt")["match"]:
+        bi, bx = metrics.match_predictions_to_detections(rec["ious"].clone())
+        assert torch.equal(bx, rec["best_idx"])
+        torch.testing.assert_close(bi, rec["best_ious"])
+
+
+def test_nms_and_box_iou():
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.5], [50, 50, 60, 60]], dtype=torch.float)
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.95, 0.1])
+    keep = metrics.nms(boxes, scores, 0.5)
+    assert keep.tolist() == [3, 2, 4]          # 0 and 1 overlap box 3 (IoU > 0.5)
+    iou = metrics.box_iou(boxes[:2], boxes[:3])
+    assert iou[0, 0] == pytest.approx(1.0) and iou[0, 2] == 0.0
+    assert iou[0, 1] == pytest.approx(81.0 / 119.0)
+    assert metrics.nms(boxes[:0], scores[:0], 0.5).numel() == 0
+
+
+def test_frame_detections_bookkeeping():
+    """One image: a matched prediction (tp), a duplicate of it (fp after NMS keeps both at IoU<=0.5? no: suppressed), a
+    missed ground-truth box (fn), a THOR-class prediction with no ground truth (fp) and a non-THOR one (ignored)."""
+    Q, C = 6, 1236
+    logits = torch.full((Q, C), -10.0)
+    logits[:, 1235] = 0.0                                   # default: background
+    boxes = torch.tensor([[0.3, 0.3, 0.2, 0.2]] * Q)
+    logits[0, 11] = 8.0                                     # tp for gt class 11
+    logits[1, 11] = 7.0; boxes[1] = torch.tensor([0.31, 0.3, 0.2, 0.2])   # near-duplicate: removed by NMS
+    logits[2, 18] = 6.0; boxes[2] = torch.tensor([0.7, 0.7, 0.1, 0.1])    # THOR class without ground truth -> fp
+    logits[3, 5] = 6.0; boxes[3] = torch.tensor([0.7, 0.2, 0.1, 0.1])     # non-THOR class without ground truth -> dropped
+    gt_boxes = torch.tensor([[0.3, 0.3, 0.2, 0.2], [0.8, 0.2, 0.1, 0.1]])
+    gt_cats = torch.tensor([11, 22])
+    dets = metrics.frame_detections(logits, boxes, gt_boxes, gt_cats, "img")
+    kinds = sorted((d["type"], d["pred_cat"]) for d in dets)
+    assert kinds == [("fn", 22), ("fp", 18), ("tp", 11)]
+    tp = [d for d in dets if d["type"] == "tp"][0]
+    assert tp["iou"] == pytest.approx(1.0, abs=1e-5) and tp["area"] == pytest.approx(0.04, rel=1e-4)
+
+
+@pytest.fixture()
+def tiny_dataset(tmp_path):
+    """Two scenes, 3 states each, 40x30 JPEGs, in the reference annotation schema (masks keep the ORIGINAL image size,
+    reference sequence_dataset.py:55-56 -- real data is 300x300, so only the GPU smoke test needs full-size images)."""
+    random.seed(0)
+    root = tmp_path / "imgs"
+    scenes = []
+    for s in range(2):
+        name = "FloorPlan%d" % s
+        os.makedirs(root / name)
+        table = {}
+        states = ["s%d_%d" % (s, k) for k in range(3)]
+        for k, st in enumerate(states):
+            Image.fromarray(np.random.RandomState(10 * s + k).randint(0, 255, (30, 40, 3), dtype=np.uint8)).save(root / name / (st + ".jpg"))
+            table[st] = {"detections": {"obj%d" % j: {"category_id": 10 + j + k, "bbox": [4 + j, 3 + j, 10, 8]} for j in range(k + 1)},
+                         "actions": {a: states[(k + 1 + i) % 3] for i, a in enumerate(ACTIONS)}}
+        scenes.append({"scene_name": name, "root": states[0], "state_table": table})
+    ann = tmp_path / "ann.json"
+    ann.write_text(json.dumps({"data": scenes, "metadata": {"actions": ACTIONS}}))
+    return str(root), str(ann)
+
+
+def test_sequence_dataset_and_collate(tiny_dataset):
+    root, ann = tiny_dataset
+    ds = SequenceDataset(root + "/", ann, "test", transform=transform)
+    assert len(ds) == 2
+    s = ds[0]
+    assert [ACTIONS[a] for a in s["actions"]] == ["RotateLeft", "MoveAhead", "RotateLeft", "MoveBack", "RotateRight"]
+    assert len(s["frames"]) == 5 and s["frames"][0].shape[0] == 3 and max(s["frames"][0].shape[1:]) == 300
+    assert s["initial_image_path"] == root + "/FloorPlan0/s0_0.jpg"
+    # labels carry the +1 offset, boxes are normalised cxcywh
+    assert s["category_ids"][0].tolist() == [11]
+    torch.testing.assert_close(s["boxes"][0], torch.tensor([[(4 + 5) / 40, (3 + 4) / 30, 10 / 40, 8 / 30]]), atol=1e-5, rtol=1e-5)
+    batch = collate_fn([ds[0], ds[1]])
+    assert batch["frames"].shape[:3] == (2, 5, 3) and batch["actions"].shape == (2, 5)
+    assert batch["masks"].dtype == torch.long and len(batch["boxes"][1]) == 5
+    tr = SequenceDataset(root, ann, "train", transform=train_transform)[1]
+    assert all(f.shape == (3, 300, 300) for f in tr["frames"])
+    assert all(bool(((b >= 0) & (b <= 1)).all()) for b in tr["boxes"])
+
+
+def test_interactive_dataset_reset_step(tiny_dataset):
+    root, ann = tiny_dataset
+    env = InteractiveDataset(root, ann, "test", transform=transform)
+    d = env.reset()
+    assert d["frames"].shape[:2] == (1, 1) and d["actions"].shape == (1, 0)
+    d = env.step(2)
+    d = env.step(0)
+    assert d["frames"].shape[:2] == (1, 3) and d["actions"].tolist() == [[2, 0]]
+    assert len(d["boxes"][0]) == 3 and d["initial_image_path"] == [root + "/FloorPlan0/s0_0.jpg"]
+    assert env.reset()["episode_ids"] == 1 and env.reset()["episode_ids"] == 0     # wraps around
+
+
+def test_logger_and_factories(tmp_path):
+    from interactron_amd.engine.logging import TBLogger
+    log = TBLogger(str(tmp_path / "logs"))
+    log.add_value("Train/x", 1.0)
+    log.add_value("Train/x", torch.tensor(3.0))
+    log.log_values()
+    rec = json.loads(open(tmp_path / "logs" / "scalars.jsonl").read().strip())
+    assert rec == {"iter": 0, "Train/x": 2.0}
+    from interactron_amd import build_evaluator, build_trainer
+    cfg = Config(**{"TRAINER": {"TYPE": "nope"}, "EVALUATOR": {"TYPE": "nope"}})
+    with pytest.raises(AssertionError):
+        build_trainer(None, cfg)
+    with pytest.raises(AssertionError):
+        build_evaluator(None, cfg)
