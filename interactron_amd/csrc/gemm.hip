@@ -42,7 +42,7 @@ struct GemmArgs {
     int split_k;
     int k_per_split;
     float alpha;
-    int a_vec, b_vec;
+    int a_vec, b_vec, c_vec;
     int tiles_m, tiles_n;
 };
 
@@ -290,28 +290,47 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     l = pack_bf16(s0, s1);
 }
 
+// KC operands: which of the 32 tile rows of a pass thread group g = tid >> 3 handles.  Consecutive groups sit 4 rows
+// apart (row = 4*(g&1) + ((g>>1)&3) + (g & 24)): a 16-lane ds_write_b64 group then covers rows r and r+4, whose 64-byte
+// chunks fall into disjoint halves of the 128-byte bank window (80-byte rows: 4*80 mod 128 = 64) instead of
+// overlapping by 16 bytes (2-way conflict on every store).  Global loads are unaffected (8 rows x 128 B either way).
+__device__ __forceinline__ int x6_kc_row(int tid) {
+    const int g = tid >> 3;
+    return ((g & 1) << 2) | ((g >> 1) & 3) | (g & 24);
+}
+
+// Wait until at most N of this wave's (inline-asm) buffer loads are outstanding, i.e. until the oldest ring stage landed.
+template <int N>
+__device__ __forceinline__ void x6_wait_stage() {
+    static_assert(N == 16 || N == 12 || N == 10, "unexpected ring stage size");
+    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
 template <int BT, bool KC>
 struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
     static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
     static constexpr int PLANE = BT * X6_ROWB;
-    float4 v[NI];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v[NI];
 
     // Branch-free: raw buffer loads (out-of-range bytes read as 0, so tiles past the K range or past the last row are
     // safe to request), tile rows clamped / surplus rows left as don't-care (they only feed C rows/cols that are never
-    // stored), k >= kmax zeroed by selects.  No branches means hipcc's waitcnt pass can count the three ring stages
-    // exactly (s_waitcnt vmcnt(16)) instead of draining the whole ring at every conversion.
+    // stored), k >= kmax zeroed by selects at conversion time.
+        // The loads are inline asm: hipcc's own waitcnt insertion would drain the whole ring (vmcnt(0)) at the loop header
+    // once per three K steps; hidden from it, the ring is waited for by hand with a counted s_waitcnt vmcnt(2 * loads
+    // per stage) in front of every conversion (x6_wait_stage), so two younger stages always stay in flight.
     __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int t0, int k0, int tmax, int kmax, int tid) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int off;
             if (KC)     // 4 consecutive k of tile row tr: a wave instruction reads 8 rows x 128 B
-                off = min(t0 + (tid >> 3) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
+                off = min(t0 + x6_kc_row(tid) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
             else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
                 off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
-            const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off * 4, 0, 0));
-            v[i] = make_float4(f.x, f.y, f.z, f.w);   // untouched until store(): nothing here may wait for the data
+            off *= 4;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
 
@@ -325,7 +344,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             float e0, e1, e2, e3;
             int row;
             if (KC) {
-                row = (tid >> 3) + 32 * i;
+                row = x6_kc_row(tid) + 32 * i;
                 e0 = v[i].x; e1 = v[i].y; e2 = v[i].z; e3 = v[i].w;
             } else {    // row i of this thread's 4x4 (k x row) register block
                 row = (tid >> 3) * 4 + i;
@@ -351,6 +370,30 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         }
     }
 };
+
+// Cooperative write-out of a row-major C tile staged in LDS (pitch BN + 4 floats) by all 512 threads: one float4 per
+// lane, consecutive lanes along a row.
+template <int BN>
+__device__ __forceinline__ void x6_store_tile(const float* __restrict__ ct, float* __restrict__ C, int64_t ldc, int m0,
+                                              int n0, int M, int N, int tid) {
+    constexpr int CP = BN + 4, CPR = BN / 4;   // float4 chunks per tile row
+#pragma unroll
+    for (int q = 0; q < X6_BT * CPR / 512; ++q) {
+        const int c = tid + 512 * q;
+        const int row = c / CPR, col = (c % CPR) * 4;
+        const int gr = m0 + row, gc = n0 + col;
+        if (gr >= M || gc >= N) continue;
+        const float4 v = *reinterpret_cast<const float4*>(&ct[row * CP + col]);
+        float* dst = C + (int64_t)gr * ldc + gc;
+        if (gc + 3 < N) {
+            *reinterpret_cast<float4*>(dst) = v;
+        } else {
+            dst[0] = v.x;
+            if (gc + 1 < N) dst[1] = v.y;
+            if (gc + 2 < N) dst[2] = v.z;
+        }
+    }
+}
 
 // Wave-specialised workgroup of 8 waves (one workgroup per CU, two waves per SIMD): waves 4-7 are PRODUCERS -- they
 // stream the fp32 operand tiles from HBM through a 3-deep register ring (loads issued three K steps ahead), split them
@@ -399,6 +442,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
     SB.load(rB, ldb, n0, kbeg + (T) * BK, p.N, kend, pt);         \
     __builtin_amdgcn_sched_barrier(0);
 #define X6_ST(SA, SB, T)                                                   \
+    x6_wait_stage<2 * (SplitLoader<BM, A_KC>::NI + SplitLoader<BN, B_KC>::NI)>();   \
     __builtin_amdgcn_sched_barrier(0);                                     \
     SA.store(lds[(T) & 1], pt, kbeg + (T) * BK, kend);                     \
     SB.store(lds[(T) & 1] + 3 * PLANE_A, pt, kbeg + (T) * BK, kend);       \
@@ -424,6 +468,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
         }
 #undef X6_LD
 #undef X6_ST
+        // the surplus tiles requested past the K range are still in flight and the compiler does not know about them
+        // (inline asm): they must land before this wave's registers can be handed to another wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p.split_k > 1 || !p.c_vec) return;   // (consumers store straight from registers in those cases)
+        __syncthreads();                          // C tile staged in LDS by the consumers: help writing it out
+        x6_store_tile<BN>(reinterpret_cast<const float*>(&lds[0][0]), p.C + bo * p.sCo + bi * p.sCi, p.ldc, m0, n0, p.M, p.N, tid);
         return;
     }
 
@@ -441,40 +491,65 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
     const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
     const int lrow = lane >> 5, lcol = lane & 31;
 
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char* ldsA = lds[kt & 1];
-        const unsigned char* ldsB = ldsA + 3 * PLANE_A;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {   // two k-slices of 16
-            bf16x8 af[TM][3], bf[TN][3];
-            const int koff = (s * 2 + lrow) * 16;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[i][pl] = *reinterpret_cast<const bf16x8*>(ldsA + pl * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + koff);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bf[j][pl] = *reinterpret_cast<const bf16x8*>(ldsB + pl * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + koff);
-            // smallest terms first; consecutive MFMAs go to different accumulators
-#define X6_TERM(PA_, PB_)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =       \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_], bf[j][PB_], acc[i][j], 0, 0, 0);
-            X6_TERM(2, 0)
-            X6_TERM(1, 1)
-            X6_TERM(0, 2)
-            X6_TERM(1, 0)
-            X6_TERM(0, 1)
-            X6_TERM(0, 0)
-#undef X6_TERM
-        }
-        __syncthreads();
+    // Fragment reads are software-pipelined around the MFMAs and across the K-step barrier: while the 24 MFMAs of one
+    // k-slice issue, the ds_read_b128s of the next slice (of this tile, or -- after the barrier -- of the next tile)
+    // are already in flight.  sched_barriers pin that order (hipcc otherwise hoists all reads and serialises).
+    bf16x8 fa0[TM][3], fb0[TN][3], fa1[TM][3], fb1[TN][3];
+#define X6_READ(FA, FB, BASE, S)                                                                                    \
+    {                                                                                                               \
+        const unsigned char* rA_ = (BASE);                                                                          \
+        const unsigned char* rB_ = rA_ + 3 * PLANE_A;                                                               \
+        const int koff_ = ((S) * 2 + lrow) * 16;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) FA[i][pl] =  \
+            *reinterpret_cast<const bf16x8*>(rA_ + pl * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + koff_);           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) FB[j][pl] =  \
+            *reinterpret_cast<const bf16x8*>(rB_ + pl * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + koff_);           \
     }
+    // smallest terms first; consecutive MFMAs go to different accumulators
+#define X6_TERM(FA, FB, PA_, PB_)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =        \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][PA_], FB[j][PB_], acc[i][j], 0, 0, 0);
+#define X6_MMA(FA, FB)  \
+    X6_TERM(FA, FB, 2, 0) X6_TERM(FA, FB, 1, 1) X6_TERM(FA, FB, 0, 2) X6_TERM(FA, FB, 1, 0) X6_TERM(FA, FB, 0, 1) X6_TERM(FA, FB, 0, 0)
+
+    __syncthreads();   // tile 0 is visible
+    if (nk > 0) X6_READ(fa0, fb0, lds[0], 0)
+    for (int kt = 0; kt < nk; ++kt) {
+        X6_READ(fa1, fb1, lds[kt & 1], 1)
+        __builtin_amdgcn_sched_barrier(0);
+        X6_MMA(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // this tile's reads are done (producers may refill it); the next tile is complete
+        if (kt + 1 < nk) X6_READ(fa0, fb0, lds[(kt + 1) & 1], 0)
+        __builtin_amdgcn_sched_barrier(0);
+        X6_MMA(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef X6_READ
+#undef X6_TERM
+#undef X6_MMA
 
     const bool add_bias = bias != nullptr && ks == 0;
+    if (p.split_k == 1 && p.c_vec) {
+        // Epilogue through LDS: the MFMA C layout gives every lane 16 scattered dwords per accumulator (one 4-byte store
+        // each, store-issue bound); staged as a row-major tile the whole workgroup (producers included) writes it out
+        // as 16-byte stores, 512 contiguous bytes per row.  The operand buffers are dead after the last K-step barrier.
+        float* ct = reinterpret_cast<float*>(&lds[0][0]);
+        constexpr int CP = BN + 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int cl = wn + j * 32 + lcol;
+                const float bv = (add_bias && n0 + cl < p.N) ? bias[n0 + cl] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + cl] = p.alpha * acc[i][j][r] + bv;
+            }
+        __syncthreads();
+        x6_store_tile<BN>(ct, C, p.ldc, m0, n0, p.M, p.N, tid);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -670,12 +745,13 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     // element-wise; the loader falls back per vector, so only base alignment matters here.
     a.a_vec = sa ? 1 : 0;
     a.b_vec = sb ? 1 : 0;
+    a.c_vec = ((sCo % 4 == 0) && (sCi % 4 == 0) && (ldc % 4 == 0) && aligned16(C)) ? 1 : 0;
     a.extA = a_kcontig ? (int64_t)(M - 1) * lda + K : (int64_t)(K - 1) * lda + M;
     a.extB = b_kcontig ? (int64_t)(N - 1) * ldb + K : (int64_t)(K - 1) * ldb + N;
     // bf16x6 kernel: 32-bit buffer offsets + 16-byte loads; its 3-stage ring and one-workgroup-per-CU residency only pay
     // off once there are enough K steps to stream (attention's K = 32 / 64 products stay on the fp32 kernel, where a
     // second resident workgroup hides the prologue)
-    const bool x6_ok = sa && sb && K >= 256 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
+    const bool x6_ok = sa && sb && K >= 64 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
     const bool want_x6 = x6_ok && (tile_hint == 1128 || (g_x6 && tile_hint != 128));
 
     // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the

@@ -44,6 +44,6 @@ def t(M, N, K, b, akc, bkc, th, reps=10):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     return us, 2.0 * M * N * K * b / us / 1e6
-for (M, N, K, b) in [(2060, 64, 2060, 128), (361, 32, 361, 640), (1805, 2048, 256, 16), (4096, 4096, 4096, 1)]:
+for (M, N, K, b) in [(2060, 64, 2060, 128), (1805, 2048, 256, 16), (1804, 2048, 256, 16), (4096, 4096, 4096, 1), (2060, 2060, 64, 128)]:
     for th in (128, 1128):
         print(M, N, K, b, "tile", th, " ".join("akc%d/bkc%d: %7.1f us %5.1f TF" % ((a, bb) + t(M, N, K, b, a, bb, th)) for a in (1, 0) for bb in (1, 0)), flush=True)
