@@ -55,6 +55,20 @@ def to_gpu(data, dev):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes); None when no such profile exists.
+    PMC counters cannot be collected from inside the process, so this is the profile's figure, not a live one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes expose 256 logical
     CPUs behind a 16-CPU cgroup quota; running 256 threads against that quota throttles the oracle ~100x."""
@@ -181,8 +195,9 @@ def main():
         k = 1 if kms[1] >= kms[0] else 0
         tf = [kfl[i] / (kms[i] * 1e-3) / 1e12 if kms[i] > 0 else 0.0 for i in range(2)]
         peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if k == 1 else FP32_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_bf16x6_kernel" if k == 1 else "gemm_f32_mfma_kernel",
-                    "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak, "traffic": None,
+        kname = "gemm_f32_bf16x6_kernel" if k == 1 else "gemm_f32_mfma_kernel"
+        roofline = {"bound": "mfma", "kernel": kname,
+                    "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak, "traffic": pmc_traffic(kname),
                     "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
                     "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
                     "note": "achieved = fp32-equivalent algorithmic FLOP/s; executed bf16 MFMA rate = 6x that "

@@ -299,21 +299,41 @@ __device__ __forceinline__ int x6_kc_row(int tid) {
     return ((g & 1) << 2) | ((g >> 1) & 3) | (g & 24);
 }
 
-// Wait until at most N of this wave's (inline-asm) buffer loads are outstanding, i.e. until the oldest ring stage landed.
-template <int N>
-__device__ __forceinline__ void x6_wait_stage() {
-    static_assert(N == 16 || N == 12 || N == 10, "unexpected ring stage size");
-    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-}
+// Wait until the oldest ring stage (registers a[0..3], b[0..NB-1]) has landed: at most `younger` * L of this wave's
+// (inline-asm) buffer loads may stay outstanding, where L = loads per stage and `younger` = how many younger stages
+// were actually requested.  The stage's registers are in/out operands of the wait, so that every use of the data
+// depends on it -- otherwise hipcc is free to hoist the conversion arithmetic above the wait (it does not know the
+// registers are still being written by the memory system).
+typedef float x6_f32x4 __attribute__((ext_vector_type(4)));
+// (macros, not a function taking pointers: the stage registers must never have their address taken, or they are
+// demoted to scratch memory and copied there right behind the asm load, i.e. before the data has arrived)
+#define X6_WAIT_ASM(SA, SB, CNT)                                                                                      \
+    if (NB_ == 4)                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(SA.v[0]), "+v"(SA.v[1]), "+v"(SA.v[2]), "+v"(SA.v[3]),        \
+                     "+v"(SB.v[0]), "+v"(SB.v[NB_ > 1 ? 1 : 0]), "+v"(SB.v[NB_ > 2 ? 2 : 0]), "+v"(SB.v[NB_ > 3 ? 3 : 0])::"memory"); \
+    else if (NB_ == 2)                                                                                                \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(SA.v[0]), "+v"(SA.v[1]), "+v"(SA.v[2]), "+v"(SA.v[3]),        \
+                     "+v"(SB.v[0]), "+v"(SB.v[NB_ > 1 ? 1 : 0])::"memory");                                           \
+    else                                                                                                              \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(SA.v[0]), "+v"(SA.v[1]), "+v"(SA.v[2]), "+v"(SA.v[3]),        \
+                     "+v"(SB.v[0])::"memory");
+#define X6_WAIT_STAGE(SA, SB, YOUNGER)                                                         \
+    {                                                                                          \
+        const int y_ = (YOUNGER);                                                              \
+        if (y_ >= 2) {                                                                         \
+            if (NB_ == 4) { X6_WAIT_ASM(SA, SB, 16) } else if (NB_ == 2) { X6_WAIT_ASM(SA, SB, 12) } else { X6_WAIT_ASM(SA, SB, 10) } \
+        } else if (y_ == 1) {                                                                  \
+            if (NB_ == 4) { X6_WAIT_ASM(SA, SB, 8) } else if (NB_ == 2) { X6_WAIT_ASM(SA, SB, 6) } else { X6_WAIT_ASM(SA, SB, 5) } \
+        } else {                                                                               \
+            X6_WAIT_ASM(SA, SB, 0)                                                             \
+        }                                                                                      \
+    }
 
 template <int BT, bool KC>
 struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
     static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
     static constexpr int PLANE = BT * X6_ROWB;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 v[NI];
+    x6_f32x4 v[NI];
 
     // Branch-free: raw buffer loads (out-of-range bytes read as 0, so tiles past the K range or past the last row are
     // safe to request), tile rows clamped / surplus rows left as don't-care (they only feed C rows/cols that are never
@@ -321,7 +341,10 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         // The loads are inline asm: hipcc's own waitcnt insertion would drain the whole ring (vmcnt(0)) at the loop header
     // once per three K steps; hidden from it, the ring is waited for by hand with a counted s_waitcnt vmcnt(2 * loads
     // per stage) in front of every conversion (x6_wait_stage), so two younger stages always stay in flight.
-    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int t0, int k0, int tmax, int kmax, int tid) {
+    // `valid` false (a tile past the K range): the request is sent with an out-of-range offset -- it returns zeros without
+    // touching memory, so every ring stage always has the same number of loads in flight and the waits stay constant.
+    __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int ld, int t0, int k0, int tmax, int kmax, int tid,
+                                         bool valid) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int off;
@@ -329,7 +352,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                 off = min(t0 + x6_kc_row(tid) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
             else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
                 off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
-            off *= 4;
+            off = valid ? off * 4 : 0x7ffffff0;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
@@ -400,6 +423,58 @@ __device__ __forceinline__ void x6_store_tile(const float* __restrict__ ct, floa
 // into bf16 planes on the VALU and write the LDS image of tile t+1 -- while waves 0-3 are CONSUMERS that only issue
 // ds_read_b128 + MFMA on tile t.  Each SIMD therefore runs one VALU-bound and one MFMA-bound wave side by side (the
 // two pipes are independent), the LDS image is double-buffered (2 x 60 KB) and there is ONE barrier per K step.
+// Producer side of the bf16x6 kernel: K tile j lives in ring stage j % 3; per K step the oldest stage is converted and
+// stored into LDS buffer (j & 1) and refilled with the tile three steps ahead; one barrier per K step (nk + 1 in total,
+// matching the consumers).  Tiles past the K range are requested out of range (free, zeros) and not converted.
+template <int BM, int BN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void x6_produce(__amdgpu_buffer_rsrc_t rA, __amdgpu_buffer_rsrc_t rB, int lda, int ldb, int m0,
+                                           int n0, int kbeg, int kend, int nk, int M, int N, unsigned char* lds, int buf_bytes,
+                                           int pt) {
+    constexpr int BK = X6_BK, PLANE_A = BM * X6_ROWB;
+    static_assert(SplitLoader<BM, A_KC>::NI == 4, "the A stage is four 16-byte loads per thread");
+    constexpr int NB_ = SplitLoader<BN, B_KC>::NI;
+    static_assert(NB_ == 4 || NB_ == 2 || NB_ == 1, "unexpected ring stage size");
+    SplitLoader<BM, A_KC> a0, a1, a2;
+    SplitLoader<BN, B_KC> b0, b1, b2;
+    // sched_barriers pin the order [wait, convert + store the oldest stage] -> [refill it].  The loads are never inside
+    // a branch: an asm output defined on one path only becomes a phi, i.e. a register copy right behind the load,
+    // before the data has arrived.
+#define X6_LD(SA, SB, T)                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                        \
+    SA.load(rA, lda, m0, kbeg + (T) * BK, M, kend, pt, (T) < nk);             \
+    SB.load(rB, ldb, n0, kbeg + (T) * BK, N, kend, pt, (T) < nk);             \
+    __builtin_amdgcn_sched_barrier(0);
+#define X6_ST(SA, SB, T)                                                                              \
+    X6_WAIT_STAGE(SA, SB, 2)                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if ((T) < nk) {                                                                                   \
+        SA.store(lds + ((T) & 1) * buf_bytes, pt, kbeg + (T) * BK, kend);                             \
+        SB.store(lds + ((T) & 1) * buf_bytes + 3 * PLANE_A, pt, kbeg + (T) * BK, kend);               \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+    X6_LD(a0, b0, 0)
+    X6_LD(a1, b1, 1)
+    X6_LD(a2, b2, 2)
+    X6_ST(a0, b0, 0)
+    X6_LD(a0, b0, 3)
+    __syncthreads();   // tile 0 is visible
+    for (int kt = 0; kt < nk; kt += 3) {
+        X6_ST(a1, b1, kt + 1)
+        X6_LD(a1, b1, kt + 4)
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        X6_ST(a2, b2, kt + 2)
+        X6_LD(a2, b2, kt + 5)
+        __syncthreads();
+        if (kt + 2 >= nk) break;
+        X6_ST(a0, b0, kt + 3)
+        X6_LD(a0, b0, kt + 6)
+        __syncthreads();
+    }
+#undef X6_LD
+#undef X6_ST
+}
+
 // BN = 128, 64 or 32 output columns per workgroup (attention's P.V products have N = head dim = 64 / 32).
 template <int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
@@ -431,45 +506,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
         const int lda = (int)p.lda, ldb = (int)p.ldb;
         // ------------------------------------------------ producers ------------------------------------------------
         const int pt = tid - 256;
-        SplitLoader<BM, A_KC> a0, a1, a2;   // K tile j lives in ring stage j % 3
-        SplitLoader<BN, B_KC> b0, b1, b2;
-        // (tiles past nk are requested and stored too: they read as zeros / land in the idle LDS buffer)
-        // sched_barriers pin the order [convert+store the oldest stage] -> [refill it]: the wait in front of a conversion
-        // is then a counted vmcnt(16) (two younger stages stay in flight) instead of a drain
-#define X6_LD(SA, SB, T)                                          \
-    __builtin_amdgcn_sched_barrier(0);                            \
-    SA.load(rA, lda, m0, kbeg + (T) * BK, p.M, kend, pt);         \
-    SB.load(rB, ldb, n0, kbeg + (T) * BK, p.N, kend, pt);         \
-    __builtin_amdgcn_sched_barrier(0);
-#define X6_ST(SA, SB, T)                                                   \
-    x6_wait_stage<2 * (SplitLoader<BM, A_KC>::NI + SplitLoader<BN, B_KC>::NI)>();   \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    SA.store(lds[(T) & 1], pt, kbeg + (T) * BK, kend);                     \
-    SB.store(lds[(T) & 1] + 3 * PLANE_A, pt, kbeg + (T) * BK, kend);       \
-    __builtin_amdgcn_sched_barrier(0);
-        X6_LD(a0, b0, 0)
-        X6_LD(a1, b1, 1)
-        X6_LD(a2, b2, 2)
-        X6_ST(a0, b0, 0)
-        X6_LD(a0, b0, 3)
-        __syncthreads();   // tile 0 is visible
-        for (int kt = 0; kt < nk; kt += 3) {
-            X6_ST(a1, b1, kt + 1)
-            X6_LD(a1, b1, kt + 4)
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            X6_ST(a2, b2, kt + 2)
-            X6_LD(a2, b2, kt + 5)
-            __syncthreads();
-            if (kt + 2 >= nk) break;
-            X6_ST(a0, b0, kt + 3)
-            X6_LD(a0, b0, kt + 6)
-            __syncthreads();
-        }
-#undef X6_LD
-#undef X6_ST
-        // the surplus tiles requested past the K range are still in flight and the compiler does not know about them
-        // (inline asm): they must land before this wave's registers can be handed to another wave
+        x6_produce<BM, BN, A_KC, B_KC>(rA, rB, lda, ldb, m0, n0, kbeg, kend, nk, p.M, p.N, &lds[0][0], BUF, pt);
+        // nothing may still be in flight when this wave ends (its registers go to another wave; the compiler does not
+        // know about the inline-asm loads)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.split_k > 1 || !p.c_vec) return;   // (consumers store straight from registers in those cases)
         __syncthreads();                          // C tile staged in LDS by the consumers: help writing it out
@@ -751,7 +790,7 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     // bf16x6 kernel: 32-bit buffer offsets + 16-byte loads; its 3-stage ring and one-workgroup-per-CU residency only pay
     // off once there are enough K steps to stream (attention's K = 32 / 64 products stay on the fp32 kernel, where a
     // second resident workgroup hides the prologue)
-    const bool x6_ok = sa && sb && K >= 64 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
+    const bool x6_ok = sa && sb && K >= 32 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
     const bool want_x6 = x6_ok && (tile_hint == 1128 || (g_x6 && tile_hint != 128));
 
     // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
@@ -763,15 +802,15 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     {
         double best = 1e300;
         const int cand_tiles[2] = {128, 64};
-        const int cand_split[12] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32};
+        const int cand_split[14] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
         for (int ti = 0; ti < 2; ++ti) {
             const int t = cand_tiles[ti];
             if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
             const int bk = t == 128 ? 32 : 64;
             // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
-            const double step_cycles = t == 128 ? (want_x6 ? 2300.0 : 4096.0) : 2048.0 * 1.15;
+            const double step_cycles = t == 128 ? (want_x6 ? 1900.0 : 4096.0) : 2048.0 * 1.15;
             const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
-            for (int si = 0; si < 12; ++si) {
+            for (int si = 0; si < 14; ++si) {
                 int sp = cand_split[si];
                 if (split_k_hint > 0) sp = split_k_hint;
                 if (sp > 1 && K < 2 * bk * sp) break;

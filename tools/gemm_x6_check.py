@@ -17,7 +17,7 @@ def run(A, B, M, N, K, b, akc, bkc, th, sh, bias=None):
     return C
 
 worst = 0.0
-for (M, N, K, b) in [(130, 77, 256, 2), (300, 260, 1805, 3), (1805, 512, 256, 2), (257, 129, 4099, 1), (2060, 64, 2060, 3), (361, 32, 361, 5), (300, 50, 777, 2), (100, 20, 300, 2)]:
+for (M, N, K, b) in [(130, 77, 256, 2), (128, 128, 32, 2), (200, 136, 64, 2), (200, 136, 96, 2), (200, 136, 100, 2), (300, 260, 1805, 3), (1805, 512, 256, 2), (257, 129, 4099, 1), (2060, 64, 2060, 3), (361, 32, 361, 5), (300, 50, 777, 2), (100, 20, 300, 2)]:
     for akc in (1, 0):
         for bkc in (1, 0):
             for sh in (1, 3):
@@ -44,6 +44,6 @@ def t(M, N, K, b, akc, bkc, th, reps=10):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     return us, 2.0 * M * N * K * b / us / 1e6
-for (M, N, K, b) in [(2060, 64, 2060, 128), (1805, 2048, 256, 16), (1804, 2048, 256, 16), (4096, 4096, 4096, 1), (2060, 2060, 64, 128)]:
+for (M, N, K, b) in [(2060, 64, 2060, 128), (1805, 2048, 256, 16), (1804, 2048, 256, 16), (4096, 4096, 4096, 1), (2060, 2060, 64, 128), (364, 364, 32, 640), (256, 256, 28880, 1)]:
     for th in (128, 1128):
         print(M, N, K, b, "tile", th, " ".join("akc%d/bkc%d: %7.1f us %5.1f TF" % ((a, bb) + t(M, N, K, b, a, bb, th)) for a in (1, 0) for bb in (1, 0)), flush=True)
