@@ -17,25 +17,50 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def cost_matrices(self, outputs, targets):
-        """Per-image cost matrices [Q, N_i] as CPU tensors (reference matcher.py:54-73): one kernel builds the whole
-        [bs*Q, sum(N_i)] matrix, one D2H copy -- the reference's own host hand-over point."""
+    def begin(self, outputs, targets):
+        """Enqueue the cost kernel (reference matcher.py:54-73: one launch builds the whole [bs*Q, sum(N_i)] matrix) and
+        its D2H copy into pinned memory; returns a handle for ``finish``.  Splitting the call lets the caller queue more
+        GPU work behind the copy and run the host-side assignment while that work executes."""
         bs, num_queries = outputs["pred_logits"].shape[:2]
-        logits = outputs["pred_logits"].flatten(0, 1)
-        boxes = outputs["pred_boxes"].flatten(0, 1)
+        sizes = [len(v["boxes"]) for v in targets]
+        if sum(sizes) == 0:
+            return None, None, sizes, bs, num_queries, targets
         tgt_ids = torch.cat([v["labels"] for v in targets])
         tgt_bbox = torch.cat([v["boxes"] for v in targets])
-        sizes = [len(v["boxes"]) for v in targets]
-        if tgt_ids.numel() == 0:
+        C = ops.match_cost(outputs["pred_logits"].flatten(0, 1), outputs["pred_boxes"].flatten(0, 1), tgt_ids, tgt_bbox,
+                           float(self.cost_class), float(self.cost_bbox), float(self.cost_giou))
+        host = torch.empty(C.shape, dtype=C.dtype, pin_memory=True)
+        host.copy_(C, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev, sizes, bs, num_queries, targets
+
+    @torch.no_grad()
+    def costs(self, handle):
+        """Per-image cost matrices [Q, N_i] as CPU tensors (waits for the copy started by ``begin``)."""
+        host, ev, sizes, bs, num_queries, _ = handle
+        if host is None:
             return [torch.empty(num_queries, 0) for _ in sizes]
-        C = ops.match_cost(logits, boxes, tgt_ids, tgt_bbox, float(self.cost_class), float(self.cost_bbox),
-                           float(self.cost_giou)).view(bs, num_queries, -1).cpu()
+        ev.synchronize()
+        C = host.view(bs, num_queries, -1)
         return [c[i].contiguous() for i, c in enumerate(C.split(sizes, -1))]
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
+    def assign(self, costs, targets):
+        """Host assignment per image (reference matcher.py:76: scipy.optimize.linear_sum_assignment)."""
         empty = torch.empty(0, dtype=torch.int64)
-        return [ops.lsap(c) if c.shape[1] else (empty.clone(), empty.clone()) for c in self.cost_matrices(outputs, targets)]
+        return [ops.lsap(c) if c.shape[1] else (empty.clone(), empty.clone()) for c in costs]
+
+    def finish(self, handle):
+        return self.assign(self.costs(handle), handle[5])
+
+    @torch.no_grad()
+    def cost_matrices(self, outputs, targets):
+        return self.costs(self.begin(outputs, targets))
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        return self.finish(self.begin(outputs, targets))
 
 
 def build_matcher(args):

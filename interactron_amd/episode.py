@@ -187,9 +187,25 @@ class _Adaptive(_EpisodeModel):
                 pt.mark("4 inner SGD + detector fwd (theta')")
                 actions_out = fusion_out["actions"].reshape(E, 4, 4)
                 # ONE matcher pass for the whole chunk (matching is per image, so the assignments are exactly those of
-                # per-episode calls): one cost kernel + one D2H instead of 2-3 host syncs per episode
+                # per-episode calls): one cost kernel + one asynchronous D2H instead of 2-3 host syncs per episode.
                 post_lb = {k: post[k] for k in ("pred_logits", "pred_boxes")}
-                idx_all = self.criterion.matcher(post_lb, [lab for ep_labels in labels for lab in ep_labels])
+                match = self.criterion.matcher.begin(post_lb, [lab for ep_labels in labels for lab in ep_labels])
+
+                # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient,
+                # not on the criterion: its forward is queued NOW, so that the GPU works on it while the host runs the
+                # Hungarian assignment and builds the criterion.  The expansion of theta is differentiable; its backward
+                # sums the per-episode gradients into theta.grad.
+                attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
+                fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
+                set_parameters(self.detector, fast1)
+                ridx = [random.randint(0, 4) for _ in ep]
+                sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
+                post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
+                post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
+                match1 = self.criterion.matcher.begin(post1_lb, [labels[i][ridx[i]] for i in range(E)])
+                pt.mark("5 first-order SGD + 1-frame fwd (queued early)")
+
+                idx_all = self.criterion.matcher.finish(match)
                 sups, gts = [], []
                 for i, t in enumerate(ep):
                     post_t = {k: v[i * s:(i + 1) * s] for k, v in post_lb.items()}
@@ -214,23 +230,13 @@ class _Adaptive(_EpisodeModel):
                     sup_losses.append({k: v.detach() for k, v in sup.items()})
                     tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
                     total = tl if total is None else total + tl
-                pt.mark("5 criterion + matcher + path storage")
+                pt.mark("6 criterion + matcher + path storage")
                 torch.autograd.backward(total, inputs=targets2)
-                pt.mark("6 second-order backward")
-
-                # first-order detector update through the adapted weights (reference interactron.py:126-134); the
-                # expansion of theta is differentiable, its backward sums the per-episode gradients into theta.grad
-                attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
-                fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
                 del grads, dtheta, fusion_out, pre, post, post_lb, sups, gts, sup, total, tl, loss_map, learned, actions_out
-                set_parameters(self.detector, fast1)
-                ridx = [random.randint(0, 4) for _ in ep]
-                sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
-                post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
-                pt.mark("7 first-order SGD + 1-frame fwd")
+
+                # criterion of the first-order branch: host work that overlaps the second-order backward on the GPU
+                idx1 = self.criterion.matcher.finish(match1)
                 total = None
-                post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
-                idx1 = self.criterion.matcher(post1_lb, [labels[i][ridx[i]] for i in range(E)])
                 for i, t in enumerate(ep):
                     post_t = {k: v[i:i + 1] for k, v in post1_lb.items()}
                     dl = self.criterion(post_t, labels[i][ridx[i]:ridx[i] + 1], background_c=0.1, indices=idx1[i:i + 1])
@@ -238,9 +244,9 @@ class _Adaptive(_EpisodeModel):
                     total = _weighted(dl) if total is None else total + _weighted(dl)
                     logits_out.append(post_t["pred_logits"].detach())
                     boxes_out.append(post_t["pred_boxes"].detach())
-                pt.mark("8 criterion (1 frame)")
+                pt.mark("7 second-order backward (+ 1-frame criterion on the host)")
                 total.backward()
-                pt.mark("9 first-order backward")
+                pt.mark("8 first-order backward")
                 del attached, fast1, post1, total
         finally:
             set_parameters(self.detector, theta)

@@ -71,13 +71,13 @@ class ReferenceMatching:
         from interactron_amd import criterion as cr
         from interactron_amd import hipops as ops
         self._cls = cr.HungarianMatcher
-        self._orig = cr.HungarianMatcher.forward
+        self._orig = cr.HungarianMatcher.assign
         outer = self
 
         @torch.no_grad()
-        def forward(matcher, outputs, targets):
+        def assign(matcher, costs, targets):
             out = []
-            for c, t in zip(matcher.cost_matrices(outputs, targets), targets):
+            for c, t in zip(costs, targets):
                 outer.calls += 1
                 cands = outer.recorded.get(image_key(t))
                 assert cands, "matcher saw an image without a recorded reference assignment"
@@ -94,8 +94,8 @@ class ReferenceMatching:
                 out.append((rr, rc))
             return out
 
-        cr.HungarianMatcher.forward = forward
+        cr.HungarianMatcher.assign = assign
         return self
 
     def __exit__(self, *exc):
-        self._cls.forward = self._orig
+        self._cls.assign = self._orig

@@ -144,7 +144,7 @@ def test_episode_batched_equals_sequential_schedule():
     data = to_gpu(synthetic_episodes(3, height=128, width=160, tag="chunk"))
     from interactron_amd import criterion as cr
     res = []
-    recorded, orig = {}, cr.HungarianMatcher.forward
+    recorded, orig = {}, cr.HungarianMatcher.assign
     for chunk in (0, 2):
         m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", EPISODE_CHUNK=chunk)))
         load_procedural(m.fusion, "fusion.")
@@ -152,16 +152,16 @@ def test_episode_batched_equals_sequential_schedule():
         m.zero_grad()
         random.seed(11)
         if chunk == 0:   # record the sequential schedule's assignments, pin the batched run to them (ties: see helpers)
-            def spy(matcher, outputs, targets):
-                out = orig(matcher, outputs, targets)
+            def spy(matcher, costs, targets):
+                out = orig(matcher, costs, targets)
                 for t, rc in zip(targets, out):
                     recorded.setdefault(image_key(t), []).append(rc)
                 return out
-            cr.HungarianMatcher.forward = spy
+            cr.HungarianMatcher.assign = spy
             try:
                 preds, losses = m(data)
             finally:
-                cr.HungarianMatcher.forward = orig
+                cr.HungarianMatcher.assign = orig
         else:
             with ReferenceMatching(recorded):
                 preds, losses = m(data)
