@@ -147,8 +147,11 @@ def main():
     data = to_gpu(synthetic_episodes(args.episodes, height=args.size, width=args.size, tag="bench-r%d" % rank), dev)
     random.seed(1234 + rank)
 
+    last = {}
+
     def step():
-        model(data)
+        _, losses = model(data)
+        last["losses"] = losses
         outer.step()
 
     def fence():
@@ -208,6 +211,8 @@ def main():
                                          "gflop_per_step": pf.value / 1e9, "kernel_ms_per_step": ms.value,
                                          "launches_per_step": int(pl.value)}}
 
+    bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
+    assert not bad, "non-finite losses after the timed steps: %s" % bad
     if rank == 0:
         frames = 5.0 * args.episodes * world * args.steps
         line = {
