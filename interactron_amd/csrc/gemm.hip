@@ -396,13 +396,13 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
 
 // Cooperative write-out of a row-major C tile staged in LDS (pitch BN + 4 floats) by all 512 threads: one float4 per
 // lane, consecutive lanes along a row.
-template <int BN>
+template <int BN, int NT = 512>
 __device__ __forceinline__ void x6_store_tile(const float* __restrict__ ct, float* __restrict__ C, int64_t ldc, int m0,
                                               int n0, int M, int N, int tid) {
     constexpr int CP = BN + 4, CPR = BN / 4;   // float4 chunks per tile row
 #pragma unroll
-    for (int q = 0; q < X6_BT * CPR / 512; ++q) {
-        const int c = tid + 512 * q;
+    for (int q = 0; q < X6_BT * CPR / NT; ++q) {
+        const int c = tid + NT * q;
         const int row = c / CPR, col = (c % CPR) * 4;
         const int gr = m0 + row, gc = n0 + col;
         if (gr >= M || gc >= N) continue;
@@ -612,6 +612,239 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form of the bf16x6 kernel: one workgroup per CU walks a list of output tiles (tile, split, batch) instead
+// of ending after one.  The producers request the first three K tiles of the NEXT output tile before the consumers
+// start the epilogue of the current one, so the HBM round trip of every tile's prologue and the epilogue's stores
+// overlap; with one workgroup per CU nothing else would hide them (K = 256 / 64 shapes spend a third of their time
+// there).  Work items are dealt per XCD (workgroup g serves XCD g & 7 = blockIdx % 8, the observed placement): each XCD
+// walks one contiguous eighth of the grouped tile order, which keeps neighbouring tiles in one L2.
+// Barriers per item, both roles: 1 (first tile visible) + nk (K steps) + 2 (C tile staged / stored).
+// ------------------------------------------------------------------------------------------------------------
+struct X6Item {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int m0, n0, kbeg, kend, nk, ks;
+};
+
+template <int BN>
+__device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
+    X6Item it;
+    const int nt = p.tiles_m * p.tiles_n, per_batch = nt * p.split_k;
+    const int zb = w / per_batch, rem = w - zb * per_batch;
+    const int ks = rem / nt, tile = rem - ks * nt;
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    it.m0 = (first_m + (tile % group_size) % gm) * X6_BT;
+    it.n0 = ((tile % group_size) / gm) * BN;
+    const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
+    it.A = p.A + bo * p.sAo + bi * p.sAi;
+    it.B = p.B + bo * p.sBo + bi * p.sBi;
+    it.C = p.C + bo * p.sCo + bi * p.sCi;
+    it.bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+    it.ks = ks;
+    it.kbeg = ks * p.k_per_split;
+    it.kend = min(p.K, it.kbeg + p.k_per_split);
+    it.nk = (it.kend - it.kbeg + X6_BK - 1) / X6_BK;
+    return it;
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(GemmArgs p, int total_items) {
+    constexpr int BM = X6_BT, BK = X6_BK;
+    constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
+    constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this workgroup's items: w = first, first + stride, ... < last   (per-XCD contiguous chunks)
+    const int per_xcd = (total_items + 7) >> 3, xcd = blockIdx.x & 7;
+    const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
+    int w = xcd * per_xcd + (blockIdx.x >> 3);
+    if (w >= last) return;
+    const bool staged = p.split_k == 1 && p.c_vec;
+
+    if (wave >= 4) {
+        // ------------------------------------------------ producers ------------------------------------------------
+        const int pt = tid - 256, lda = (int)p.lda, ldb = (int)p.ldb;
+        static_assert(SplitLoader<BM, A_KC>::NI == 4, "the A stage is four 16-byte loads per thread");
+        constexpr int NB_ = SplitLoader<BN, B_KC>::NI;
+        static_assert(NB_ == 4 || NB_ == 2 || NB_ == 1, "unexpected ring stage size");
+        SplitLoader<BM, A_KC> a0, a1, a2;
+        SplitLoader<BN, B_KC> b0, b1, b2;
+        X6Item it = x6_item<BN>(p, w);
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)it.A, 0, (int)(p.extA * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)it.B, 0, (int)(p.extB * 4), 0x00020000);
+#define X6_LD(SA, SB, T, OK)                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    SA.load(rA, lda, it.m0, it.kbeg + (T) * BK, p.M, it.kend, pt, (OK) && (T) < it.nk);        \
+    SB.load(rB, ldb, it.n0, it.kbeg + (T) * BK, p.N, it.kend, pt, (OK) && (T) < it.nk);        \
+    __builtin_amdgcn_sched_barrier(0);
+#define X6_ST(SA, SB, T)                                                                              \
+    X6_WAIT_STAGE(SA, SB, 2)                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if ((T) < it.nk) {                                                                                \
+        SA.store(lds[(T) & 1], pt, it.kbeg + (T) * BK, it.kend);                                      \
+        SB.store(lds[(T) & 1] + 3 * PLANE_A, pt, it.kbeg + (T) * BK, it.kend);                        \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);
+        X6_LD(a0, b0, 0, true)
+        X6_LD(a1, b1, 1, true)
+        X6_LD(a2, b2, 2, true)
+        for (;;) {
+            X6_ST(a0, b0, 0)
+            X6_LD(a0, b0, 3, true)
+            __syncthreads();   // tile 0 of this item is visible
+            for (int kt = 0; kt < it.nk; kt += 3) {
+                X6_ST(a1, b1, kt + 1)
+                X6_LD(a1, b1, kt + 4, true)
+                __syncthreads();
+                if (kt + 1 >= it.nk) break;
+                X6_ST(a2, b2, kt + 2)
+                X6_LD(a2, b2, kt + 5, true)
+                __syncthreads();
+                if (kt + 2 >= it.nk) break;
+                X6_ST(a0, b0, kt + 3)
+                X6_LD(a0, b0, kt + 6, true)
+                __syncthreads();
+            }
+            // request the next item's first three K tiles now: they fly while the consumers run this item's epilogue.
+            // (No next item: same instructions with out-of-range offsets -- the loads must never sit in a branch.)
+            w += stride;
+            const bool more = w < last;
+            it = x6_item<BN>(p, more ? w : last - 1);
+            rA = __builtin_amdgcn_make_buffer_rsrc((void*)it.A, 0, (int)(p.extA * 4), 0x00020000);
+            rB = __builtin_amdgcn_make_buffer_rsrc((void*)it.B, 0, (int)(p.extB * 4), 0x00020000);
+            X6_LD(a0, b0, 0, more)
+            X6_LD(a1, b1, 1, more)
+            X6_LD(a2, b2, 2, more)
+            __syncthreads();   // the C tile is staged in LDS
+            __syncthreads();   // ... and written out: the LDS buffers are free again
+            if (!more) break;
+        }
+#undef X6_LD
+#undef X6_ST
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    bf16x8 fa0[TM][3], fb0[TN][3], fa1[TM][3], fb1[TN][3];
+#define X6_READ(FA, FB, BASE, S)                                                                                    \
+    {                                                                                                               \
+        const unsigned char* rA_ = (BASE);                                                                          \
+        const unsigned char* rB_ = rA_ + 3 * PLANE_A;                                                               \
+        const int koff_ = ((S) * 2 + lrow) * 16;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) FA[i][pl] =  \
+            *reinterpret_cast<const bf16x8*>(rA_ + pl * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + koff_);           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) FB[j][pl] =  \
+            *reinterpret_cast<const bf16x8*>(rB_ + pl * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + koff_);           \
+    }
+#define X6_TERM(FA, FB, PA_, PB_)                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =        \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][PA_], FB[j][PB_], acc[i][j], 0, 0, 0);
+#define X6_MMA(FA, FB)  \
+    X6_TERM(FA, FB, 2, 0) X6_TERM(FA, FB, 1, 1) X6_TERM(FA, FB, 0, 2) X6_TERM(FA, FB, 1, 0) X6_TERM(FA, FB, 0, 1) X6_TERM(FA, FB, 0, 0)
+    for (; w < last; w += stride) {
+        const X6Item it = x6_item<BN>(p, w);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __syncthreads();   // tile 0 is visible
+        if (it.nk > 0) X6_READ(fa0, fb0, lds[0], 0)
+        for (int kt = 0; kt < it.nk; ++kt) {
+            X6_READ(fa1, fb1, lds[kt & 1], 1)
+            __builtin_amdgcn_sched_barrier(0);
+            X6_MMA(fa0, fb0)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (kt + 1 < it.nk) X6_READ(fa0, fb0, lds[(kt + 1) & 1], 0)
+            __builtin_amdgcn_sched_barrier(0);
+            X6_MMA(fa1, fb1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool add_bias = it.bias != nullptr && it.ks == 0;
+        if (staged) {
+            float* ct = reinterpret_cast<float*>(&lds[0][0]);
+            constexpr int CP = BN + 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn + j * 32 + lcol;
+                    const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ct[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + cl] = p.alpha * acc[i][j][r] + bv;
+                }
+            __syncthreads();   // staged
+            x6_store_tile<BN, 256>(ct, it.C, p.ldc, it.m0, it.n0, p.M, p.N, tid);
+            __syncthreads();   // stored
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = it.n0 + wn + j * 32 + lcol;
+                    if (col >= p.N) continue;
+                    const float bv = add_bias ? it.bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = it.m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                        if (row < p.M) {
+                            const float v = p.alpha * acc[i][j][r] + bv;
+                            float* dst = it.C + (int64_t)row * p.ldc + col;
+                            if (p.split_k > 1)
+                                unsafeAtomicAdd(dst, v);
+                            else
+                                *dst = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+#undef X6_READ
+#undef X6_TERM
+#undef X6_MMA
+}
+
+template <int BN>
+static void launch_x6p_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_persistent_kernel<BN, true, true>), grid, dim3(512), 0, stream, a, items);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_persistent_kernel<BN, true, false>), grid, dim3(512), 0, stream, a, items);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_persistent_kernel<BN, false, true>), grid, dim3(512), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_bf16x6_persistent_kernel<BN, false, false>), grid, dim3(512), 0, stream, a, items);
+}
+
+static void launch_x6p(const GemmArgs& a, int bn, int a_kc, int b_kc, int items, hipStream_t stream) {
+    if (bn == 128)
+        launch_x6p_bn<128>(a, a_kc, b_kc, items, stream);
+    else if (bn == 64)
+        launch_x6p_bn<64>(a, a_kc, b_kc, items, stream);
+    else
+        launch_x6p_bn<32>(a, a_kc, b_kc, items, stream);
+}
+
 template <int BN>
 static void launch_x6_bn(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t stream) {
     if (a_kc && b_kc)
@@ -661,7 +894,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // a hipEvent pair around every contraction launch on its own stream, summed by ix_gemm_prof_read after a sync --
 // that is the "average launch duration measured with HIP events" the roofline fraction is computed from.
 #include <vector>
-static int g_x6 = 1;   // 1 (default): 128x128 tiles run on the bf16x6 kernel; 0: fp32 MFMA only (ix_gemm_set_mode)
+static int g_x6 = 2;   // 2 (default): persistent bf16x6 kernel; 1: one-tile-per-workgroup bf16x6 kernel; 0: fp32 MFMA only
 static double g_flops = 0.0;
 static int64_t g_launches = 0;
 static bool g_prof_on = false;
@@ -681,7 +914,7 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
 // from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
 extern "C" int ix_gemm_set_mode(int mode) {
     const int old = g_x6;
-    g_x6 = mode ? 1 : 0;
+    g_x6 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);   // 2: persistent bf16x6 kernel
     return old;
 }
 
@@ -853,7 +1086,9 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     g_launches += 1;
     if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
     prof_mark(stream);
-    if (use_x6)
+    if (use_x6 && g_x6 == 2 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+        launch_x6p(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    else if (use_x6)
         launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);
     else if (bm == 128)
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);

@@ -7,6 +7,7 @@ from interactron_amd import _lib
 lib = _lib.load()
 stream = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)
+lib.ix_gemm_set_mode(int(os.environ.get("IX_MODE", "1")))
 
 def run(A, B, M, N, K, b, akc, bkc, th, sh, bias=None):
     C = torch.empty(b, M, N, device="cuda")
