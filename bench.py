@@ -35,13 +35,21 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16
 X6_PRODUCTS = 6                  # bf16 MFMAs the bf16x6 kernel issues per fp32 multiply-add (3-way split, 6 kept terms)
 
 
-def model_cfg(size, queries, chunk=8):
+CONFIGS = {   # --config -> (reference yaml, MODEL.TYPE, oracle fusion style)
+    "interactron": ("configs/interactron.yaml", "interactron", "gpt"),
+    "interactron_random": ("configs/interactron_random.yaml", "interactron_random", "decoder"),
+    "multi_frame_baseline": ("configs/multi_frame_baseline.yaml", "detr_multiframe", "gpt"),
+    "single_frame_baseline": ("configs/single_frame_baseline.yaml", "detr", None),
+}
+
+
+def model_cfg(size, queries, chunk=8, model_type="interactron"):
     # stride-16 backbone: h = w = ceil(size / 16) after the stem/maxpool/strided stages (19 at 300, 50 at 800)
     h = size
     for k, s, p in ((7, 2, 3), (3, 2, 1), (3, 2, 1), (3, 2, 1)):
         h = (h + 2 * p - k) // s + 1
     tokens = h * h
-    return dict(TYPE="interactron", WEIGHTS="procedural", NUM_CLASSES=1235, SET_COST_CLASS=1.0, SET_COST_BBOX=5.0,
+    return dict(TYPE=model_type, WEIGHTS="procedural", NUM_CLASSES=1235, SET_COST_CLASS=1.0, SET_COST_BBOX=5.0,
                 SET_COST_GIOU=2.0, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=5 * (tokens + queries) + 5,
                 IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
                 ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries, EPISODE_CHUNK=chunk), tokens
@@ -88,7 +96,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, size):
+def cpu_baseline(cfg, size, config="interactron"):
     """The CPU oracle (a from-scratch PyTorch-CPU restatement of the reference path, pinned to fixtures captured from
     the imported reference) on ONE synthetic episode of the same workload, all host cores."""
     import torch
@@ -98,16 +106,29 @@ def cpu_baseline(cfg, size):
     torch.set_num_threads(cores)
     det = {k[len("detector."):]: v for k, v in
            procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
-    fus = {k[len("fusion."):]: v for k, v in
-           procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, "gpt").items()}).items()}
+    style = CONFIGS[config][2]
+    fus = None
+    if style is not None:
+        fus = {k[len("fusion."):]: v for k, v in
+               procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, style).items()}).items()}
+        if style == "decoder" and "pos_embed" not in fus:
+            fus["pos_embed"] = of.decoder_fusion_pos_embed()
     data = synthetic_episodes(1, height=size, width=size, tag="bench-r0")
     random.seed(0)
     t0 = time.perf_counter()
-    oe.interactron_forward(det, fus, data, cfg, {}, "gpt")
+    if config == "single_frame_baseline":
+        oe.detr_train_forward(det, data)
+        fn = "detr_train_forward"
+    elif config == "multi_frame_baseline":
+        oe.multiframe_forward(det, fus, data, cfg)
+        fn = "multiframe_forward"
+    else:
+        oe.interactron_forward(det, fus, data, cfg, {}, style)
+        fn = "interactron_forward"
     dt = time.perf_counter() - t0
     return {"value": 5.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 meta-train episode (5 frames, %dx%d, fp32) through oracle/episode.py:interactron_forward, "
-                      "no warm-up, %.1f s" % (size, size, dt)}
+            "sample": "1 training episode (5 frames, %dx%d, fp32) through oracle/episode.py:%s, no warm-up, %.1f s"
+                      % (size, size, fn, dt)}
 
 
 def main():
@@ -118,6 +139,8 @@ def main():
     ap.add_argument("--size", type=int, default=300, help="frame height = width (300 = reference data, 800 = north-star)")
     ap.add_argument("--queries", type=int, default=50)
     ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
+    ap.add_argument("--config", default="interactron", choices=sorted(CONFIGS),
+                    help="which reference config's training step to run (default: the headline meta-train step)")
     ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -139,11 +162,15 @@ def main():
     dev = torch.device("cuda", local)
     lib = _lib.load()
 
-    cfg, tokens = model_cfg(args.size, args.queries, args.chunk)
+    cfg, tokens = model_cfg(args.size, args.queries, args.chunk, CONFIGS[args.config][1])
     model = build_model(Config(**cfg))
-    load_procedural(model.fusion, "fusion.")
+    if hasattr(model, "fusion"):
+        load_procedural(model.fusion, "fusion.")
     model = model.to(dev).train()
-    outer = FlatOuterStep(model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
+    if hasattr(model, "detector"):
+        outer = FlatOuterStep(model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
+    else:   # configs/single_frame_baseline.yaml: one Adam over the whole DETR (direct-supervision trainer)
+        outer = FlatOuterStep(model, max_norm=1.0, groups=[list(model.parameters())], lrs=[1e-5])
     data = to_gpu(synthetic_episodes(args.episodes, height=args.size, width=args.size, tag="bench-r%d" % rank), dev)
     random.seed(1234 + rank)
 
@@ -219,16 +246,17 @@ def main():
             "metric": "frames/sec (5-frame episodes)", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs/interactron.yaml meta-train step (interactron.forward + all-reduce + clip + 2x Adam), "
+            "config": {"workload": "%s training step (%s.forward + all-reduce + clip + Adam), "
                                    "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode"
-                                   % (args.episodes, args.size, args.size, args.queries, cfg["BLOCK_SIZE"]),
+                                   % (CONFIGS[args.config][0], CONFIGS[args.config][1], args.episodes, args.size, args.size,
+                                      args.queries, cfg["BLOCK_SIZE"]),
                        "episodes_per_gpu": args.episodes, "frame_size": args.size, "parallelism": "dp%d" % world},
             "gemm_gflop_per_step": flops.value / 1e9 / args.steps, "gemm_launches_per_step": launches.value / args.steps,
             "roofline": roofline,
             "cpu_baseline": None,
         }
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.size)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -207,7 +207,13 @@ class TransformerDecoder(nn.Module):
         self.norm = LayerNorm(d_model) if norm else None
 
     def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos):
-        memory_key = ops.add(memory, pos) if pos is not None else memory
+        if pos is None:
+            memory_key = memory
+        elif pos.shape[0] == 1 and memory.shape[0] > 1:   # one fixed position table shared by a batch of sequences
+            b = memory.shape[0]
+            memory_key = ops.AddRowVec.apply(memory.reshape(b, -1), pos.reshape(-1), 1).reshape(memory.shape)
+        else:
+            memory_key = ops.add(memory, pos)
         for layer in self.layers:
             tgt = layer(tgt, memory, memory_key, memory_key_padding_mask, query_pos)
         # return_intermediate=True in the reference, but only hs[-1] is consumed (detr.py:69): norm the last output

@@ -109,7 +109,6 @@ class _Adaptive(_EpisodeModel):
     phase_times = None
 
     use_policy = False
-    fusion_batched = True
 
     def _second_order_targets(self):
         """Leaves that keep a .grad from the supervisor backward: fusion parameters and the detector parameters that
@@ -153,8 +152,6 @@ class _Adaptive(_EpisodeModel):
         chunk = int(getattr(self.config, "EPISODE_CHUNK", 16))
         if chunk <= 0:
             return self._forward_sequential(data)
-        if not self.fusion_batched:
-            chunk = 1   # the decoder-style fusion is only defined for one sequence at a time (new_transformer.py)
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
@@ -331,7 +328,6 @@ class interactron(_Adaptive):
 
 class interactron_random(_Adaptive):
     use_policy = False
-    fusion_batched = False
 
     def __init__(self, config):
         super().__init__()
@@ -358,16 +354,39 @@ class detr_multiframe(_EpisodeModel):
                 "pred_logits": out["pred_logits"].view(b, s, *out["pred_logits"].shape[1:])}
 
     def forward(self, data):
+        """reference detr_multiframe.py:55-109 (criterion on the fusion outputs, one backward per episode).  The weights
+        are shared by all episodes here, so a chunk of episodes is simply one batch: detector on E*5 frames, fusion
+        with batch E, one matcher pass, the per-episode criteria summed into one backward (EPISODE_CHUNK: 0 keeps the
+        task-by-task loop)."""
+        chunk = int(getattr(self.config, "EPISODE_CHUNK", 16))
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         losses, lo, bo = [], [], []
-        for task in range(b):
-            out = self.fusion(_lift(self.detector(NestedTensor(img[task], mask[task]))))
-            loss = self.criterion(out, _labels(data, task), background_c=0.1)
-            _weighted(loss).backward()
-            losses.append({k: v.detach() for k, v in loss.items()})
-            lo.append(out["pred_logits"][0:1].detach())
-            bo.append(out["pred_boxes"][0:1].detach())
+        if chunk <= 0:
+            for task in range(b):
+                out = self.fusion(_lift(self.detector(NestedTensor(img[task], mask[task]))))
+                loss = self.criterion(out, _labels(data, task), background_c=0.1)
+                _weighted(loss).backward()
+                losses.append({k: v.detach() for k, v in loss.items()})
+                lo.append(out["pred_logits"][0:1].detach())
+                bo.append(out["pred_boxes"][0:1].detach())
+        for e0 in range(0, b if chunk > 0 else 0, max(chunk, 1)):
+            E = min(chunk, b - e0)
+            labels = [_labels(data, t) for t in range(e0, e0 + E)]
+            det = self.detector(NestedTensor(img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)))
+            out = self.fusion({k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in det.items()})
+            logits = out["pred_logits"].reshape(E * s, *out["pred_logits"].shape[-2:])
+            boxes = out["pred_boxes"].reshape(E * s, *out["pred_boxes"].shape[-2:])
+            idx = self.criterion.matcher({"pred_logits": logits, "pred_boxes": boxes}, [l for ep in labels for l in ep])
+            total = None
+            for i in range(E):
+                o = {"pred_logits": logits[i * s:(i + 1) * s], "pred_boxes": boxes[i * s:(i + 1) * s]}
+                loss = self.criterion(o, labels[i], background_c=0.1, indices=idx[i * s:(i + 1) * s])
+                total = _weighted(loss) if total is None else total + _weighted(loss)
+                losses.append({k: v.detach() for k, v in loss.items()})
+                lo.append(o["pred_logits"][0:1].detach())
+                bo.append(o["pred_boxes"][0:1].detach())
+            total.backward()
         return {"pred_logits": torch.stack(lo, dim=0), "pred_boxes": torch.stack(bo, dim=0)}, \
             _mean_losses(losses, "loss_detector")
 

@@ -179,7 +179,8 @@ class DecoderTransformer(nn.Module):
     def forward(self, x):
         img, pred = _token_inputs(self, x)
         b, s, p, n = pred.shape
-        assert b == 1, "the reference indexes the decoder output as [1, tokens, ...]; only b == 1 is defined"
+        # (the reference indexes the decoder output as [1, tokens, ...], i.e. b == 1; b > 1 = independent sequences, used
+        #  by the episode-batched training step)
         dev = pred.device
         mem_len, L = 5 * self.img_len, self.img_len
         parts = [img.reshape(b, -1, n)]

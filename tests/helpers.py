@@ -34,8 +34,10 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     if g.numel() == 1:
         # a one-element gradient (the scalar bias of the learned-loss head) is a single, heavily cancelling sum: float32
         # implementations scatter by 0.1-0.7 % around the float64 value on it (the reference itself is 0.56 % off in G13),
-        # and there are no other elements to average that noise out of the norm
-        rel = max(rel, 2e-2)
+        # and run to run it is bimodal (eight runs of config 3: 6.77e-5 x5, 6.93e-5 x3 -- an element of the clipped inner
+        # SGD step or a ReLU sitting on its kink flips with the summation order); there are no other elements to average
+        # that out of the norm (tools/scalar_spread.py)
+        rel = max(rel, 5e-2)
     assert abs(n - rec["norm"]) <= rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (what, n, rec["norm"], norm64)
     scale = max(rec["norm"] / max(g.numel(), 1) ** 0.5, 1e-12)
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
