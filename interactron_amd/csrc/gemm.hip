@@ -283,6 +283,12 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // v_cvt_pk_
 
 // (x0, x1) -> packed bf16 pairs of the three planes
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#ifdef X6_DIAG_NOCONV   // diagnostic build: no conversion arithmetic (wrong numbers), isolates the producers' VALU cost
+    h = __float_as_uint(x0);
+    m = __float_as_uint(x1);
+    l = h ^ m;
+    return;
+#endif
     h = pack_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
     m = pack_bf16(r0, r1);
@@ -749,8 +755,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 #define X6_TERM(FA, FB, PA_, PB_)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =        \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i][PA_], FB[j][PB_], acc[i][j], 0, 0, 0);
+#ifdef X6_DIAG_NOMMA    // diagnostic build: one MFMA term instead of six (wrong numbers), isolates the consumers' MFMA cost
+#define X6_MMA(FA, FB) X6_TERM(FA, FB, 0, 0)
+#else
 #define X6_MMA(FA, FB)  \
     X6_TERM(FA, FB, 2, 0) X6_TERM(FA, FB, 1, 1) X6_TERM(FA, FB, 0, 2) X6_TERM(FA, FB, 1, 0) X6_TERM(FA, FB, 0, 1) X6_TERM(FA, FB, 0, 0)
+#endif
     for (; w < last; w += stride) {
         const X6Item it = x6_item<BN>(p, w);
         f32x16 acc[TM][TN];
