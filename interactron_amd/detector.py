@@ -22,6 +22,7 @@ class NestedTensor(object):
     def __init__(self, tensors, mask):
         self.tensors = tensors
         self.mask = mask
+        self.stem = None   # optional: precomputed frozen stem features of `tensors` (ResNet50Body.frozen_stem)
 
     def to(self, device):
         return NestedTensor(self.tensors.to(device), None if self.mask is None else self.mask.to(device))
@@ -76,9 +77,12 @@ class ResNet50Body(nn.Module):
         self.layer3 = _make_layer(512, 256, 6, 2, 1, 1)
         self.layer4 = _make_layer(1024, 512, 3, 1, 1, 2)
 
-    def forward(self, frames_nchw):
+    def frozen_stem(self, frames_nchw):
+        """conv1 / bn1 / maxpool / layer1: frozen and fed by inputs without gradient (reference backbone.py:61-63), so the
+        result depends on the frames only -- the episode models compute it once per chunk and reuse it for the adapted
+        forwards (``NestedTensor.stem``)."""
         n, c, H, W = frames_nchw.shape
-        with torch.no_grad():   # conv1 / bn1 / layer1 are frozen and the input carries no gradient (backbone.py:61-63)
+        with torch.no_grad():
             g = ops.conv_geom(n, H, W, c, 7, 7, 2, 3, 1)
             cols = ops.im2col_any_layout(frames_nchw, g, channels_last=False)
             w = self.conv1.weight.permute(0, 2, 3, 1).reshape(64, -1)
@@ -87,7 +91,10 @@ class ResNet50Body(nn.Module):
             x = ops.linear(cols, w).reshape(n, g.OH, g.OW, 64)
             x = self.bn1(x, relu=True)
             x = ops.maxpool_nhwc(x, 3, 2, 1)
-            x = self.layer1(x)
+            return self.layer1(x)
+
+    def forward(self, frames_nchw, stem=None):
+        x = stem if stem is not None else self.frozen_stem(frames_nchw)
         x = self.layer2(x)
         x = self.layer3(x)
         return self.layer4(x)
@@ -103,7 +110,7 @@ class Backbone(nn.Module):
                 p.requires_grad_(False)
 
     def forward(self, tensor_list):
-        feat = self.body(tensor_list.tensors)                       # [n, h, w, 2048]
+        feat = self.body(tensor_list.tensors, getattr(tensor_list, "stem", None))   # [n, h, w, 2048]
         m = tensor_list.mask
         assert m is not None
         mask = ops.mask_nearest((m != 0).to(torch.uint8).contiguous(), feat.shape[1], feat.shape[2])

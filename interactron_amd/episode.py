@@ -170,7 +170,10 @@ class _Adaptive(_EpisodeModel):
                 dtheta = [ops.BcastRows.apply(p.detach().reshape(-1), E).reshape((E,) + tuple(p.shape)).requires_grad_(True)
                           for p in theta]
                 set_parameters(self.detector, dtheta)
-                pre = self.detector(NestedTensor(frames, masks))
+                # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
+                nt = NestedTensor(frames, masks)
+                nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
+                pre = self.detector(nt)
                 pt.mark("1 detector fwd (theta)")
                 pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
                 fusion_out = self.fusion(pre)
@@ -180,7 +183,7 @@ class _Adaptive(_EpisodeModel):
                 grads = torch.autograd.grad(learned, dtheta, create_graph=True, retain_graph=True, allow_unused=True)
                 pt.mark("3 learned-loss grad (create_graph)")
                 set_parameters(self.detector, sgd_step(dtheta, grads, lr))
-                post = self.detector(NestedTensor(frames, masks))
+                post = self.detector(nt)
                 pt.mark("4 inner SGD + detector fwd (theta')")
                 actions_out = fusion_out["actions"].reshape(E, 4, 4)
                 # ONE matcher pass for the whole chunk (matching is per image, so the assignments are exactly those of
@@ -197,7 +200,9 @@ class _Adaptive(_EpisodeModel):
                 set_parameters(self.detector, fast1)
                 ridx = [random.randint(0, 4) for _ in ep]
                 sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
-                post1 = self.detector(NestedTensor(frames[sel], masks[sel]))
+                nt1 = NestedTensor(frames[sel], masks[sel])
+                nt1.stem = nt.stem[sel]
+                post1 = self.detector(nt1)
                 post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
                 match1 = self.criterion.matcher.begin(post1_lb, [labels[i][ridx[i]] for i in range(E)])
                 pt.mark("5 first-order SGD + 1-frame fwd (queued early)")
