@@ -625,7 +625,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
 // overlap; with one workgroup per CU nothing else would hide them (K = 256 / 64 shapes spend a third of their time
 // there).  Work items are dealt per XCD (workgroup g serves XCD g & 7 = blockIdx % 8, the observed placement): each XCD
 // walks one contiguous eighth of the grouped tile order, which keeps neighbouring tiles in one L2.
-// Barriers per item, both roles: 1 (first tile visible) + nk (K steps) + 2 (C tile staged / stored).
+// Barriers, both roles: one per flat K tile of the workgroup's item stream.  The epilogue needs none: every consumer wave
+// transposes its own accumulators through a PRIVATE LDS strip (outside the operand buffers) into 16-byte row-major
+// stores, so the producers convert the next item's first K tile into the operand buffers while the consumers are
+// still writing the current C tile -- short-K items (K = 64 / 32 attention products) are mostly epilogue otherwise.
 // ------------------------------------------------------------------------------------------------------------
 struct X6Item {
     const float* A;
@@ -659,14 +662,74 @@ __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     return it;
 }
 
+#ifdef X6_DIAG_TIMING   // diagnostic build (tools/gemm_diag.py): clock stamps of workgroup 0's first producer / consumer wave
+__device__ long long x6_dbg[2][1024];
+#define X6_STAMP(ROLE, TAG)                                                           \
+    if (blockIdx.x == 0 && lane == 0 && wave == ((ROLE) ? 4 : 0) && dbgn < 511) {     \
+        x6_dbg[ROLE][2 * dbgn] = (TAG);                                               \
+        x6_dbg[ROLE][2 * dbgn + 1] = clock64();                                       \
+        ++dbgn;                                                                       \
+    }
+extern "C" int ix_gemm_dbg_read(long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(x6_dbg), sizeof(x6_dbg));
+}
+// write-pattern probe: 256 persistent workgroups store bm x bn tiles of a [batch, M, ldc] tensor (no compute), tiles dealt
+// like the GEMM's (order 0: per-XCD contiguous chunks of the m-fastest grouped order; 1: plain round robin, n fastest)
+__global__ __launch_bounds__(256) void diag_tile_fill_kernel(float* C, int M, int N, int64_t ldc, int batch, int bm, int bn, int order) {
+    const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, nt = tm * tn, total = nt * batch;
+    const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int last = order == 0 ? min(total, (xcd + 1) * per_xcd) : total;
+    int w = order == 0 ? xcd * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int step = order == 0 ? stride : gridDim.x;
+    const int cpr = bn / 4;
+    for (; w < last; w += step) {
+        const int zb = w / nt, tile = w % nt;
+        int m0, n0;
+        if (order == 0) {
+            const int gs = 8 * tn, fm = (tile / gs) * 8, gm = min(tm - fm, 8);
+            m0 = (fm + (tile % gs) % gm) * bm;
+            n0 = ((tile % gs) / gm) * bn;
+        } else {
+            m0 = (tile / tn) * bm;
+            n0 = (tile % tn) * bn;
+        }
+        float* base = C + (int64_t)zb * M * ldc;
+        for (int c = threadIdx.x; c < bm * cpr; c += 256) {
+            const int gr = m0 + c / cpr, gc = n0 + (c % cpr) * 4;
+            if (gr < M && gc + 3 < N) *reinterpret_cast<float4*>(base + (int64_t)gr * ldc + gc) = make_float4(1.f, 2.f, 3.f, 4.f);
+        }
+    }
+}
+extern "C" int ix_diag_tile_fill(float* C, int M, int N, int64_t ldc, int batch, int bm, int bn, int order, int grid, hipStream_t stream) {
+    hipLaunchKernelGGL(diag_tile_fill_kernel, dim3(grid), dim3(256), 0, stream, C, M, N, ldc, batch, bm, bn, order);
+    return (int)hipGetLastError();
+}
+#else
+#define X6_STAMP(ROLE, TAG)
+#endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's global-memory counter
+// (vmcnt(0)): in the persistent kernel that would make the consumers sit out the HBM acknowledgement of the C tile
+// they have just stored before they may join the next item's first barrier.  Global memory is never used to
+// communicate inside the workgroup, so only the LDS operations have to have completed.
+__device__ __forceinline__ void x6_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(GemmArgs p, int total_items) {
     constexpr int BM = X6_BT, BK = X6_BK;
     constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
     constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
+    constexpr int CP = WN + 4;                                           // pitch of a consumer wave's C strip (floats)
+    __shared__ __attribute__((aligned(16))) float cstrip[4][32 * CP];    // 32 rows x WN columns per consumer wave
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int dbgn = 0;
+    (void)dbgn;
     // this workgroup's items: w = first, first + stride, ... < last   (per-XCD contiguous chunks)
     const int per_xcd = (total_items + 7) >> 3, xcd = blockIdx.x & 7;
     const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
@@ -676,64 +739,69 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 
     if (wave >= 4) {
         // ------------------------------------------------ producers ------------------------------------------------
+        // One flat stream of K tiles over all of this workgroup's items: flat tile g lives in ring stage g % 3 and LDS
+        // buffer g & 1, and is requested three flat tiles ahead -- for K = 64 that is one and a half items ahead, so
+        // the HBM round trip of an item's first tile is hidden behind the previous items, not exposed once per item.
+        // Two cursors walk the (item, K tile) sequence: L (next tile to request) runs three tiles ahead of S (next
+        // tile to convert and store).
         const int pt = tid - 256, lda = (int)p.lda, ldb = (int)p.ldb;
         static_assert(SplitLoader<BM, A_KC>::NI == 4, "the A stage is four 16-byte loads per thread");
         constexpr int NB_ = SplitLoader<BN, B_KC>::NI;
         static_assert(NB_ == 4 || NB_ == 2 || NB_ == 1, "unexpected ring stage size");
         SplitLoader<BM, A_KC> a0, a1, a2;
         SplitLoader<BN, B_KC> b0, b1, b2;
-        X6Item it = x6_item<BN>(p, w);
-        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)it.A, 0, (int)(p.extA * 4), 0x00020000);
-        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)it.B, 0, (int)(p.extB * 4), 0x00020000);
-#define X6_LD(SA, SB, T, OK)                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    SA.load(rA, lda, it.m0, it.kbeg + (T) * BK, p.M, it.kend, pt, (OK) && (T) < it.nk);        \
-    SB.load(rB, ldb, it.n0, it.kbeg + (T) * BK, p.N, it.kend, pt, (OK) && (T) < it.nk);        \
-    __builtin_amdgcn_sched_barrier(0);
-#define X6_ST(SA, SB, T)                                                                              \
-    X6_WAIT_STAGE(SA, SB, 2)                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                                \
-    if ((T) < it.nk) {                                                                                \
-        SA.store(lds[(T) & 1], pt, it.kbeg + (T) * BK, it.kend);                                      \
-        SB.store(lds[(T) & 1] + 3 * PLANE_A, pt, it.kbeg + (T) * BK, it.kend);                        \
-    }                                                                                                 \
-    __builtin_amdgcn_sched_barrier(0);
-        X6_LD(a0, b0, 0, true)
-        X6_LD(a1, b1, 1, true)
-        X6_LD(a2, b2, 2, true)
+        X6Item itL = x6_item<BN>(p, w), itS = itL;
+        int wL = w, tL = 0, wS = w, tS = 0, buf = 0;
+        bool moreL = true, moreS = true;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, (int)(p.extA * 4), 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, (int)(p.extB * 4), 0x00020000);
+        // (no next tile: same instructions with out-of-range offsets -- the loads must never sit in a branch)
+#define X6_LD(SA, SB)                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    SA.load(rA, lda, itL.m0, itL.kbeg + tL * BK, p.M, itL.kend, pt, moreL);                     \
+    SB.load(rB, ldb, itL.n0, itL.kbeg + tL * BK, p.N, itL.kend, pt, moreL);                     \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (++tL >= itL.nk) {                                                                       \
+        tL = 0;                                                                                 \
+        wL += stride;                                                                           \
+        moreL = wL < last;                                                                      \
+        itL = x6_item<BN>(p, moreL ? wL : last - 1);                                            \
+        rA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, (int)(p.extA * 4), 0x00020000); \
+        rB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, (int)(p.extB * 4), 0x00020000); \
+    }
+#define X6_STEP(SA, SB)                                                                         \
+    X6_STAMP(1, 0)                                                                              \
+    X6_WAIT_STAGE(SA, SB, 2)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    X6_STAMP(1, 1)                                                                              \
+    SA.store(lds[buf], pt, itS.kbeg + tS * BK, itS.kend);                                       \
+    SB.store(lds[buf] + 3 * PLANE_A, pt, itS.kbeg + tS * BK, itS.kend);                         \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    X6_STAMP(1, 2)                                                                              \
+    buf ^= 1;                                                                                   \
+    if (++tS >= itS.nk) {                                                                       \
+        tS = 0;                                                                                 \
+        wS += stride;                                                                           \
+        moreS = wS < last;                                                                      \
+        if (moreS) itS = x6_item<BN>(p, wS);                                                    \
+    }                                                                                           \
+    X6_LD(SA, SB)                                                                               \
+    X6_STAMP(1, 3)                                                                              \
+    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */ \
+    X6_STAMP(1, 4)
+        X6_LD(a0, b0)
+        X6_LD(a1, b1)
+        X6_LD(a2, b2)
         for (;;) {
-            X6_ST(a0, b0, 0)
-            X6_LD(a0, b0, 3, true)
-            __syncthreads();   // tile 0 of this item is visible
-            for (int kt = 0; kt < it.nk; kt += 3) {
-                X6_ST(a1, b1, kt + 1)
-                X6_LD(a1, b1, kt + 4, true)
-                __syncthreads();
-                if (kt + 1 >= it.nk) break;
-                X6_ST(a2, b2, kt + 2)
-                X6_LD(a2, b2, kt + 5, true)
-                __syncthreads();
-                if (kt + 2 >= it.nk) break;
-                X6_ST(a0, b0, kt + 3)
-                X6_LD(a0, b0, kt + 6, true)
-                __syncthreads();
-            }
-            // request the next item's first three K tiles now: they fly while the consumers run this item's epilogue.
-            // (No next item: same instructions with out-of-range offsets -- the loads must never sit in a branch.)
-            w += stride;
-            const bool more = w < last;
-            it = x6_item<BN>(p, more ? w : last - 1);
-            rA = __builtin_amdgcn_make_buffer_rsrc((void*)it.A, 0, (int)(p.extA * 4), 0x00020000);
-            rB = __builtin_amdgcn_make_buffer_rsrc((void*)it.B, 0, (int)(p.extB * 4), 0x00020000);
-            X6_LD(a0, b0, 0, more)
-            X6_LD(a1, b1, 1, more)
-            X6_LD(a2, b2, 2, more)
-            __syncthreads();   // the C tile is staged in LDS
-            __syncthreads();   // ... and written out: the LDS buffers are free again
-            if (!more) break;
+            X6_STEP(a0, b0)
+            if (!moreS) break;
+            X6_STEP(a1, b1)
+            if (!moreS) break;
+            X6_STEP(a2, b2)
+            if (!moreS) break;
         }
 #undef X6_LD
-#undef X6_ST
+#undef X6_STEP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
         return;
     }
@@ -761,7 +829,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 #define X6_MMA(FA, FB)  \
     X6_TERM(FA, FB, 2, 0) X6_TERM(FA, FB, 1, 1) X6_TERM(FA, FB, 0, 2) X6_TERM(FA, FB, 1, 0) X6_TERM(FA, FB, 0, 1) X6_TERM(FA, FB, 0, 0)
 #endif
+    int buf = 0;
+    x6_lds_barrier();   // flat tile 0 is visible
+    X6_READ(fa0, fb0, lds[0], 0)
     for (; w < last; w += stride) {
+        X6_STAMP(0, 10)
         const X6Item it = x6_item<BN>(p, w);
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -770,36 +842,78 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        __syncthreads();   // tile 0 is visible
-        if (it.nk > 0) X6_READ(fa0, fb0, lds[0], 0)
+        X6_STAMP(0, 11)
         for (int kt = 0; kt < it.nk; ++kt) {
-            X6_READ(fa1, fb1, lds[kt & 1], 1)
+            X6_READ(fa1, fb1, lds[buf], 1)
             __builtin_amdgcn_sched_barrier(0);
             X6_MMA(fa0, fb0)
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (kt + 1 < it.nk) X6_READ(fa0, fb0, lds[(kt + 1) & 1], 0)
+            // the next flat tile (of this item, or the first one of the next item: its fragments then stay in
+            // registers across the epilogue) is complete behind this barrier; none after the very last tile
+            if (kt + 1 < it.nk || w + stride < last) {
+                X6_STAMP(0, 12)
+                x6_lds_barrier();
+                X6_STAMP(0, 13)
+                X6_READ(fa0, fb0, lds[buf ^ 1], 0)
+            }
             __builtin_amdgcn_sched_barrier(0);
             X6_MMA(fa1, fb1)
             __builtin_amdgcn_sched_barrier(0);
+            buf ^= 1;
         }
+        X6_STAMP(0, 14)
         const bool add_bias = it.bias != nullptr && it.ks == 0;
         if (staged) {
-            float* ct = reinterpret_cast<float*>(&lds[0][0]);
-            constexpr int CP = BN + 4;
+            float* ct = cstrip[wave];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int cl = wn + j * 32 + lcol;
                     const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        ct[(wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + cl] = p.alpha * acc[i][j][r] + bv;
+                        ct[((r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] = p.alpha * acc[i][j][r] + bv;
                 }
-            __syncthreads();   // staged
-            x6_store_tile<BN, 256>(ct, it.C, p.ldc, it.m0, it.n0, p.M, p.N, tid);
-            __syncthreads();   // stored
+                // same wave wrote and reads the strip: LDS operations of one wave execute in order (the wave barrier only
+                // keeps the compiler from moving the reads above the writes)
+                __builtin_amdgcn_wave_barrier();
+                constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;   // float4 chunks per strip row / per lane
+                const int r0 = it.m0 + wm + i * 32, c0 = it.n0 + wn;
+                if (r0 + 32 <= p.M && c0 + WN <= p.N) {
+                    // interior strip (wave-uniform test): all reads first, then all stores, no per-lane branches
+                    float4 v[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        v[q] = *reinterpret_cast<const float4*>(&ct[(c / CPR) * CP + (c % CPR) * 4]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+#ifdef X6_DIAG_NOSTORE   // diagnostic build: C is not written (isolates the store stream's cost)
+                        asm volatile("" ::"v"(v[q].x), "v"(v[q].y), "v"(v[q].z), "v"(v[q].w));
+#else
+                        *reinterpret_cast<float4*>(it.C + (int64_t)(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
+#endif
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        const int row = c / CPR, col = (c % CPR) * 4;
+                        const int gr = r0 + row, gc = c0 + col;
+                        if (gr >= p.M || gc >= p.N) continue;
+                        const float* src = &ct[row * CP + col];
+                        float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                        dst[0] = src[0];
+                        if (gc + 1 < p.N) dst[1] = src[1];
+                        if (gc + 2 < p.N) dst[2] = src[2];
+                        if (gc + 3 < p.N) dst[3] = src[3];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -822,8 +936,6 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
                     }
                 }
             }
-            __syncthreads();
-            __syncthreads();
         }
     }
 #undef X6_READ
