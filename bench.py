@@ -225,13 +225,15 @@ def main():
         k = 1 if kms[1] >= kms[0] else 0
         tf = [kfl[i] / (kms[i] * 1e-3) / 1e12 if kms[i] > 0 else 0.0 for i in range(2)]
         peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if k == 1 else FP32_MFMA_PEAK_TFLOPS
-        kname = "gemm_f32_bf16x6_kernel" if k == 1 else "gemm_f32_mfma_kernel"
+        kname = "gemm_f32_bf16x6_p12_kernel" if k == 1 else "gemm_f32_mfma_kernel"
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak, "traffic": pmc_traffic(kname),
                     "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
                     "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
                     "note": "achieved = fp32-equivalent algorithmic FLOP/s; executed bf16 MFMA rate = 6x that "
-                            "(%.0f of %.0f TFLOP/s)" % (6 * tf[1], BF16_MFMA_PEAK_TFLOPS),
+                            "(%.0f of %.0f TFLOP/s).  The peak assumes 2.4 GHz: back to back this kernel holds the package at "
+                            "its 1400 W cap and the shader clock at 1.4-1.8 GHz (profiles/README.md, power probe)"
+                            % (6 * tf[1], BF16_MFMA_PEAK_TFLOPS),
                     "fp32_mfma_kernel": {"achieved": tf[0], "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf[0] / FP32_MFMA_PEAK_TFLOPS,
                                          "launches_per_step": int(kn[0]), "kernel_ms_per_step": kms[0]},
                     "all_contractions": {"achieved": pf.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,

@@ -664,14 +664,19 @@ __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
 
 #ifdef X6_DIAG_TIMING   // diagnostic build (tools/gemm_diag.py): clock stamps of workgroup 0's first producer / consumer wave
 __device__ long long x6_dbg[2][1024];
+__device__ long long x6_dbg_wall[2][512];   // s_memrealtime (constant 100 MHz) next to every s_memtime stamp
 #define X6_STAMP(ROLE, TAG)                                                           \
     if (blockIdx.x == 0 && lane == 0 && wave == ((ROLE) ? 4 : 0) && dbgn < 511) {     \
         x6_dbg[ROLE][2 * dbgn] = (TAG);                                               \
         x6_dbg[ROLE][2 * dbgn + 1] = clock64();                                       \
+        x6_dbg_wall[ROLE][dbgn] = wall_clock64();                                     \
         ++dbgn;                                                                       \
     }
 extern "C" int ix_gemm_dbg_read(long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(x6_dbg), sizeof(x6_dbg));
+}
+extern "C" int ix_gemm_dbg_read_wall(long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(x6_dbg_wall), sizeof(x6_dbg_wall));
 }
 // write-pattern probe: 256 persistent workgroups store bm x bn tiles of a [batch, M, ldc] tensor (no compute), tiles dealt
 // like the GEMM's (order 0: per-XCD contiguous chunks of the m-fastest grouped order; 1: plain round robin, n fastest)
@@ -943,6 +948,265 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 #undef X6_MMA
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Twelve-wave form of the persistent kernel (768 threads, three waves per SIMD): waves 0-3 consume as before, waves
+// 4-7 produce the A operand's planes and waves 8-11 the B operand's.  Measured on gfx950 (tools/micro/valu_rate): one
+// wave issues a VALU instruction every ~4.5 clocks while the SIMD retires one every ~2.2, so a single producer wave
+// per SIMD leaves half of the conversion throughput unused and the K step was bound by it (consumers waited ~2000 of
+// every ~4000 clocks).  Two producer waves per SIMD halve the per-wave conversion work.  Three waves per SIMD leave 168
+// registers per wave, so the consumers keep ONE set of operand fragments and refill each plane as soon as its last
+// MFMA of the slice has issued (only plane 0, which is used last and needed first, is double-buffered):
+//     order per k-slice   l.h  h.l  m.m  m.h  h.m  h.h      (A plane, B plane)
+//     refill after        A.l  B.l   -   A.m  B.m   -        A.h / B.h of the next slice load at the slice start
+// ------------------------------------------------------------------------------------------------------------
+#define X6Q_WAIT1(S, CNT)                                                                                              \
+    if (NI_ == 4)                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(S.v[0]), "+v"(S.v[NI_ > 1 ? 1 : 0]), "+v"(S.v[NI_ > 2 ? 2 : 0]), \
+                     "+v"(S.v[NI_ > 3 ? 3 : 0])::"memory");                                                            \
+    else if (NI_ == 2)                                                                                                 \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(S.v[0]), "+v"(S.v[NI_ > 1 ? 1 : 0])::"memory");                \
+    else                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(" #CNT ")" : "+v"(S.v[0])::"memory");
+// the oldest ring stage has landed: two younger stages (2 * NI_ loads) may stay in flight
+#define X6Q_WAIT_STAGE(S)                                                                      \
+    if (NI_ == 4) { X6Q_WAIT1(S, 8) } else if (NI_ == 2) { X6Q_WAIT1(S, 4) } else { X6Q_WAIT1(S, 2) }
+
+// One operand's producer waves (256 threads): flat stream of K tiles over the workgroup's items, as in the 8-wave
+// kernel, for the A operand (IS_B false: BT = 128 rows of M) or the B operand (BT = BN rows of N).
+template <int BN, int BT, bool KC, bool IS_B>
+__device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int buf_bytes,
+                                            int plane_off, int pt) {
+    constexpr int BK = X6_BK;
+    constexpr int NI_ = SplitLoader<BT, KC>::NI;
+    static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
+    SplitLoader<BT, KC> s0, s1, s2;
+    const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
+    const int ext = (int)((IS_B ? p.extB : p.extA) * 4);
+    X6Item itL = x6_item<BN>(p, w), itS = itL;
+    int wL = w, tL = 0, wS = w, tS = 0, buf = 0;
+    bool moreL = true, moreS = true;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
+#define X6Q_LD(S)                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    S.load(rs, ld, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, tmax, itL.kend, pt, moreL);                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (++tL >= itL.nk) {                                                                                   \
+        tL = 0;                                                                                             \
+        wL += stride;                                                                                       \
+        moreL = wL < last;                                                                                  \
+        itL = x6_item<BN>(p, moreL ? wL : last - 1);                                                        \
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);          \
+    }
+#define X6Q_STEP(S)                                                                                         \
+    X6Q_WAIT_STAGE(S)                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    S.store(lds0 + buf * buf_bytes + plane_off, pt, itS.kbeg + tS * BK, itS.kend);                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    buf ^= 1;                                                                                               \
+    if (++tS >= itS.nk) {                                                                                   \
+        tS = 0;                                                                                             \
+        wS += stride;                                                                                       \
+        moreS = wS < last;                                                                                  \
+        if (moreS) itS = x6_item<BN>(p, wS);                                                                \
+    }                                                                                                       \
+    X6Q_LD(S)                                                                                               \
+    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */
+    X6Q_LD(s0)
+    X6Q_LD(s1)
+    X6Q_LD(s2)
+    for (;;) {
+        X6Q_STEP(s0)
+        if (!moreS) break;
+        X6Q_STEP(s1)
+        if (!moreS) break;
+        X6Q_STEP(s2)
+        if (!moreS) break;
+    }
+#undef X6Q_LD
+#undef X6Q_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
+}
+
+template <int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
+    constexpr int BM = X6_BT;
+    constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
+    constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
+    constexpr int CP = WN + 4;
+    __shared__ __attribute__((aligned(16))) float cstrip[4][32 * CP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int dbgn = 0;
+    (void)dbgn;
+    const int per_xcd = (total_items + 7) >> 3, xcd = blockIdx.x & 7;
+    const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
+    int w = xcd * per_xcd + (blockIdx.x >> 3);
+    if (w >= last) return;
+    const bool staged = p.split_k == 1 && p.c_vec;
+
+    if (wave >= 8) {
+        x6q_produce<BN, BN, B_KC, true>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - 512);
+        return;
+    }
+    if (wave >= 4) {
+        x6q_produce<BN, BM, A_KC, false>(p, w, stride, last, &lds[0][0], BUF, 0, tid - 256);
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
+    const int lrow = lane >> 5, lcol = lane & 31;
+    bf16x8 a0x[TM], a0y[TM], a1[TM], a2[TM], b0x[TN], b0y[TN], b1[TN], b2[TN];
+#define X6Q_LDA(DST, PL, BASE, S)                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) DST[i] = *reinterpret_cast<const bf16x8*>(                        \
+        (BASE) + (PL) * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + ((S) * 2 + lrow) * 16);
+#define X6Q_LDB(DST, PL, BASE, S)                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) DST[j] = *reinterpret_cast<const bf16x8*>(                        \
+        (BASE) + 3 * PLANE_A + (PL) * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + ((S) * 2 + lrow) * 16);
+#define X6Q_MM(FA, FB)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =         \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+#define X6Q_SB __builtin_amdgcn_sched_barrier(0);
+    // one k-slice on fragments (A0C, a1, a2, B0C, b1, b2); meanwhile the fragments of the NEXT slice (LDS buffer NBASE,
+    // slice NS) are fetched: plane 0 into (A0N, B0N), the others in place as soon as their last MFMA has issued
+#define X6Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                      \
+    X6Q_LDA(A0N, 0, NBASE, NS) X6Q_LDB(B0N, 0, NBASE, NS) X6Q_SB                                                      \
+    X6Q_MM(a2, B0C) X6Q_SB X6Q_LDA(a2, 2, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(A0C, b2) X6Q_SB X6Q_LDB(b2, 2, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(a1, b1) X6Q_SB                                                                                             \
+    X6Q_MM(a1, B0C) X6Q_SB X6Q_LDA(a1, 1, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(A0C, b1) X6Q_SB X6Q_LDB(b1, 1, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(A0C, B0C) X6Q_SB
+    int buf = 0;
+    x6_lds_barrier();   // flat tile 0 is visible
+    X6Q_LDA(a0x, 0, lds[0], 0) X6Q_LDA(a1, 1, lds[0], 0) X6Q_LDA(a2, 2, lds[0], 0)
+    X6Q_LDB(b0x, 0, lds[0], 0) X6Q_LDB(b1, 1, lds[0], 0) X6Q_LDB(b2, 2, lds[0], 0)
+    for (; w < last; w += stride) {
+        const X6Item it = x6_item<BN>(p, w);
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        X6_STAMP(0, 11)
+        for (int kt = 0; kt < it.nk; ++kt) {
+            X6Q_SB
+            X6Q_SLICE(a0x, b0x, a0y, b0y, lds[buf], 1)
+            X6_STAMP(0, 12)
+            // every read of this tile has been issued; the next flat tile (of this item or the next one) is complete
+            // behind the barrier -- none after the very last tile (its prefetch then re-reads this buffer, unused)
+            const bool more = kt + 1 < it.nk || w + stride < last;
+            if (more) x6_lds_barrier();
+            X6_STAMP(0, 13)
+            const unsigned char* nb = lds[more ? buf ^ 1 : buf];
+            X6Q_SB
+            X6Q_SLICE(a0y, b0y, a0x, b0x, nb, 0)
+            buf ^= 1;
+        }
+        X6_STAMP(0, 14)
+        const bool add_bias = it.bias != nullptr && it.ks == 0;
+        if (staged) {
+            float* ct = cstrip[wave];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn + j * 32 + lcol;
+                    const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ct[((r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] = p.alpha * acc[i][j][r] + bv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;
+                const int r0 = it.m0 + wm + i * 32, c0 = it.n0 + wn;
+                if (r0 + 32 <= p.M && c0 + WN <= p.N) {
+                    float4 v[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        v[q] = *reinterpret_cast<const float4*>(&ct[(c / CPR) * CP + (c % CPR) * 4]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        *reinterpret_cast<float4*>(it.C + (int64_t)(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        const int row = c / CPR, col = (c % CPR) * 4;
+                        const int gr = r0 + row, gc = c0 + col;
+                        if (gr >= p.M || gc >= p.N) continue;
+                        const float* src = &ct[row * CP + col];
+                        float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                        dst[0] = src[0];
+                        if (gc + 1 < p.N) dst[1] = src[1];
+                        if (gc + 2 < p.N) dst[2] = src[2];
+                        if (gc + 3 < p.N) dst[3] = src[3];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = it.n0 + wn + j * 32 + lcol;
+                    if (col >= p.N) continue;
+                    const float bv = add_bias ? it.bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = it.m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                        if (row < p.M) {
+                            const float v = p.alpha * acc[i][j][r] + bv;
+                            float* dst = it.C + (int64_t)row * p.ldc + col;
+                            if (p.split_k > 1)
+                                unsafeAtomicAdd(dst, v);
+                            else
+                                *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef X6Q_LDA
+#undef X6Q_LDB
+#undef X6Q_MM
+#undef X6Q_SB
+#undef X6Q_SLICE
+}
+
+template <int BN>
+static void launch_x6q_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true>), grid, dim3(768), 0, stream, a, items);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, false>), grid, dim3(768), 0, stream, a, items);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, true>), grid, dim3(768), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false>), grid, dim3(768), 0, stream, a, items);
+}
+
+static void launch_x6q(const GemmArgs& a, int bn, int a_kc, int b_kc, int items, hipStream_t stream) {
+    if (bn == 128)
+        launch_x6q_bn<128>(a, a_kc, b_kc, items, stream);
+    else if (bn == 64)
+        launch_x6q_bn<64>(a, a_kc, b_kc, items, stream);
+    else
+        launch_x6q_bn<32>(a, a_kc, b_kc, items, stream);
+}
+
 template <int BN>
 static void launch_x6p_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
     int g = (items + 7) / 8 * 8;
@@ -1016,7 +1280,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // a hipEvent pair around every contraction launch on its own stream, summed by ix_gemm_prof_read after a sync --
 // that is the "average launch duration measured with HIP events" the roofline fraction is computed from.
 #include <vector>
-static int g_x6 = 2;   // 2 (default): persistent bf16x6 kernel; 1: one-tile-per-workgroup bf16x6 kernel; 0: fp32 MFMA only
+static int g_x6 = 3;   // 3 (default): 12-wave persistent bf16x6 kernel; 2: 8-wave persistent; 1: one tile per workgroup; 0: fp32 MFMA only
 static double g_flops = 0.0;
 static int64_t g_launches = 0;
 static bool g_prof_on = false;
@@ -1036,7 +1300,7 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
 // from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
 extern "C" int ix_gemm_set_mode(int mode) {
     const int old = g_x6;
-    g_x6 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);   // 2: persistent bf16x6 kernel
+    g_x6 = mode < 0 ? 0 : (mode > 3 ? 3 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
     return old;
 }
 
@@ -1208,7 +1472,9 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     g_launches += 1;
     if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
     prof_mark(stream);
-    if (use_x6 && g_x6 == 2 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+    if (use_x6 && g_x6 == 3 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+        launch_x6q(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    else if (use_x6 && g_x6 == 2 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
         launch_x6p(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
     else if (use_x6)
         launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);

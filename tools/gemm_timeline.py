@@ -12,7 +12,7 @@ P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 lib.ix_gemm_f32.argtypes = [P, P, P, P, I, I, I, I, I, L, L, L, I, I, L, L, L, L, L, L, L, F, I, I, P]
 lib.ix_gemm_set_mode.argtypes = [I]
 lib.ix_gemm_dbg_read.argtypes = [P]
-lib.ix_gemm_set_mode(2)
+lib.ix_gemm_set_mode(int(os.environ.get("IX_MODE", "3")))
 M, N, K, b = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else (2060, 2060, 64, 128))]
 A = torch.randn(b, M * K, device="cuda"); B = torch.randn(b, K * N, device="cuda"); C = torch.empty(b, M, N, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
@@ -23,6 +23,16 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 2048)()
 assert lib.ix_gemm_dbg_read(buf) == 0
+wall = (ctypes.c_longlong * 1024)()
+lib.ix_gemm_dbg_read_wall.argtypes = [P]
+assert lib.ix_gemm_dbg_read_wall(wall) == 0
+for role in (0, 1):   # shader clock actually delivered while the kernel ran: s_memtime ticks per 10 ns s_memrealtime tick
+    n = 0
+    while n < 511 and buf[role * 1024 + 2 * n + 1]: n += 1
+    if n > 2:
+        dt = buf[role * 1024 + 2 * (n - 1) + 1] - buf[role * 1024 + 1]
+        dw = wall[role * 512 + n - 1] - wall[role * 512]
+        print("%s: %d stamps, %d s_memtime ticks over %d x 10 ns -> %.3f GHz" % ("producer" if role else "consumer", n, dt, dw, dt / max(dw, 1) / 10.0))
 ev = []
 for role in (0, 1):
     for i in range(511):
