@@ -99,6 +99,17 @@ int ix_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows,
                        ix_stream_t stream);
 int ix_softmax_bwd_bwd_f32(const float* G, const float* y, const float* dy, float* grad_y, float* grad_dy,
                            int64_t rows, int len, int64_t ld, ix_stream_t stream);
+/* Attention probabilities as one node: y = softmax(x [+ key mask]) (y may alias x), d = dropout(y) (d may be NULL);
+   its backward gs = softmax_bwd(y, dropout_bwd(gd)); and the double backward of that pair (HgD = dL/d gd, HS = dL/dx
+   given G1 + G2 = dL/d gs and HD = dL/d d).  Replaces the softmax -> dropout node pairs of
+   models/gpt.py:48-52 and nn.MultiheadAttention (models/detr_models/transformer.py:153,216,219) on the [L, S] tensors. */
+int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t rows, int len, int64_t ld, const uint8_t* mask,
+                         int rows_per_mask, int64_t mask_ld, float p, uint64_t seed, ix_stream_t stream);
+int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, int64_t rows, int len, int64_t ld, float p,
+                         uint64_t seed, ix_stream_t stream);
+int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const float* y, const float* gd, const float* HD,
+                             float* HgD, float* HS, int64_t rows, int len, int64_t ld, float p, uint64_t seed,
+                             ix_stream_t stream);
 int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                          int64_t rows, int D, float eps, int groups, ix_stream_t stream);
 int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -165,6 +165,172 @@ extern "C" int ix_softmax_bwd_bwd_f32(const float* G, const float* y, const floa
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Attention probabilities: softmax + dropout as ONE node and its first / second backward.  The [L, S] score tensors are
+// the largest tensors of the step (2 GB per fusion layer at 16 episodes); every separate elementwise node on them is
+// a full HBM round trip, so the dropout mask (a pure function of (seed, element index), same hash as dropout_kernel)
+// is applied inside the softmax kernels instead of in passes of its own.
+//   forward      y = softmax(x [+ key mask]),  d = m * y / keep
+//   backward     gs = y * (gy - sum(y * gy)),  gy = m * gd / keep
+//   double bwd   given G = dL/d(gs) and HD = dL/d(d) (both [L, S]):
+//                  s = sum(y gy), t = sum(y G)
+//                  HgD = m / keep * y (G - t)                              = dL/d(gd)
+//                  HY  = G (gy - s) - gy t + m / keep * HD                 = dL/d(y), all paths
+//                  HS  = y * (HY - sum(y HY))                              = dL/d(x) through the softmax
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t attn_mix32(uint64_t z) {   // == mix32 of elementwise.hip
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ float attn_keep(uint64_t seed, int64_t k, uint32_t thresh, float scale) {
+    if (thresh == 0) return 1.f;
+    return attn_mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull)) >= thresh ? scale : 0.f;
+}
+
+template <int NREG>
+__global__ __launch_bounds__(256) void attn_prob_fwd_kernel(const float* x, float* y, float* __restrict__ d, int64_t rows,
+                                                            int len, int64_t ld, const uint8_t* __restrict__ mask,
+                                                            int rows_per_mask, int64_t mask_ld, uint32_t thresh, float scale,
+                                                            uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ld;   // (y may alias x: a row is read completely before it is written)
+    float* yr = y + row * ld;
+    const uint8_t* mr = mask ? mask + (row / rows_per_mask) * mask_ld : nullptr;
+    float v[NREG];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        float t = -INFINITY;
+        if (c < len) {
+            t = xr[c];
+            if (mr && mr[c]) t = -INFINITY;
+        }
+        v[i] = t;
+        mx = fmaxf(mx, t);
+    }
+    mx = ix_wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        v[i] = __expf(v[i] - mx);
+        s += v[i];
+    }
+    s = ix_wave_sum(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ld) {   // pad columns [len, ld) are written as zeros: the tensors need no separate fill
+            const float val = c < len ? v[i] * inv : 0.f;
+            yr[c] = val;
+            if (d) d[row * ld + c] = val * attn_keep(seed, row * ld + c, thresh, scale);
+        }
+    }
+}
+
+extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t rows, int len, int64_t ld, const uint8_t* mask,
+                                    int rows_per_mask, int64_t mask_ld, float p, uint64_t seed, hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(x && y && ld >= len && ld <= 2304, "ix_attn_prob_fwd_f32: bad args (row pitch up to 2304)");
+    IX_CHECK_ARG(!mask || rows_per_mask > 0, "ix_attn_prob_fwd_f32: rows_per_mask must be > 0 with a mask");
+    IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_fwd_f32: p=%f outside [0,1)", p);
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const float scale = 1.f / (1.f - p);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define SM(N) hipLaunchKernelGGL(attn_prob_fwd_kernel<N>, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed)
+    if (ld <= 64) SM(1);
+    else if (ld <= 256) SM(4);
+    else if (ld <= 512) SM(8);
+    else if (ld <= 1024) SM(16);
+    else SM(36);
+#undef SM
+    IX_CHECK_LAUNCH("ix_attn_prob_fwd_f32");
+    return IX_OK;
+}
+
+__global__ __launch_bounds__(256) void attn_prob_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gd,
+                                                            float* __restrict__ gs, int64_t rows, int len, int64_t ld,
+                                                            uint32_t thresh, float scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) s += y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale));
+    s = ix_wave_sum(s);
+    for (int c = lane; c < ld; c += 64)
+        gs[off + c] = c < len ? y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale) - s) : 0.f;
+}
+
+extern "C" int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, int64_t rows, int len, int64_t ld, float p,
+                                    uint64_t seed, hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(y && gd && gs && ld >= len, "ix_attn_prob_bwd_f32: bad args");
+    IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_f32: p=%f outside [0,1)", p);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    hipLaunchKernelGGL(attn_prob_bwd_kernel, grid, dim3(256), 0, stream, y, gd, gs, rows, len, ld,
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+    IX_CHECK_LAUNCH("ix_attn_prob_bwd_f32");
+    return IX_OK;
+}
+
+// G = G1 + G2 (either may be null), HD may be null (no cotangent reached d); writes HgD and HS (see the block comment)
+__global__ __launch_bounds__(256) void attn_prob_bwd_bwd_kernel(const float* __restrict__ G1, const float* __restrict__ G2,
+                                                                const float* __restrict__ y, const float* __restrict__ gd,
+                                                                const float* __restrict__ HD, float* __restrict__ HgD,
+                                                                float* __restrict__ HS, int64_t rows, int len, int64_t ld,
+                                                                uint32_t thresh, float scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    // one reduction pass: with hy = g (gy - s) - gy t + hd m,  u = sum(y hy) = sum(y g gy) - 2 s t + sum(y hd m)
+    float s = 0.f, t = 0.f, a = 0.f, b = 0.f;
+    for (int c = lane; c < len; c += 64) {
+        const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
+        const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
+        const float gy = gd[off + c] * m;
+        s += yy * gy;
+        t += yy * g;
+        a += yy * g * gy;
+        if (HD) b += yy * (HD[off + c] * m);
+    }
+    s = ix_wave_sum(s);
+    t = ix_wave_sum(t);
+    const float u = ix_wave_sum(a + b) - 2.f * s * t;
+    for (int c = lane; c < ld; c += 64) {
+        float hgd = 0.f, hs = 0.f;
+        if (c < len) {
+            const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
+            const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
+            const float gy = gd[off + c] * m;
+            const float hy = g * (gy - s) - gy * t + (HD ? HD[off + c] * m : 0.f);
+            hgd = (yy * (g - t)) * m;
+            hs = yy * (hy - u);
+        }
+        HgD[off + c] = hgd;
+        HS[off + c] = hs;
+    }
+}
+
+extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const float* y, const float* gd, const float* HD,
+                                        float* HgD, float* HS, int64_t rows, int len, int64_t ld, float p, uint64_t seed,
+                                        hipStream_t stream) {
+    if (rows <= 0 || len <= 0) return IX_OK;
+    IX_CHECK_ARG(y && gd && HgD && HS && ld >= len, "ix_attn_prob_bwd_bwd_f32: bad args");
+    IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_bwd_f32: p=%f outside [0,1)", p);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
+    hipLaunchKernelGGL(attn_prob_bwd_bwd_kernel, grid, dim3(256), 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld,
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+    IX_CHECK_LAUNCH("ix_attn_prob_bwd_bwd_f32");
+    return IX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // LayerNorm over the last dim D (D <= 64*NREG), eps inside the sqrt, biased variance (torch semantics)
 // ------------------------------------------------------------------------------------------------------------
 template <int NREG>

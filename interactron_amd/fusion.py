@@ -41,9 +41,8 @@ class SelfAttention(nn.Module):
         H = self.NUM_HEADS
         hd = C // H
         k, q, v = self.key(x), self.query(x), self.value(x)
-        att = ops.attention_scores(q, k, B, H, T, T, hd, C, C, 0, 0, 1.0 / math.sqrt(hd))
-        att = self.attn_drop(ops.Softmax.apply(att, T, None, 0))
-        y = ops.attention_apply(att, v, B, H, T, T, hd, C, 0)
+        y = ops.attention(q, k, v, B, H, T, T, hd, C, C, 0, 0, C, 0, 1.0 / math.sqrt(hd), None, self.attn_drop.p,
+                          self.attn_drop.training)
         return self.resid_drop(self.proj(y))
 
 

@@ -169,6 +169,146 @@ def attention_apply(p, v, nbatch, heads, L, S, hd, v_ld, v_off):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# attention core as ONE autograd node (and its backward as one node)
+# ---------------------------------------------------------------------------------------------------------
+def _spec_dA(sp, a_shape):
+    """spec of dA for C = alpha A B with A stored untransposed: dA (MxK) = alpha dC (MxN) B^T; operands (dC, b)."""
+    assert not sp.A.trans
+    return GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B), View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si),
+                    a_shape, sp.alpha)
+
+
+def _spec_dB(sp, b_shape):
+    """spec of dB: B stored untransposed -> dB (KxN) = alpha A^T dC, operands (a, dC); B stored transposed (NxK rows)
+    -> dB^T = alpha dC^T A, operands (dC, a).  Returns (spec, dc_first)."""
+    out = View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si)
+    if not sp.B.trans:
+        return GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C, out, b_shape, sp.alpha), False
+    return GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A, out, b_shape, sp.alpha), True
+
+
+def _attn_specs(g):
+    Sp = (g.S + 3) // 4 * 4
+    E = g.heads * g.hd
+    tt = View(0, Sp, False, g.heads * g.L * Sp, g.L * Sp)
+    scores = GemmSpec(g.L, g.S, g.hd, g.n, g.heads, View(g.q_off, g.q_ld, False, g.L * g.q_ld, g.hd),
+                      View(g.k_off, g.k_ld, True, g.S * g.k_ld, g.hd), tt, (g.n, g.heads, g.L, Sp), g.scale)
+    apply_ = GemmSpec(g.L, g.hd, g.S, g.n, g.heads, tt, View(g.v_off, g.v_ld, False, g.S * g.v_ld, g.hd),
+                      View(0, E, False, g.L * E, g.hd), (g.n, g.L, E), 1.0)
+    return scores, apply_, Sp
+
+
+AttnGeom = namedtuple("AttnGeom", "n heads L S hd q_ld k_ld q_off k_off v_ld v_off scale")
+ATTN_FUSED_MAX_PITCH = 2304   # row pitch the register-resident fused softmax kernel covers
+
+
+def _sum2(a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    return Axpby.apply(a, b, 1.0, 1.0)
+
+
+class AttentionCore(Function):
+    """out[b,l,h*hd+:] = dropout(softmax(scale q k^T [+ key mask])) v  per (batch, head), as one node.
+
+    Same arithmetic as attention_scores -> Softmax -> dropout -> attention_apply, but the [L, S] tensors meet exactly
+    one elementwise kernel per pass (softmax+dropout fused, mask regenerated from the seed), autograd never sums
+    [L, S]-sized gradients, and the double backward (AttentionCoreBwd.backward) is written out by hand."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, g, mask, p, seed):
+        q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
+        sp_s, sp_a, Sp = _attn_specs(g)
+        y = _run_gemm(q, k, None, sp_s)
+        d = torch.empty_like(y) if p > 0.0 else None
+        _chk(_L().ix_attn_prob_fwd_f32(y.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None,
+                                       g.n * g.heads * g.L, g.S, Sp, mask.data_ptr() if mask is not None else None,
+                                       g.heads * g.L, mask.shape[-1] if mask is not None else 0, p, seed, _stream()),
+             "ix_attn_prob_fwd_f32")
+        if d is None:
+            d = y
+        ctx.g, ctx.p, ctx.seed = g, p, seed
+        ctx.save_for_backward(q, k, v, y, d)
+        return _run_gemm(d, v, None, sp_a)
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, y, d = ctx.saved_tensors
+        gq, gk, gv = AttentionCoreBwd.apply(q, k, v, y, d, do, ctx.g, ctx.p, ctx.seed)
+        return gq, gk, gv, None, None, None, None
+
+
+class AttentionCoreBwd(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, y, d, do, g, p, seed):
+        do = _req(do.contiguous(), "attention dO")
+        sp_s, sp_a, Sp = _attn_specs(g)
+        rows = g.n * g.heads * g.L
+        gd = _run_gemm(do, v, None, _spec_dA(sp_a, tuple(y.shape)))                 # dO v^T            [n,H,L,Sp]
+        gs = torch.empty_like(y)
+        _chk(_L().ix_attn_prob_bwd_f32(y.data_ptr(), gd.data_ptr(), gs.data_ptr(), rows, g.S, Sp, p, seed, _stream()),
+             "ix_attn_prob_bwd_f32")
+        gq = _run_gemm(gs, k, None, _spec_dA(sp_s, tuple(q.shape)))                 # scale gs k
+        s_k, dc_first = _spec_dB(sp_s, tuple(k.shape))
+        gk = _run_gemm(gs, q, None, s_k) if dc_first else _run_gemm(q, gs, None, s_k)   # scale gs^T q
+        s_v, dc_first_v = _spec_dB(sp_a, tuple(v.shape))
+        gv = _run_gemm(do, d, None, s_v) if dc_first_v else _run_gemm(d, do, None, s_v)  # d^T dO
+        ctx.g, ctx.p, ctx.seed = g, p, seed
+        ctx.save_for_backward(q, k, v, y, d, do, gd, gs)
+        return gq, gk, gv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hq, hk, hv):
+        q, k, v, y, d, do, gd, gs = ctx.saved_tensors
+        g, p, seed = ctx.g, ctx.p, ctx.seed
+        sp_s, sp_a, Sp = _attn_specs(g)
+        rows = g.n * g.heads * g.L
+        hq = _req(hq.contiguous()) if hq is not None else None
+        hk = _req(hk.contiguous()) if hk is not None else None
+        hv = _req(hv.contiguous()) if hv is not None else None
+        # G = dL/d gs = scale (hq k^T + q hk^T);  HD = dL/d d = dO hv^T
+        G1 = _run_gemm(hq, k, None, sp_s) if hq is not None else None
+        G2 = _run_gemm(q, hk, None, sp_s) if hk is not None else None
+        HD = _run_gemm(do, hv, None, _spec_dA(sp_a, tuple(y.shape))) if hv is not None else None
+        HgD, HS = torch.empty_like(y), torch.empty_like(y)
+        nul = lambda t: t.data_ptr() if t is not None else None
+        _chk(_L().ix_attn_prob_bwd_bwd_f32(nul(G1), nul(G2), y.data_ptr(), gd.data_ptr(), nul(HD), HgD.data_ptr(),
+                                           HS.data_ptr(), rows, g.S, Sp, p, seed, _stream()), "ix_attn_prob_bwd_bwd_f32")
+        del G1, G2, HD
+        s_q = _spec_dA(sp_s, tuple(q.shape))
+        s_k, kf = _spec_dB(sp_s, tuple(k.shape))
+        s_v, vf = _spec_dB(sp_a, tuple(v.shape))
+        rk = lambda dc, a: _run_gemm(dc, a, None, s_k) if kf else _run_gemm(a, dc, None, s_k)
+        need = ctx.needs_input_grad
+        grad_q = grad_k = grad_v = grad_do = None
+        if need[0]:   # scale (gs hk + HS k)
+            grad_q = _sum2(_run_gemm(gs, hk, None, s_q) if hk is not None else None, _run_gemm(HS, k, None, s_q))
+        if need[1]:   # scale (gs^T hq + HS^T q)
+            grad_k = _sum2(rk(gs, hq) if hq is not None else None, rk(HS, q))
+        if need[2]:   # HgD^T dO
+            grad_v = _run_gemm(do, HgD, None, s_v) if vf else _run_gemm(HgD, do, None, s_v)
+        if need[5]:   # d hv + HgD v
+            grad_do = _sum2(_run_gemm(d, hv, None, sp_a) if hv is not None else None, _run_gemm(HgD, v, None, sp_a))
+        return grad_q, grad_k, grad_v, None, None, grad_do, None, None, None
+
+
+def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, scale, mask, p, training):
+    """Scaled-dot-product attention out of packed projection buffers (see attention_scores / attention_apply for the
+    layouts); `mask`: optional uint8 key-padding mask [nbatch, S]."""
+    p = float(p) if training else 0.0
+    Sp = (S + 3) // 4 * 4
+    if Sp > ATTN_FUSED_MAX_PITCH:   # rows too long for the register-resident fused kernel: node-by-node form
+        att = attention_scores(q, k, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, scale)
+        att = Softmax.apply(att, S, mask, heads * L)
+        return attention_apply(dropout(att, p, training), v, nbatch, heads, L, S, hd, v_ld, v_off)
+    g = AttnGeom(nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, float(scale))
+    return AttentionCore.apply(q, k, v, g, mask, p, _next_seed() if p > 0.0 else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------
 # elementwise / broadcast
 # ---------------------------------------------------------------------------------------------------------
 class ColSum(Function):

@@ -99,13 +99,11 @@ class MultiheadAttention(nn.Module):
             k = ops.linear(key, W[E:2 * E], B[E:2 * E])
             q_ld, k_ld, q_off, k_off = E, E, 0, 0
         v = ops.linear(value, W[2 * E:], B[2 * E:])
-        scores = ops.attention_scores(q, k, n, H, L, S, hd, q_ld, k_ld, q_off, k_off, 1.0 / math.sqrt(hd))
         mask = None
         if key_padding_mask is not None:
             mask = key_padding_mask.to(torch.uint8).contiguous()
-        p = ops.Softmax.apply(scores, S, mask, H * L)
-        p = ops.dropout(p, self.dropout, self.training)
-        o = ops.attention_apply(p, v, n, H, L, S, hd, E, 0)
+        o = ops.attention(q, k, v, n, H, L, S, hd, q_ld, k_ld, q_off, k_off, E, 0, 1.0 / math.sqrt(hd), mask,
+                          self.dropout, self.training)
         return self.out_proj(o)
 
 

@@ -128,6 +128,64 @@ def test_packed_qk_projection_offsets(ops):
              name="packed qk")
 
 
+@pytest.mark.parametrize("n,H,L,S,hd,masked", [(2, 8, 50, 361, 32, True), (3, 4, 37, 37, 64, False), (2, 2, 70, 130, 32, True)])
+def test_attention_core_against_float64(ops, n, H, L, S, hd, masked):
+    """The one-node attention (scores -> softmax -> apply, no dropout) and its hand-written double backward."""
+    E = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    mask = torch.zeros(n, S, dtype=torch.uint8)
+    if masked:
+        mask[0, S - 5:] = 1
+        mask[-1, 3:9] = 1
+    mask_d = mask.cuda() if masked else None
+
+    def ref(q, k, v):
+        s = torch.einsum("blhd,bshd->bhls", q.view(n, L, H, hd), k.view(n, S, H, hd)) * scale
+        if masked:
+            s = s.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
+        return torch.einsum("bhls,bshd->blhd", s.softmax(-1), v.view(n, S, H, hd)).reshape(n, L, E)
+
+    def hip(q, k, v):
+        return ops.attention(q, k, v, n, H, L, S, hd, E, E, 0, 0, E, 0, scale, mask_d, 0.0, True)
+
+    check_op(hip, ref, [rnd(n, L, E), rnd(n, S, E), rnd(n, S, E)], name="attention core")
+
+
+def test_attention_core_packed_qk_and_dropout_match_node_by_node(ops):
+    """With dropout the fused node must reproduce the node-by-node graph (same seed -> same mask) at every
+    derivative level: output, gradients, and the gradient of a functional of the gradients."""
+    n, H, L, hd, p = 2, 4, 45, 32, 0.2
+    E = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    mask = torch.zeros(n, L, dtype=torch.uint8)
+    mask[1, L - 7:] = 1
+    mask = mask.cuda()
+
+    def fused(qk, v):
+        return ops.attention(qk, qk, v, n, H, L, L, hd, 2 * E, 2 * E, 0, E, E, 0, scale, mask, p, True)
+
+    def nodes(qk, v):
+        att = ops.attention_scores(qk, qk, n, H, L, L, hd, 2 * E, 2 * E, 0, E, scale)
+        att = ops.dropout(ops.Softmax.apply(att, L, mask, H * L), p, True)
+        return ops.attention_apply(att, v, n, H, L, L, hd, E, 0)
+
+    res = []
+    for fn in (fused, nodes):
+        ops.manual_seed(1234)
+        qk = rnd(n, L, 2 * E).cuda().requires_grad_(True)
+        v = rnd(n, L, E, seed=3).cuda().requires_grad_(True)
+        gy = rnd(n, L, E, seed=5).cuda().requires_grad_(True)
+        out = fn(qk, v)
+        g = torch.autograd.grad(out, [qk, v], gy, create_graph=True)
+        func = sum((a * rnd(*a.shape, seed=40 + i).cuda()).sum() for i, a in enumerate(g)) + (out * out).sum()
+        g2 = torch.autograd.grad(func, [qk, v, gy])
+        res.append([out] + list(g) + list(g2))
+    names = ["out", "d qk", "d v", "dd qk", "dd v", "dd gy"]
+    for name, a, b in zip(names, res[0], res[1]):
+        close(a, b, 2e-5, "fused vs nodes: " + name)
+    assert float((res[0][0] == 0).float().mean()) < 0.01   # (dropout really was active: outputs differ from p = 0)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw", [(64, 32, 3, 1, 1, 1, 19), (32, 64, 3, 2, 1, 1, 20),
                                                            (64, 64, 3, 1, 2, 2, 11), (128, 256, 1, 2, 0, 1, 15),
                                                            (256, 64, 1, 1, 0, 1, 9)])
