@@ -85,17 +85,26 @@ class _EpisodeModel(nn.Module):
 
 
 class _PhaseTimer:
-    """Optional per-phase wall-clock of one meta-train step (set ``model.phase_times = {}`` to enable): synchronises at
-    every phase boundary, so it is a diagnostic, never on in timed runs."""
+    """Optional per-phase clock of one meta-train step, a diagnostic that is never on in timed runs.
+    ``model.phase_times = {}``: synchronises at every phase boundary and accumulates wall-clock per phase.
+    ``model.phase_times = []``: no synchronisation -- appends (name, host time, HIP event) per boundary, so the lag of
+    the GPU behind the host (is the GPU ever starved?) can be read off afterwards (tools/phase_lag.py)."""
 
     def __init__(self, sink):
         self.sink = sink
-        if sink is not None:
+        if isinstance(sink, dict):
             torch.cuda.synchronize()
             self.t = time.perf_counter()
+        elif sink is not None:
+            self.mark("start")
 
     def mark(self, name):
         if self.sink is None:
+            return
+        if isinstance(self.sink, list):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.sink.append((name, time.perf_counter(), ev))
             return
         torch.cuda.synchronize()
         now = time.perf_counter()
