@@ -92,8 +92,16 @@ class SetCriterion(nn.Module):
         bs, Q, C = logits.shape
         num_boxes = max(float(sum(len(t["labels"]) for t in targets)), 1.0)
         batch_idx, src_idx = self._src_idx(indices)
-        flat_idx = (batch_idx * Q + src_idx).to(dev)
-        labels_o = torch.cat([t["labels"][J.to(t["labels"].device)] for t, (_, J) in zip(targets, indices)]).to(dev)
+        # matched (query, target) pairs of all images in ONE non-blocking upload: row 0 = flat query index, row 1 =
+        # index into the concatenated targets (reference detr.py:104-108,150-152 gathers image by image)
+        offs, n = [], 0
+        for t in targets:
+            offs.append(n)
+            n += len(t["labels"])
+        tgt_idx = torch.cat([J + o for (_, J), o in zip(indices, offs)])
+        pairs = ops.h2d_async(torch.stack([batch_idx * Q + src_idx, tgt_idx]))
+        flat_idx, tgt_idx = pairs[0], pairs[1]
+        labels_o = torch.cat([t["labels"] for t in targets])[tgt_idx]
         losses = {}
         argmax = None
         for loss in self.losses:
@@ -110,7 +118,7 @@ class SetCriterion(nn.Module):
                     acc = (argmax[flat_idx] == labels_o).float().sum() * (100.0 / labels_o.numel())
                 losses["class_error"] = 100 - acc
             elif loss == "boxes":
-                tgt_boxes = torch.cat([t["boxes"][i.to(t["boxes"].device)] for t, (_, i) in zip(targets, indices)], dim=0)
+                tgt_boxes = torch.cat([t["boxes"] for t in targets], dim=0)[tgt_idx]
                 sums = ops.BoxLoss.apply(boxes.reshape(bs * Q, 4), flat_idx, tgt_boxes)
                 losses["loss_bbox"] = sums[0] / num_boxes
                 losses["loss_giou"] = sums[1] / num_boxes
@@ -118,7 +126,7 @@ class SetCriterion(nn.Module):
                 with torch.no_grad():
                     if argmax is None:
                         argmax = logits.argmax(-1).reshape(-1)
-                    lengths = torch.as_tensor([len(v["labels"]) for v in targets], device=dev, dtype=torch.float32)
+                    lengths = ops.h2d_async(torch.tensor([float(len(v["labels"])) for v in targets]))
                     card = (argmax.view(bs, Q) != C - 1).sum(1).float()
                     losses["cardinality_error"] = (card - lengths).abs().mean()
             else:

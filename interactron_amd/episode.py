@@ -182,6 +182,10 @@ class _Adaptive(_EpisodeModel):
                 # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
                 nt = NestedTensor(frames, masks)
                 nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
+                # the first-order branch's random frame per episode (reference :126): drawn and uploaded before anything
+                # is queued -- a blocking upload later would make the host sit out the whole queue
+                ridx = [random.randint(0, 4) for _ in ep]
+                sel = ops.h2d_async(torch.tensor([i * s + r for i, r in enumerate(ridx)]))
                 pre = self.detector(nt)
                 pt.mark("1 detector fwd (theta)")
                 pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
@@ -207,8 +211,6 @@ class _Adaptive(_EpisodeModel):
                 attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
                 fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
                 set_parameters(self.detector, fast1)
-                ridx = [random.randint(0, 4) for _ in ep]
-                sel = torch.arange(E, device=frames.device) * s + torch.tensor(ridx, device=frames.device)
                 nt1 = NestedTensor(frames[sel], masks[sel])
                 nt1.stem = nt.stem[sel]
                 post1 = self.detector(nt1)
@@ -227,17 +229,20 @@ class _Adaptive(_EpisodeModel):
                         gts.append(_weighted(self.criterion(first, [labels[i][0]], background_c=0.1, indices=idx[:1])))
                 rewards = torch.stack(gts).tolist() if self.use_policy else None   # one D2H for all episodes
                 total = None
-                for i, t in enumerate(ep):
-                    sup = sups[i]
-                    if self.use_policy:
-                        gt = gts[i]
+                if self.use_policy:   # PathStorage bookkeeping on the host, in episode order; ONE upload of the labels
+                    best_host = []
+                    for i, t in enumerate(ep):
                         store = self.path_storage.setdefault(data["initial_image_path"][t], PathStorage())
                         actions = actions_host[t][:4]
                         store.add_path(actions, rewards[i])
-                        best = torch.tensor(store.get_label(actions), dtype=torch.long, device=gt.device)
-                        weight = torch.ones(4, device=gt.device)
-                        sup["loss_path"], _ = ops.WeightedCE.apply(actions_out[i], best, weight)
-                        sup["policy_reward"] = gt
+                        best_host.append(store.get_label(actions))
+                    best_all = ops.h2d_async(torch.tensor(best_host, dtype=torch.long))
+                    weight = torch.ones(4, device=frames.device)
+                for i, t in enumerate(ep):
+                    sup = sups[i]
+                    if self.use_policy:
+                        sup["loss_path"], _ = ops.WeightedCE.apply(actions_out[i], best_all[i], weight)
+                        sup["policy_reward"] = gts[i]
                     sup_losses.append({k: v.detach() for k, v in sup.items()})
                     tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
                     total = tl if total is None else total + tl

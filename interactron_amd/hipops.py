@@ -38,6 +38,17 @@ def _stream():
     return _raw_stream(_dev[0])
 
 
+def h2d_async(t):
+    """Host tensor -> current GPU through a pinned staging buffer, without blocking the host.  A plain ``.to(device)``
+    of pageable memory is stream-ordered AND host-blocking: the host then sits out everything queued before it (the
+    criterion's index tensors used to cost one such stall per image)."""
+    if t.numel() == 0:
+        return torch.empty(t.shape, dtype=t.dtype, device="cuda")
+    stage = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    stage.copy_(t)
+    return stage.to("cuda", non_blocking=True)
+
+
 class _NullCtx:
     """Stand-in for the autograd context when a Function's forward is run without recording (see Function.call)."""
     needs_input_grad = (False,) * 64
