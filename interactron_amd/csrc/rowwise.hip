@@ -252,6 +252,8 @@ extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t 
     return IX_OK;
 }
 
+// Rows up to 64 * NREG entries stay in registers between the reduction and the write: every operand is read once.
+template <int NREG>
 __global__ __launch_bounds__(256) void attn_prob_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gd,
                                                             float* __restrict__ gs, int64_t rows, int len, int64_t ld,
                                                             uint32_t thresh, float scale, uint64_t seed) {
@@ -259,26 +261,53 @@ __global__ __launch_bounds__(256) void attn_prob_bwd_kernel(const float* __restr
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t off = row * ld;
+    float yv[NREG], gy[NREG];
+    // all loads first (branch-free, clamped column), then the mask hash and the arithmetic: the row's 2 * NREG loads
+    // are in flight together
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = min(lane + 64 * i, len - 1);
+        yv[i] = y[off + c];
+        gy[i] = gd[off + c];
+    }
     float s = 0.f;
-    for (int c = lane; c < len; c += 64) s += y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale));
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        const bool in = c < len;
+        yv[i] = in ? yv[i] : 0.f;
+        gy[i] = in ? gy[i] * attn_keep(seed, off + c, thresh, scale) : 0.f;
+        s += yv[i] * gy[i];
+    }
     s = ix_wave_sum(s);
-    for (int c = lane; c < ld; c += 64)
-        gs[off + c] = c < len ? y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale) - s) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ld) gs[off + c] = c < len ? yv[i] * (gy[i] - s) : 0.f;
+    }
 }
 
 extern "C" int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, int64_t rows, int len, int64_t ld, float p,
                                     uint64_t seed, hipStream_t stream) {
     if (rows <= 0 || len <= 0) return IX_OK;
-    IX_CHECK_ARG(y && gd && gs && ld >= len, "ix_attn_prob_bwd_f32: bad args");
+    IX_CHECK_ARG(y && gd && gs && ld >= len && ld <= 2304, "ix_attn_prob_bwd_f32: bad args (row pitch up to 2304)");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_f32: p=%f outside [0,1)", p);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    hipLaunchKernelGGL(attn_prob_bwd_kernel, grid, dim3(256), 0, stream, y, gd, gs, rows, len, ld,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const float scale = 1.f / (1.f - p);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_kernel<N>, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed)
+    if (ld <= 64) SM(1);
+    else if (ld <= 256) SM(4);
+    else if (ld <= 512) SM(8);
+    else if (ld <= 1024) SM(16);
+    else SM(36);
+#undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_f32");
     return IX_OK;
 }
 
 // G = G1 + G2 (either may be null), HD may be null (no cotangent reached d); writes HgD and HS (see the block comment)
+template <int NREG>
 __global__ __launch_bounds__(256) void attn_prob_bwd_bwd_kernel(const float* __restrict__ G1, const float* __restrict__ G2,
                                                                 const float* __restrict__ y, const float* __restrict__ gd,
                                                                 const float* __restrict__ HD, float* __restrict__ HgD,
@@ -288,32 +317,50 @@ __global__ __launch_bounds__(256) void attn_prob_bwd_bwd_kernel(const float* __r
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t off = row * ld;
-    // one reduction pass: with hy = g (gy - s) - gy t + hd m,  u = sum(y hy) = sum(y g gy) - 2 s t + sum(y hd m)
-    float s = 0.f, t = 0.f, a = 0.f, b = 0.f;
-    for (int c = lane; c < len; c += 64) {
-        const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
-        const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
-        const float gy = gd[off + c] * m;
-        s += yy * gy;
-        t += yy * g;
-        a += yy * g * gy;
-        if (HD) b += yy * (HD[off + c] * m);
+    // one pass over the operands (kept in registers): with hy = g (gy - s) - gy t + hd m,
+    //   u = sum(y hy) = sum(y g gy) - 2 s t + sum(y hd m)
+    float yv[NREG], gv[NREG], gy[NREG], hd[NREG];
+    uint64_t kept = 0;
+    float s = 0.f, t = 0.f, a = 0.f;
+    // loads first (branch-free, clamped column; null operands are wave-uniform), then mask hash + arithmetic
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = min(lane + 64 * i, len - 1);
+        yv[i] = y[off + c];
+        gy[i] = gd[off + c];
+        gv[i] = G1 ? G1[off + c] : 0.f;
+        hd[i] = HD ? HD[off + c] : 0.f;
+    }
+    if (G2) {
+#pragma unroll
+        for (int i = 0; i < NREG; ++i) gv[i] += G2[off + min(lane + 64 * i, len - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        const bool in = c < len;
+        const float m = in ? attn_keep(seed, off + c, thresh, scale) : 0.f;
+        if (m != 0.f) kept |= 1ull << i;
+        yv[i] = in ? yv[i] : 0.f;
+        gv[i] = in ? gv[i] : 0.f;
+        gy[i] *= m;
+        hd[i] *= m;
+        s += yv[i] * gy[i];
+        t += yv[i] * gv[i];
+        a += yv[i] * gv[i] * gy[i] + yv[i] * hd[i];
     }
     s = ix_wave_sum(s);
     t = ix_wave_sum(t);
-    const float u = ix_wave_sum(a + b) - 2.f * s * t;
-    for (int c = lane; c < ld; c += 64) {
-        float hgd = 0.f, hs = 0.f;
-        if (c < len) {
-            const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
-            const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
-            const float gy = gd[off + c] * m;
-            const float hy = g * (gy - s) - gy * t + (HD ? HD[off + c] * m : 0.f);
-            hgd = (yy * (g - t)) * m;
-            hs = yy * (hy - u);
+    const float u = ix_wave_sum(a) - 2.f * s * t;
+#pragma unroll
+    for (int i = 0; i < NREG; ++i) {
+        const int c = lane + 64 * i;
+        if (c < ld) {
+            const float m = ((kept >> i) & 1) ? scale : 0.f;
+            const float hy = gv[i] * (gy[i] - s) - gy[i] * t + hd[i];
+            HgD[off + c] = c < len ? (yv[i] * (gv[i] - t)) * m : 0.f;
+            HS[off + c] = c < len ? yv[i] * (hy - u) : 0.f;
         }
-        HgD[off + c] = hgd;
-        HS[off + c] = hs;
     }
 }
 
@@ -321,11 +368,18 @@ extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const 
                                         float* HgD, float* HS, int64_t rows, int len, int64_t ld, float p, uint64_t seed,
                                         hipStream_t stream) {
     if (rows <= 0 || len <= 0) return IX_OK;
-    IX_CHECK_ARG(y && gd && HgD && HS && ld >= len, "ix_attn_prob_bwd_bwd_f32: bad args");
+    IX_CHECK_ARG(y && gd && HgD && HS && ld >= len && ld <= 2304, "ix_attn_prob_bwd_bwd_f32: bad args (row pitch up to 2304)");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_bwd_f32: p=%f outside [0,1)", p);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK));
-    hipLaunchKernelGGL(attn_prob_bwd_bwd_kernel, grid, dim3(256), 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const float scale = 1.f / (1.f - p);
+    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
+#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_bwd_kernel<N>, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed)
+    if (ld <= 64) SM(1);
+    else if (ld <= 256) SM(4);
+    else if (ld <= 512) SM(8);
+    else if (ld <= 1024) SM(16);
+    else SM(36);
+#undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_bwd_f32");
     return IX_OK;
 }
