@@ -318,8 +318,20 @@ class AttentionCoreBwd(Function):
         hk = _req(hk.contiguous()) if hk is not None else None
         hv = _req(hv.contiguous()) if hv is not None else None
         # G = dL/d gs = scale (hq k^T + q hk^T);  HD = dL/d d = dO hv^T
-        G1 = _run_gemm(hq, k, None, sp_s) if hq is not None else None
-        G2 = _run_gemm(q, hk, None, sp_s) if hk is not None else None
+        G2 = None
+        if hq is not None and hk is not None:
+            # both terms as ONE product over a doubled head dim, [hq | q] [k | hk]^T: the two small operand copies
+            # replace a whole [L, S] tensor written by one GEMM and read again by the kernel below
+            heads = lambda t, off, ld, rows: t.view(g.n, rows, ld)[..., off:off + g.heads * g.hd].reshape(g.n, rows, g.heads, g.hd)
+            a2 = torch.cat([heads(hq, g.q_off, g.q_ld, g.L), heads(q, g.q_off, g.q_ld, g.L)], -1)
+            b2 = torch.cat([heads(k, g.k_off, g.k_ld, g.S), heads(hk, g.k_off, g.k_ld, g.S)], -1)
+            E2 = 2 * g.heads * g.hd
+            sp2 = GemmSpec(g.L, g.S, 2 * g.hd, g.n, g.heads, View(0, E2, False, g.L * E2, 2 * g.hd),
+                           View(0, E2, True, g.S * E2, 2 * g.hd), sp_s.C, sp_s.out_shape, g.scale)
+            G1 = _run_gemm(a2, b2, None, sp2)
+            del a2, b2
+        else:
+            G1 = _run_gemm(hq, k, None, sp_s) if hq is not None else (_run_gemm(q, hk, None, sp_s) if hk is not None else None)
         HD = _run_gemm(do, hv, None, _spec_dA(sp_a, tuple(y.shape))) if hv is not None else None
         HgD, HS = torch.empty_like(y), torch.empty_like(y)
         nul = lambda t: t.data_ptr() if t is not None else None
