@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
     ap.add_argument("--config", default="interactron", choices=sorted(CONFIGS),
                     help="which reference config's training step to run (default: the headline meta-train step)")
+    ap.add_argument("--mode", default="train", choices=["train", "predict", "interactive"],
+                    help="train (default, the headline): meta-train step; predict: model.predict per episode (eval adapt, "
+                         "reference interactron.py:31-59); interactive: predict + 4 x get_next_action per episode (SURVEY 8d iii)")
     ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -161,6 +164,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()
+    if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
+        lib.ix_gemm_set_mode(int(os.environ["IX_GEMM_MODE"]))
 
     cfg, tokens = model_cfg(args.size, args.queries, args.chunk, CONFIGS[args.config][1])
     model = build_model(Config(**cfg))
@@ -176,10 +181,28 @@ def main():
 
     last = {}
 
+    def episode(i, frames=None):
+        d = {"frames": data["frames"][i:i + 1, :frames], "masks": data["masks"][i:i + 1, :frames],
+             "category_ids": [data["category_ids"][i][:frames]], "boxes": [data["boxes"][i][:frames]],
+             "actions": data["actions"][i:i + 1], "initial_image_path": [data["initial_image_path"][i]]}
+        return d
+
+    if args.mode != "train":   # evaluation modes: one episode at a time, as the reference evaluators call them
+        assert args.config in ("interactron", "interactron_random") or args.mode == "predict"
+        model.eval()
+
     def step():
-        _, losses = model(data)
-        last["losses"] = losses
-        outer.step()
+        if args.mode == "train":
+            _, losses = model(data)
+            last["losses"] = losses
+            outer.step()
+            return
+        for i in range(args.episodes):
+            if args.mode == "interactive":   # the policy looks at 1..4 frames, then the adapted prediction on all 5
+                for s in range(1, 5):
+                    model.get_next_action(episode(i, s))
+            out = model.predict(episode(i))
+            last["losses"] = {"pred_logits": out["pred_logits"]}
 
     def fence():
         if world > 1:
@@ -248,16 +271,21 @@ def main():
             "metric": "frames/sec (5-frame episodes)", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s training step (%s.forward + all-reduce + clip + Adam), "
-                                   "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode"
-                                   % (CONFIGS[args.config][0], CONFIGS[args.config][1], args.episodes, args.size, args.size,
-                                      args.queries, cfg["BLOCK_SIZE"]),
+            "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
+                                    "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode"
+                                    % (CONFIGS[args.config][0], CONFIGS[args.config][1], args.episodes, args.size, args.size,
+                                       args.queries, cfg["BLOCK_SIZE"])) if args.mode == "train" else
+                                   ("%s %s, one episode at a time (%d episodes/GPU x 5 frames x 3x%dx%d), eval mode"
+                                    % (CONFIGS[args.config][0], {"predict": "predict() (adapt + frame-0 prediction)",
+                                                                 "interactive": "interactive episode (4 x get_next_action + predict)"}
+                                       [args.mode], args.episodes, args.size, args.size)),
+                       "mode": args.mode,
                        "episodes_per_gpu": args.episodes, "frame_size": args.size, "parallelism": "dp%d" % world},
             "gemm_gflop_per_step": flops.value / 1e9 / args.steps, "gemm_launches_per_step": launches.value / args.steps,
             "roofline": roofline,
             "cpu_baseline": None,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.mode == "train":
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -335,11 +335,18 @@ typedef float x6_f32x4 __attribute__((ext_vector_type(4)));
         }                                                                                      \
     }
 
-template <int BT, bool KC>
+// SWZ: compact LDS image -- 64-byte rows (no padding) whose four 16-byte chunks are XOR-swizzled with bits 2-3 of the
+// row, which keeps the consumers' ds_read_b128 fragment reads conflict-free (a 16-lane read group covers rows with all
+// 16 combinations of row & 3 and (row >> 2) & 3) and frees 24 KB of LDS for full-size C strips (deferred C stores).
+template <int BT, bool KC, bool SWZ = false>
 struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
     static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
-    static constexpr int PLANE = BT * X6_ROWB;
+    static constexpr int ROWB = SWZ ? 64 : X6_ROWB;
+    static constexpr int PLANE = BT * ROWB;
     x6_f32x4 v[NI];
+    // KC operands: tile row of thread group g = tid >> 3 within a 32-row pass.  Padded image: rows 4 apart per 16-lane
+    // store group (see x6_kc_row); compact image: consecutive rows (different 64-byte segments of the bank window).
+    static __device__ __forceinline__ int kc_row(int tid) { return SWZ ? (tid >> 3) : x6_kc_row(tid); }
 
     // Branch-free: raw buffer loads (out-of-range bytes read as 0, so tiles past the K range or past the last row are
     // safe to request), tile rows clamped / surplus rows left as don't-care (they only feed C rows/cols that are never
@@ -355,7 +362,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         for (int i = 0; i < NI; ++i) {
             int off;
             if (KC)     // 4 consecutive k of tile row tr: a wave instruction reads 8 rows x 128 B
-                off = min(t0 + x6_kc_row(tid) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
+                off = min(t0 + kc_row(tid) + 32 * i, tmax - 1) * ld + k0 + (tid & 7) * 4;
             else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
                 off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
             off = valid ? off * 4 : 0x7ffffff0;
@@ -373,7 +380,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             float e0, e1, e2, e3;
             int row;
             if (KC) {
-                row = x6_kc_row(tid) + 32 * i;
+                row = kc_row(tid) + 32 * i;
                 e0 = v[i].x; e1 = v[i].y; e2 = v[i].z; e3 = v[i].w;
             } else {    // row i of this thread's 4x4 (k x row) register block
                 row = (tid >> 3) * 4 + i;
@@ -390,7 +397,8 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             unsigned h0, m0, l0, h1, m1, l1;
             split3(e0, e1, h0, m0, l0);
             split3(e2, e3, h1, m1, l1);
-            unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
+            unsigned char* dst = SWZ ? planes + row * 64 + ((((tid & 7) >> 1) ^ ((row >> 2) & 3)) << 4) + ((tid & 1) << 3)
+                                     : planes + row * X6_ROWB + (tid & 7) * 8;
             u32x2 ph, pm, pl;
             ph.x = h0; ph.y = h1; pm.x = m0; pm.y = m1; pl.x = l0; pl.y = l1;
             *(lds_u2*)(dst) = ph;
@@ -680,17 +688,18 @@ extern "C" int ix_gemm_dbg_read_wall(long long* dst) {
 }
 // write-pattern probe: 256 persistent workgroups store bm x bn tiles of a [batch, M, ldc] tensor (no compute), tiles dealt
 // like the GEMM's (order 0: per-XCD contiguous chunks of the m-fastest grouped order; 1: plain round robin, n fastest)
-__global__ __launch_bounds__(256) void diag_tile_fill_kernel(float* C, int M, int N, int64_t ldc, int batch, int bm, int bn, int order) {
+__global__ __launch_bounds__(1024) void diag_tile_fill_kernel(float* C, int M, int N, int64_t ldc, int batch, int bm, int bn, int order) {
     const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, nt = tm * tn, total = nt * batch;
     const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-    const int last = order == 0 ? min(total, (xcd + 1) * per_xcd) : total;
-    int w = order == 0 ? xcd * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    const int step = order == 0 ? stride : gridDim.x;
+    const bool grouped = (order & 1) == 0;   // order bit 0: tile order, bit 1: non-temporal stores
+    const int last = grouped ? min(total, (xcd + 1) * per_xcd) : total;
+    int w = grouped ? xcd * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const int step = grouped ? stride : gridDim.x;
     const int cpr = bn / 4;
     for (; w < last; w += step) {
         const int zb = w / nt, tile = w % nt;
         int m0, n0;
-        if (order == 0) {
+        if (grouped) {
             const int gs = 8 * tn, fm = (tile / gs) * 8, gm = min(tm - fm, 8);
             m0 = (fm + (tile % gs) % gm) * bm;
             n0 = ((tile % gs) / gm) * bn;
@@ -699,14 +708,25 @@ __global__ __launch_bounds__(256) void diag_tile_fill_kernel(float* C, int M, in
             n0 = (tile % tn) * bn;
         }
         float* base = C + (int64_t)zb * M * ldc;
-        for (int c = threadIdx.x; c < bm * cpr; c += 256) {
+        for (int c = threadIdx.x; c < bm * cpr; c += blockDim.x) {
             const int gr = m0 + c / cpr, gc = n0 + (c % cpr) * 4;
-            if (gr < M && gc + 3 < N) *reinterpret_cast<float4*>(base + (int64_t)gr * ldc + gc) = make_float4(1.f, 2.f, 3.f, 4.f);
+            if (gr < M && gc + 3 < N) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 v = {1.f, 2.f, 3.f, 4.f};
+                f4* dst = reinterpret_cast<f4*>(base + (int64_t)gr * ldc + gc);
+                if (order & 2)
+                    __builtin_nontemporal_store(v, dst);
+                else
+                    *dst = v;
+            }
         }
     }
 }
 extern "C" int ix_diag_tile_fill(float* C, int M, int N, int64_t ldc, int batch, int bm, int bn, int order, int grid, hipStream_t stream) {
-    hipLaunchKernelGGL(diag_tile_fill_kernel, dim3(grid), dim3(256), 0, stream, C, M, N, ldc, batch, bm, bn, order);
+    // order bits 8..: threads per workgroup / 64 (0 = 4 waves)
+    const int waves = (order >> 8) ? (order >> 8) : 4;
+    order &= 255;
+    hipLaunchKernelGGL(diag_tile_fill_kernel, dim3(grid), dim3(64 * waves), 0, stream, C, M, N, ldc, batch, bm, bn, order);
     return (int)hipGetLastError();
 }
 #else
@@ -973,13 +993,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 
 // One operand's producer waves (256 threads): flat stream of K tiles over the workgroup's items, as in the 8-wave
 // kernel, for the A operand (IS_B false: BT = 128 rows of M) or the B operand (BT = BN rows of N).
-template <int BN, int BT, bool KC, bool IS_B>
+template <int BN, int BT, bool KC, bool IS_B, bool SWZ>
 __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int buf_bytes,
                                             int plane_off, int pt) {
     constexpr int BK = X6_BK;
-    constexpr int NI_ = SplitLoader<BT, KC>::NI;
+    constexpr int NI_ = SplitLoader<BT, KC, SWZ>::NI;
     static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
-    SplitLoader<BT, KC> s0, s1, s2;
+    SplitLoader<BT, KC, SWZ> s0, s1, s2;
     const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
     const int ext = (int)((IS_B ? p.extB : p.extA) * 4);
     X6Item itL = x6_item<BN>(p, w), itS = itL;
@@ -1027,14 +1047,20 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
 }
 
-template <int BN, bool A_KC, bool B_KC>
+// DEFER (mode 4): compact swizzled operand image (SplitLoader SWZ) + one full-size private C strip per consumer wave, and
+// the C tile of item i leaves the strip as 16-byte stores interleaved into the MFMA stream of item i + 1.  Measured
+// (tools/micro/store_overlap, tools/tile_fill_nt.py): a wave completes one 1-KB store per ~300 clocks however it is
+// issued, but only stalls when the NEXT store comes sooner -- MFMAs issue underneath.  Back to back the 16 stores of a
+// sub-tile stall a consumer ~4600 clocks per item (a whole K = 64 item is ~8000 clocks of MFMA).
+template <int BN, bool A_KC, bool B_KC, bool DEFER>
 __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
     constexpr int BM = X6_BT;
-    constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
+    constexpr int ROWB = DEFER ? 64 : X6_ROWB;
+    constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 3 * (PLANE_A + PLANE_B);
     constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
-    constexpr int CP = WN + 4;
-    __shared__ __attribute__((aligned(16))) float cstrip[4][32 * CP];
+    constexpr int CP = DEFER ? WN : WN + 4, SROWS = DEFER ? WM : 32;
+    __shared__ __attribute__((aligned(16))) float cstrip[4][SROWS * CP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int dbgn = 0;
@@ -1046,38 +1072,80 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
     const bool staged = p.split_k == 1 && p.c_vec;
 
     if (wave >= 8) {
-        x6q_produce<BN, BN, B_KC, true>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - 512);
+        x6q_produce<BN, BN, B_KC, true, DEFER>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - 512);
         return;
     }
     if (wave >= 4) {
-        x6q_produce<BN, BM, A_KC, false>(p, w, stride, last, &lds[0][0], BUF, 0, tid - 256);
+        x6q_produce<BN, BM, A_KC, false, DEFER>(p, w, stride, last, &lds[0][0], BUF, 0, tid - 256);
         return;
     }
 
     // ---------------------------------------------------- consumers ----------------------------------------------------
     const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
     const int lrow = lane >> 5, lcol = lane & 31;
+    // byte offset of this lane's 16-byte fragment chunk inside its row, for k-slice 0 / 1 (compact image: swizzled with
+    // bits 2-3 of the row; the fragment row is wm|wn + 32 i + lcol with wm, wn multiples of 32)
+    const int swz = DEFER ? (lcol >> 2) & 3 : 0;
+    const int ko0 = (lrow ^ swz) * 16, ko1 = ((2 + lrow) ^ swz) * 16;
     bf16x8 a0x[TM], a0y[TM], a1[TM], a2[TM], b0x[TN], b0y[TN], b1[TN], b2[TN];
 #define X6Q_LDA(DST, PL, BASE, S)                                                                                    \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) DST[i] = *reinterpret_cast<const bf16x8*>(                        \
-        (BASE) + (PL) * PLANE_A + (wm + i * 32 + lcol) * X6_ROWB + ((S) * 2 + lrow) * 16);
+        (BASE) + (PL) * PLANE_A + (wm + i * 32 + lcol) * ROWB + ((S) ? ko1 : ko0));
 #define X6Q_LDB(DST, PL, BASE, S)                                                                                    \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) DST[j] = *reinterpret_cast<const bf16x8*>(                        \
-        (BASE) + 3 * PLANE_A + (PL) * PLANE_B + (wn + j * 32 + lcol) * X6_ROWB + ((S) * 2 + lrow) * 16);
+        (BASE) + 3 * PLANE_A + (PL) * PLANE_B + (wn + j * 32 + lcol) * ROWB + ((S) ? ko1 : ko0));
 #define X6Q_MM(FA, FB)                                                                                               \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =         \
         __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);
 #define X6Q_SB __builtin_amdgcn_sched_barrier(0);
     // one k-slice on fragments (A0C, a1, a2, B0C, b1, b2); meanwhile the fragments of the NEXT slice (LDS buffer NBASE,
     // slice NS) are fetched: plane 0 into (A0N, B0N), the others in place as soon as their last MFMA has issued
-#define X6Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                      \
+    // Deferred C stores of the previous item.  Per hook: store the strip chunk held in vq (unit dq), read the next one.
+    // The hooks are straight-line code (a branch inside the MFMA stream costs ~8 %: the waitcnt pass drains the
+    // rolling fragment loads at every block boundary), so K steps come in two copies -- with hooks while units are
+    // pending, plain otherwise -- and a hook past the last unit re-stores the last unit (idempotent, <= 5 per item).
+    // Hooks are >= ~300 clocks apart (three per slice on 4-MFMA groups, one per slice on narrower tiles): a wave
+    // completes one 1-KB store per ~300 clocks and only stalls when the next store comes sooner.
+    float* const ct = cstrip[wave];
+    constexpr int CPR = WN / 4, RPU = 64 / CPR;            // float4 chunks per strip row; strip rows per 64-lane unit
+    const int sl = (lane / CPR) * CP + (lane % CPR) * 4;   // this lane's float offset inside a unit
+    float* dC = nullptr;                                   // this lane's address in unit 0 of the pending tile
+    int64_t dstep = 0;                                     // floats between consecutive units (RPU rows of C)
+    int dn = 0, dq = 0;                                    // units of the pending tile / units stored so far
+    float4 vq = make_float4(0.f, 0.f, 0.f, 0.f);           // strip chunk of unit min(dq, dn - 1)
+#define X6Q_HOOK                                                                                                      \
+    {                                                                                                                 \
+        *reinterpret_cast<float4*>(dC + min(dq, dn - 1) * dstep) = vq;                                                \
+        ++dq;                                                                                                         \
+        vq = *reinterpret_cast<const float4*>(&ct[sl + min(dq, dn - 1) * (RPU * CP)]);                                \
+        X6Q_SB                                                                                                        \
+    }
+#define X6Q_HOOK3 if (TN == 2) X6Q_HOOK
+#define X6Q_NOHOOK
+#define X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, H3, H1)                                                              \
     X6Q_LDA(A0N, 0, NBASE, NS) X6Q_LDB(B0N, 0, NBASE, NS) X6Q_SB                                                      \
     X6Q_MM(a2, B0C) X6Q_SB X6Q_LDA(a2, 2, NBASE, NS) X6Q_SB                                                           \
-    X6Q_MM(A0C, b2) X6Q_SB X6Q_LDB(b2, 2, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(A0C, b2) X6Q_SB X6Q_LDB(b2, 2, NBASE, NS) X6Q_SB H3                                                        \
     X6Q_MM(a1, b1) X6Q_SB                                                                                             \
-    X6Q_MM(a1, B0C) X6Q_SB X6Q_LDA(a1, 1, NBASE, NS) X6Q_SB                                                           \
+    X6Q_MM(a1, B0C) X6Q_SB X6Q_LDA(a1, 1, NBASE, NS) X6Q_SB H3                                                        \
     X6Q_MM(A0C, b1) X6Q_SB X6Q_LDB(b1, 1, NBASE, NS) X6Q_SB                                                           \
-    X6Q_MM(A0C, B0C) X6Q_SB
+    X6Q_MM(A0C, B0C) X6Q_SB H1
+#define X6Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS) X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, X6Q_NOHOOK, X6Q_NOHOOK)
+#define X6Q_SLICE_H(A0C, B0C, A0N, B0N, NBASE, NS) X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, X6Q_HOOK3, X6Q_HOOK)
+    // one K step = two k-slices around the flat-tile barrier
+#define X6Q_KSTEP(SL)                                                                                                 \
+    {                                                                                                                 \
+        X6Q_SB                                                                                                        \
+        SL(a0x, b0x, a0y, b0y, lds[buf], 1)                                                                           \
+        /* every read of this tile has been issued; the next flat tile (of this item or the next one) is complete  */ \
+        /* behind the barrier -- none after the very last tile (its prefetch then re-reads this buffer, unused)    */ \
+        const bool more = kt + 1 < it.nk || w + stride < last;                                                        \
+        if (more) x6_lds_barrier();                                                                                   \
+        const unsigned char* nb = lds[more ? buf ^ 1 : buf];                                                          \
+        X6Q_SB                                                                                                        \
+        SL(a0y, b0y, a0x, b0x, nb, 0)                                                                                 \
+        buf ^= 1;                                                                                                     \
+    }
     int buf = 0;
     x6_lds_barrier();   // flat tile 0 is visible
     X6Q_LDA(a0x, 0, lds[0], 0) X6Q_LDA(a1, 1, lds[0], 0) X6Q_LDA(a2, 2, lds[0], 0)
@@ -1093,23 +1161,54 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         X6_STAMP(0, 11)
         for (int kt = 0; kt < it.nk; ++kt) {
-            X6Q_SB
-            X6Q_SLICE(a0x, b0x, a0y, b0y, lds[buf], 1)
-            X6_STAMP(0, 12)
-            // every read of this tile has been issued; the next flat tile (of this item or the next one) is complete
-            // behind the barrier -- none after the very last tile (its prefetch then re-reads this buffer, unused)
-            const bool more = kt + 1 < it.nk || w + stride < last;
-            if (more) x6_lds_barrier();
-            X6_STAMP(0, 13)
-            const unsigned char* nb = lds[more ? buf ^ 1 : buf];
-            X6Q_SB
-            X6Q_SLICE(a0y, b0y, a0x, b0x, nb, 0)
-            buf ^= 1;
+            if (DEFER && dq < dn)
+                X6Q_KSTEP(X6Q_SLICE_H)
+            else
+                X6Q_KSTEP(X6Q_SLICE)
         }
         X6_STAMP(0, 14)
         const bool add_bias = it.bias != nullptr && it.ks == 0;
-        if (staged) {
-            float* ct = cstrip[wave];
+        if (staged && DEFER) {
+            // whatever is still pending of the previous tile goes out now (short K loops), then the strip is refilled
+            while (dq < dn) X6Q_HOOK
+            dn = dq = 0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn + j * 32 + lcol;
+                    const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] = p.alpha * acc[i][j][r] + bv;
+                }
+            __builtin_amdgcn_wave_barrier();
+            const int r0 = it.m0 + wm, c0 = it.n0 + wn;
+            if (r0 + WM <= p.M && c0 + WN <= p.N) {   // interior sub-tile (wave-uniform): deferred, branch-free stores
+                dC = it.C + (int64_t)(r0 + lane / CPR) * p.ldc + c0 + (lane % CPR) * 4;
+                dstep = (int64_t)RPU * p.ldc;
+                dn = WM * CPR / 64;
+                dq = 0;
+                vq = *reinterpret_cast<const float4*>(&ct[sl]);
+            } else {
+#pragma unroll 1
+                for (int q = 0; q < WM * CPR / 64; ++q) {
+                    const int c = lane + 64 * q;
+                    const int row = c / CPR, col = (c % CPR) * 4;
+                    const int gr = r0 + row, gc = c0 + col;
+                    if (gr >= p.M || gc >= p.N) continue;
+                    const float* src = &ct[row * CP + col];
+                    float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                    dst[0] = src[0];
+                    if (gc + 1 < p.N) dst[1] = src[1];
+                    if (gc + 2 < p.N) dst[2] = src[2];
+                    if (gc + 3 < p.N) dst[3] = src[3];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (staged) {
+            constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;   // float4 chunks per strip row / per lane
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1121,7 +1220,6 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
                         ct[((r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] = p.alpha * acc[i][j][r] + bv;
                 }
                 __builtin_amdgcn_wave_barrier();
-                constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;
                 const int r0 = it.m0 + wm + i * 32, c0 = it.n0 + wn;
                 if (r0 + 32 <= p.M && c0 + WN <= p.N) {
                     float4 v[NQ];
@@ -1176,6 +1274,15 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
             }
         }
     }
+    if (DEFER) {   // the last tile's pending stores
+        while (dq < dn) X6Q_HOOK
+    }
+#undef X6Q_HOOK
+#undef X6Q_HOOK3
+#undef X6Q_NOHOOK
+#undef X6Q_SLICE_
+#undef X6Q_SLICE_H
+#undef X6Q_KSTEP
 #undef X6Q_LDA
 #undef X6Q_LDB
 #undef X6Q_MM
@@ -1183,28 +1290,29 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
 #undef X6Q_SLICE
 }
 
-template <int BN>
+template <int BN, bool DEFER>
 static void launch_x6q_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
     if (a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true>), grid, dim3(768), 0, stream, a, items);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true, DEFER>), grid, dim3(768), 0, stream, a, items);
     else if (a_kc && !b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, false>), grid, dim3(768), 0, stream, a, items);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, false, DEFER>), grid, dim3(768), 0, stream, a, items);
     else if (!a_kc && b_kc)
-        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, true>), grid, dim3(768), 0, stream, a, items);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, true, DEFER>), grid, dim3(768), 0, stream, a, items);
     else
-        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false>), grid, dim3(768), 0, stream, a, items);
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, DEFER>), grid, dim3(768), 0, stream, a, items);
 }
 
+template <bool DEFER>
 static void launch_x6q(const GemmArgs& a, int bn, int a_kc, int b_kc, int items, hipStream_t stream) {
     if (bn == 128)
-        launch_x6q_bn<128>(a, a_kc, b_kc, items, stream);
+        launch_x6q_bn<128, DEFER>(a, a_kc, b_kc, items, stream);
     else if (bn == 64)
-        launch_x6q_bn<64>(a, a_kc, b_kc, items, stream);
+        launch_x6q_bn<64, DEFER>(a, a_kc, b_kc, items, stream);
     else
-        launch_x6q_bn<32>(a, a_kc, b_kc, items, stream);
+        launch_x6q_bn<32, DEFER>(a, a_kc, b_kc, items, stream);
 }
 
 template <int BN>
@@ -1300,7 +1408,7 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
 // from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
 extern "C" int ix_gemm_set_mode(int mode) {
     const int old = g_x6;
-    g_x6 = mode < 0 ? 0 : (mode > 3 ? 3 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
+    g_x6 = mode < 0 ? 0 : (mode > 4 ? 4 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
     return old;
 }
 
@@ -1472,8 +1580,10 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     g_launches += 1;
     if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
     prof_mark(stream);
-    if (use_x6 && g_x6 == 3 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
-        launch_x6q(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    if (use_x6 && g_x6 == 4 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+        launch_x6q<true>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    else if (use_x6 && g_x6 == 3 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+        launch_x6q<false>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
     else if (use_x6 && g_x6 == 2 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
         launch_x6p(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
     else if (use_x6)

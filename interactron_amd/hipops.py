@@ -98,6 +98,13 @@ View = namedtuple("View", "offset ld trans so si")
 GemmSpec = namedtuple("GemmSpec", "M N K bo bi A B C out_shape alpha")
 
 
+def attn_pitch(S):
+    """Row pitch (floats) of the [L, S] attention tensors: rows start on 128-byte lines.  Measured with the C-tile store
+    pattern of the score product (tools/tile_fill_probe.py): rows that straddle cache lines (pitch 2060) drain at 3.4
+    TB/s chip-wide, aligned rows at 5.6 -- the K = 64 score product sits exactly on that limit."""
+    return (S + 31) // 32 * 32
+
+
 def _flip(v):
     return View(v.offset, v.ld, not v.trans, v.so, v.si)
 
@@ -198,10 +205,10 @@ def matmul_nn(a, b):
 
 
 def attention_scores(q, k, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, scale):
-    """scores[b,h,l,s] = scale * sum_d q[b,l,h*hd+d] * k[b,s,h*hd+d]  -> [nbatch, heads, L, Sp], Sp = S rounded up to 4.
+    """scores[b,h,l,s] = scale * sum_d q[b,l,h*hd+d] * k[b,s,h*hd+d]  -> [nbatch, heads, L, Sp], Sp = attn_pitch(S).
 
     q / k are [nbatch, L|S, ld] activations (possibly packed side by side: offsets q_off / k_off inside a row)."""
-    Sp = (S + 3) // 4 * 4
+    Sp = attn_pitch(S)
     sp = GemmSpec(L, S, hd, nbatch, heads, View(q_off, q_ld, False, L * q_ld, hd), View(k_off, k_ld, True, S * k_ld, hd),
                   View(0, Sp, False, heads * L * Sp, L * Sp), (nbatch, heads, L, Sp), scale)
     return Gemm.call(q, k, None, sp)
@@ -236,7 +243,7 @@ def _spec_dB(sp, b_shape):
 
 
 def _attn_specs(g):
-    Sp = (g.S + 3) // 4 * 4
+    Sp = attn_pitch(g.S)
     E = g.heads * g.hd
     tt = View(0, Sp, False, g.heads * g.L * Sp, g.L * Sp)
     scores = GemmSpec(g.L, g.S, g.hd, g.n, g.heads, View(g.q_off, g.q_ld, False, g.L * g.q_ld, g.hd),
@@ -359,7 +366,7 @@ def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, 
     """Scaled-dot-product attention out of packed projection buffers (see attention_scores / attention_apply for the
     layouts); `mask`: optional uint8 key-padding mask [nbatch, S]."""
     p = float(p) if training else 0.0
-    Sp = (S + 3) // 4 * 4
+    Sp = attn_pitch(S)
     if Sp > ATTN_FUSED_MAX_PITCH:   # rows too long for the register-resident fused kernel: node-by-node form
         att = attention_scores(q, k, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, scale)
         att = Softmax.call(att, S, mask, heads * L)

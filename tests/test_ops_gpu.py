@@ -94,7 +94,7 @@ def test_attention_gemms(ops, n, H, L, S, hd):
 
     check_op(hip_scores, ref_scores, [rnd(n, L, E), rnd(n, S, E)], name="scores")
 
-    Sp = (S + 3) // 4 * 4
+    Sp = ops.attn_pitch(S)
 
     def ref_apply(p, v):
         return torch.einsum("bhls,bshd->blhd", p[..., :S], v.view(n, S, H, hd)).reshape(n, L, E)
