@@ -1151,6 +1151,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
     X6Q_LDA(a0x, 0, lds[0], 0) X6Q_LDA(a1, 1, lds[0], 0) X6Q_LDA(a2, 2, lds[0], 0)
     X6Q_LDB(b0x, 0, lds[0], 0) X6Q_LDB(b1, 1, lds[0], 0) X6Q_LDB(b2, 2, lds[0], 0)
     for (; w < last; w += stride) {
+        X6_STAMP(0, 10)
         const X6Item it = x6_item<BN>(p, w);
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -1172,6 +1173,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
             // whatever is still pending of the previous tile goes out now (short K loops), then the strip is refilled
             while (dq < dn) X6Q_HOOK
             dn = dq = 0;
+            X6_STAMP(0, 15)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1184,6 +1186,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
                         ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] = p.alpha * acc[i][j][r] + bv;
                 }
             __builtin_amdgcn_wave_barrier();
+            X6_STAMP(0, 16)
             const int r0 = it.m0 + wm, c0 = it.n0 + wn;
             if (r0 + WM <= p.M && c0 + WN <= p.N) {   // interior sub-tile (wave-uniform): deferred, branch-free stores
                 dC = it.C + (int64_t)(r0 + lane / CPR) * p.ldc + c0 + (lane % CPR) * 4;
