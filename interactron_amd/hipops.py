@@ -116,8 +116,10 @@ def _numel(shape):
     return n
 
 
-def _run_gemm(a, b, bias, sp):
-    covered = sp.bo * sp.bi * sp.M * sp.N == _numel(sp.out_shape)
+def _run_gemm(a, b, bias, sp, fill=True):
+    """fill=False: the caller guarantees nobody reads the elements of `out` the product does not write (the pad columns
+    of attention tensors: every consumer stops at the row length) -- saves a memset of the whole tensor."""
+    covered = not fill or sp.bo * sp.bi * sp.M * sp.N == _numel(sp.out_shape)
     out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
     assert not sp.C.trans
     esz = 4
@@ -276,7 +278,7 @@ class AttentionCore(Function):
     def forward(ctx, q, k, v, g, mask, p, seed):
         q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
         sp_s, sp_a, Sp = _attn_specs(g)
-        y = _run_gemm(q, k, None, sp_s)
+        y = _run_gemm(q, k, None, sp_s, fill=False)
         d = torch.empty_like(y) if p > 0.0 else None
         _chk(_L().ix_attn_prob_fwd_f32(y.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None,
                                        g.n * g.heads * g.L, g.S, Sp, mask.data_ptr() if mask is not None else None,
@@ -301,7 +303,7 @@ class AttentionCoreBwd(Function):
         do = _req(do.contiguous(), "attention dO")
         sp_s, sp_a, Sp = _attn_specs(g)
         rows = g.n * g.heads * g.L
-        gd = _run_gemm(do, v, None, _spec_dA(sp_a, tuple(y.shape)))                 # dO v^T            [n,H,L,Sp]
+        gd = _run_gemm(do, v, None, _spec_dA(sp_a, tuple(y.shape)), fill=False)                 # dO v^T            [n,H,L,Sp]
         gs = torch.empty_like(y)
         _chk(_L().ix_attn_prob_bwd_f32(y.data_ptr(), gd.data_ptr(), gs.data_ptr(), rows, g.S, Sp, p, seed, _stream()),
              "ix_attn_prob_bwd_f32")
@@ -335,11 +337,11 @@ class AttentionCoreBwd(Function):
             E2 = 2 * g.heads * g.hd
             sp2 = GemmSpec(g.L, g.S, 2 * g.hd, g.n, g.heads, View(0, E2, False, g.L * E2, 2 * g.hd),
                            View(0, E2, True, g.S * E2, 2 * g.hd), sp_s.C, sp_s.out_shape, g.scale)
-            G1 = _run_gemm(a2, b2, None, sp2)
+            G1 = _run_gemm(a2, b2, None, sp2, fill=False)
             del a2, b2
         else:
-            G1 = _run_gemm(hq, k, None, sp_s) if hq is not None else (_run_gemm(q, hk, None, sp_s) if hk is not None else None)
-        HD = _run_gemm(do, hv, None, _spec_dA(sp_a, tuple(y.shape))) if hv is not None else None
+            G1 = _run_gemm(hq, k, None, sp_s, fill=False) if hq is not None else (_run_gemm(q, hk, None, sp_s, fill=False) if hk is not None else None)
+        HD = _run_gemm(do, hv, None, _spec_dA(sp_a, tuple(y.shape)), fill=False) if hv is not None else None
         HgD, HS = torch.empty_like(y), torch.empty_like(y)
         nul = lambda t: t.data_ptr() if t is not None else None
         _chk(_L().ix_attn_prob_bwd_bwd_f32(nul(G1), nul(G2), y.data_ptr(), gd.data_ptr(), nul(HD), HgD.data_ptr(),
