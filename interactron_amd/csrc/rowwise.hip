@@ -188,6 +188,9 @@ __device__ __forceinline__ float attn_keep(uint64_t seed, int64_t k, uint32_t th
     return attn_mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull)) >= thresh ? scale : 0.f;
 }
 
+__global__ void attn_prob_fwd_stream_kernel(const float*, float*, float*, int64_t, int, int64_t, const uint8_t*, int, int64_t, uint32_t, float, uint64_t);
+__global__ void attn_prob_bwd_stream_kernel(const float*, const float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t);
+__global__ void attn_prob_bwd_bwd_stream_kernel(const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t);
 template <int NREG>
 __global__ __launch_bounds__(256) void attn_prob_fwd_kernel(const float* x, float* y, float* __restrict__ d, int64_t rows,
                                                             int len, int64_t ld, const uint8_t* __restrict__ mask,
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_prob_fwd_kernel(const float* x, floa
 extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t rows, int len, int64_t ld, const uint8_t* mask,
                                     int rows_per_mask, int64_t mask_ld, float p, uint64_t seed, hipStream_t stream) {
     if (rows <= 0 || len <= 0) return IX_OK;
-    IX_CHECK_ARG(x && y && ld >= len && ld <= 2304, "ix_attn_prob_fwd_f32: bad args (row pitch up to 2304)");
+    IX_CHECK_ARG(x && y && ld >= len, "ix_attn_prob_fwd_f32: bad args");
     IX_CHECK_ARG(!mask || rows_per_mask > 0, "ix_attn_prob_fwd_f32: rows_per_mask must be > 0 with a mask");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_fwd_f32: p=%f outside [0,1)", p);
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
@@ -246,7 +249,8 @@ extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t 
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
-    else SM(36);
+    else if (ld <= 2304) SM(36);
+    else hipLaunchKernelGGL(attn_prob_fwd_stream_kernel, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_fwd_f32");
     return IX_OK;
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_prob_bwd_kernel(const float* __restr
 extern "C" int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, int64_t rows, int len, int64_t ld, float p,
                                     uint64_t seed, hipStream_t stream) {
     if (rows <= 0 || len <= 0) return IX_OK;
-    IX_CHECK_ARG(y && gd && gs && ld >= len && ld <= 2304, "ix_attn_prob_bwd_f32: bad args (row pitch up to 2304)");
+    IX_CHECK_ARG(y && gd && gs && ld >= len, "ix_attn_prob_bwd_f32: bad args");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_f32: p=%f outside [0,1)", p);
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const float scale = 1.f / (1.f - p);
@@ -300,7 +304,8 @@ extern "C" int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, 
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
-    else SM(36);
+    else if (ld <= 2304) SM(36);
+    else hipLaunchKernelGGL(attn_prob_bwd_stream_kernel, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_f32");
     return IX_OK;
@@ -368,7 +373,7 @@ extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const 
                                         float* HgD, float* HS, int64_t rows, int len, int64_t ld, float p, uint64_t seed,
                                         hipStream_t stream) {
     if (rows <= 0 || len <= 0) return IX_OK;
-    IX_CHECK_ARG(y && gd && HgD && HS && ld >= len && ld <= 2304, "ix_attn_prob_bwd_bwd_f32: bad args (row pitch up to 2304)");
+    IX_CHECK_ARG(y && gd && HgD && HS && ld >= len, "ix_attn_prob_bwd_bwd_f32: bad args");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_attn_prob_bwd_bwd_f32: p=%f outside [0,1)", p);
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const float scale = 1.f / (1.f - p);
@@ -378,10 +383,87 @@ extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const 
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
-    else SM(36);
+    else if (ld <= 2304) SM(36);
+    else hipLaunchKernelGGL(attn_prob_bwd_bwd_stream_kernel, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_bwd_f32");
     return IX_OK;
+}
+
+// Streaming forms of the three attention-probability kernels for rows longer than the register-resident variants
+// (800x800 frames: fusion T = 12 755, detector S = 2 500): operands are read twice (three times in the forward), the
+// second pass out of L2.
+__global__ __launch_bounds__(256) void attn_prob_fwd_stream_kernel(const float* x, float* y, float* __restrict__ d,
+                                                                   int64_t rows, int len, int64_t ld,
+                                                                   const uint8_t* __restrict__ mask, int rows_per_mask,
+                                                                   int64_t mask_ld, uint32_t thresh, float scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    const uint8_t* mr = mask ? mask + (row / rows_per_mask) * mask_ld : nullptr;
+    float mx = -INFINITY;
+    for (int c = lane; c < len; c += 64) mx = fmaxf(mx, (mr && mr[c]) ? -INFINITY : x[off + c]);
+    mx = ix_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) s += __expf(((mr && mr[c]) ? -INFINITY : x[off + c]) - mx);
+    s = ix_wave_sum(s);
+    const float inv = 1.f / s;
+    for (int c = lane; c < ld; c += 64) {   // (y may alias x: element c is read and written by the same lane)
+        const float val = c < len ? __expf(((mr && mr[c]) ? -INFINITY : x[off + c]) - mx) * inv : 0.f;
+        y[off + c] = val;
+        if (d) d[off + c] = val * attn_keep(seed, off + c, thresh, scale);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_prob_bwd_stream_kernel(const float* __restrict__ y, const float* __restrict__ gd,
+                                                                   float* __restrict__ gs, int64_t rows, int len, int64_t ld,
+                                                                   uint32_t thresh, float scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    float s = 0.f;
+    for (int c = lane; c < len; c += 64) s += y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale));
+    s = ix_wave_sum(s);
+    for (int c = lane; c < ld; c += 64)
+        gs[off + c] = c < len ? y[off + c] * (gd[off + c] * attn_keep(seed, off + c, thresh, scale) - s) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void attn_prob_bwd_bwd_stream_kernel(const float* __restrict__ G1, const float* __restrict__ G2,
+                                                                       const float* __restrict__ y, const float* __restrict__ gd,
+                                                                       const float* __restrict__ HD, float* __restrict__ HgD,
+                                                                       float* __restrict__ HS, int64_t rows, int len, int64_t ld,
+                                                                       uint32_t thresh, float scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t off = row * ld;
+    float s = 0.f, t = 0.f, a = 0.f;
+    for (int c = lane; c < len; c += 64) {
+        const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
+        const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
+        const float gy = gd[off + c] * m;
+        s += yy * gy;
+        t += yy * g;
+        a += yy * g * gy + (HD ? yy * (HD[off + c] * m) : 0.f);
+    }
+    s = ix_wave_sum(s);
+    t = ix_wave_sum(t);
+    const float u = ix_wave_sum(a) - 2.f * s * t;
+    for (int c = lane; c < ld; c += 64) {
+        float hgd = 0.f, hs = 0.f;
+        if (c < len) {
+            const float yy = y[off + c], m = attn_keep(seed, off + c, thresh, scale);
+            const float g = (G1 ? G1[off + c] : 0.f) + (G2 ? G2[off + c] : 0.f);
+            const float gy = gd[off + c] * m;
+            const float hy = g * (gy - s) - gy * t + (HD ? HD[off + c] * m : 0.f);
+            hgd = (yy * (g - t)) * m;
+            hs = yy * (hy - u);
+        }
+        HgD[off + c] = hgd;
+        HS[off + c] = hs;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

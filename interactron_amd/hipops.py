@@ -256,7 +256,6 @@ def _attn_specs(g):
 
 
 AttnGeom = namedtuple("AttnGeom", "n heads L S hd q_ld k_ld q_off k_off v_ld v_off scale")
-ATTN_FUSED_MAX_PITCH = 2304   # row pitch the register-resident fused softmax kernel covers
 
 
 def _sum2(a, b):
@@ -265,6 +264,18 @@ def _sum2(a, b):
     if b is None:
         return a
     return Axpby.call(a, b, 1.0, 1.0)
+
+
+ATTN_LEAN_BYTES = 4 << 30   # [L, S] tensors at least this large: AttentionCore keeps two of them per layer instead of four
+
+
+def _dropout_of(y, p, seed):
+    """d = dropout(y) with the mask of (seed, flat index) -- what ix_attn_prob_fwd_f32 wrote as its second output."""
+    if p <= 0.0:
+        return y
+    d = torch.empty_like(y)
+    _chk(_L().ix_dropout_f32(y.data_ptr(), d.data_ptr(), y.numel(), p, seed, _stream()), "ix_dropout_f32")
+    return d
 
 
 class AttentionCore(Function):
@@ -286,23 +297,36 @@ class AttentionCore(Function):
              "ix_attn_prob_fwd_f32")
         if d is None:
             d = y
+        out = _run_gemm(d, v, None, sp_a)
+        # lean mode (800x800 frames: one [L, S] tensor is 5 GB per episode): keep y only, regenerate d = dropout(y)
+        # and gs = softmax_bwd(y, dropout_bwd(gd)) where they are needed -- two saved [L, S] tensors per layer, not four
+        ctx.lean = ATTN_LEAN_BYTES is not None and y.numel() * 4 >= ATTN_LEAN_BYTES
         ctx.g, ctx.p, ctx.seed = g, p, seed
-        ctx.save_for_backward(q, k, v, y, d)
-        return _run_gemm(d, v, None, sp_a)
+        if ctx.lean and d is not y:
+            ctx.save_for_backward(q, k, v, y)
+        else:
+            ctx.save_for_backward(q, k, v, y, d)
+        return out
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, y, d = ctx.saved_tensors
-        gq, gk, gv = AttentionCoreBwd.call(q, k, v, y, d, do, ctx.g, ctx.p, ctx.seed)
+        if len(ctx.saved_tensors) == 4:
+            q, k, v, y = ctx.saved_tensors
+            d = None
+        else:
+            q, k, v, y, d = ctx.saved_tensors
+        gq, gk, gv = AttentionCoreBwd.call(q, k, v, y, d, do, ctx.g, ctx.p, ctx.seed, ctx.lean)
         return gq, gk, gv, None, None, None, None
 
 
 class AttentionCoreBwd(Function):
     @staticmethod
-    def forward(ctx, q, k, v, y, d, do, g, p, seed):
+    def forward(ctx, q, k, v, y, d, do, g, p, seed, lean=False):
         do = _req(do.contiguous(), "attention dO")
         sp_s, sp_a, Sp = _attn_specs(g)
         rows = g.n * g.heads * g.L
+        if d is None:
+            d = _dropout_of(y, p, seed)
         gd = _run_gemm(do, v, None, _spec_dA(sp_a, tuple(y.shape)), fill=False)                 # dO v^T            [n,H,L,Sp]
         gs = torch.empty_like(y)
         _chk(_L().ix_attn_prob_bwd_f32(y.data_ptr(), gd.data_ptr(), gs.data_ptr(), rows, g.S, Sp, p, seed, _stream()),
@@ -312,17 +336,24 @@ class AttentionCoreBwd(Function):
         gk = _run_gemm(gs, q, None, s_k) if dc_first else _run_gemm(q, gs, None, s_k)   # scale gs^T q
         s_v, dc_first_v = _spec_dB(sp_a, tuple(v.shape))
         gv = _run_gemm(do, d, None, s_v) if dc_first_v else _run_gemm(d, do, None, s_v)  # d^T dO
-        ctx.g, ctx.p, ctx.seed = g, p, seed
-        ctx.save_for_backward(q, k, v, y, d, do, gd, gs)
+        ctx.g, ctx.p, ctx.seed, ctx.lean = g, p, seed, lean
+        if lean:
+            ctx.save_for_backward(q, k, v, y, do, gd)
+        else:
+            ctx.save_for_backward(q, k, v, y, do, gd, d, gs)
         return gq, gk, gv
 
     @staticmethod
     @once_differentiable
     def backward(ctx, hq, hk, hv):
-        q, k, v, y, d, do, gd, gs = ctx.saved_tensors
         g, p, seed = ctx.g, ctx.p, ctx.seed
         sp_s, sp_a, Sp = _attn_specs(g)
         rows = g.n * g.heads * g.L
+        if ctx.lean:
+            q, k, v, y, do, gd = ctx.saved_tensors
+            d = gs = None
+        else:
+            q, k, v, y, do, gd, d, gs = ctx.saved_tensors
         hq = _req(hq.contiguous()) if hq is not None else None
         hk = _req(hk.contiguous()) if hk is not None else None
         hv = _req(hv.contiguous()) if hv is not None else None
@@ -353,26 +384,28 @@ class AttentionCoreBwd(Function):
         rk = lambda dc, a: _run_gemm(dc, a, None, s_k) if kf else _run_gemm(a, dc, None, s_k)
         need = ctx.needs_input_grad
         grad_q = grad_k = grad_v = grad_do = None
+        if gs is None and (need[0] or need[1]):
+            gs = torch.empty_like(y)
+            _chk(_L().ix_attn_prob_bwd_f32(y.data_ptr(), gd.data_ptr(), gs.data_ptr(), rows, g.S, Sp, p, seed, _stream()),
+                 "ix_attn_prob_bwd_f32")
         if need[0]:   # scale (gs hk + HS k)
             grad_q = _sum2(_run_gemm(gs, hk, None, s_q) if hk is not None else None, _run_gemm(HS, k, None, s_q))
         if need[1]:   # scale (gs^T hq + HS^T q)
             grad_k = _sum2(rk(gs, hq) if hq is not None else None, rk(HS, q))
         if need[2]:   # HgD^T dO
             grad_v = _run_gemm(do, HgD, None, s_v) if vf else _run_gemm(HgD, do, None, s_v)
+        del gs, HS
         if need[5]:   # d hv + HgD v
+            if d is None and hv is not None:
+                d = _dropout_of(y, p, seed)
             grad_do = _sum2(_run_gemm(d, hv, None, sp_a) if hv is not None else None, _run_gemm(HgD, v, None, sp_a))
-        return grad_q, grad_k, grad_v, None, None, grad_do, None, None, None
+        return grad_q, grad_k, grad_v, None, None, grad_do, None, None, None, None
 
 
 def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, scale, mask, p, training):
     """Scaled-dot-product attention out of packed projection buffers (see attention_scores / attention_apply for the
     layouts); `mask`: optional uint8 key-padding mask [nbatch, S]."""
     p = float(p) if training else 0.0
-    Sp = attn_pitch(S)
-    if Sp > ATTN_FUSED_MAX_PITCH:   # rows too long for the register-resident fused kernel: node-by-node form
-        att = attention_scores(q, k, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, scale)
-        att = Softmax.call(att, S, mask, heads * L)
-        return attention_apply(dropout(att, p, training), v, nbatch, heads, L, S, hd, v_ld, v_off)
     g = AttnGeom(nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, float(scale))
     return AttentionCore.call(q, k, v, g, mask, p, _next_seed() if p > 0.0 else 0)
 
