@@ -245,6 +245,43 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
     unsafeAtomicAdd(&out[c], s);
 }
 
+// 16-byte form (C % 4 == 0, aligned rows): a thread owns 4 adjacent columns, the block's 4 waves take rows r, r+1, r+2,
+// r+3 of the band with two independent accumulator sets (8 row loads in flight per thread), LDS-reduced to one atomic
+// per column per block.
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                         int C, int rows_per_block) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    x += (int64_t)blockIdx.z * rows * C;
+    out += (int64_t)blockIdx.z * C;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (c < C) {
+        int64_t r = r0 + wave;
+        for (; r + 4 < r1; r += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+            const float4 b = *reinterpret_cast<const float4*>(x + (r + 4) * C + c);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (r < r1) {
+            const float4 a = *reinterpret_cast<const float4*>(x + r * C + c);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    red[wave][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (wave == 0 && c < C) {
+        const float4 a = red[0][lane], b = red[1][lane], d = red[2][lane], e = red[3][lane];
+        unsafeAtomicAdd(&out[c + 0], (a.x + b.x) + (d.x + e.x));
+        unsafeAtomicAdd(&out[c + 1], (a.y + b.y) + (d.y + e.y));
+        unsafeAtomicAdd(&out[c + 2], (a.z + b.z) + (d.z + e.z));
+        unsafeAtomicAdd(&out[c + 3], (a.w + b.w) + (d.w + e.w));
+    }
+}
+
 // out[g, c] = sum_r x[g, r, c]
 extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, hipStream_t stream) {
     IX_CHECK_ARG(out && C >= 0 && groups >= 0 && groups <= 65535, "ix_colsum_f32: bad args");
@@ -255,7 +292,10 @@ extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, in
     int rpb = 64;
     while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
     dim3 grid(ix_div_up(C, 256), (unsigned)((rows + rpb - 1) / rpb), groups);
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
+    if ((C & 3) == 0 && al16(x))
+        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
     IX_CHECK_LAUNCH("ix_colsum_f32");
     return IX_OK;
 }
