@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
     ap.add_argument("--config", default="interactron", choices=sorted(CONFIGS),
                     help="which reference config's training step to run (default: the headline meta-train step)")
-    ap.add_argument("--mode", default="train", choices=["train", "predict", "interactive"],
+    ap.add_argument("--mode", default="train", choices=["train", "predict", "interactive", "predict-batched"],
                     help="train (default, the headline): meta-train step; predict: model.predict per episode (eval adapt, "
                          "reference interactron.py:31-59); interactive: predict + 4 x get_next_action per episode (SURVEY 8d iii)")
     ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
@@ -197,12 +197,14 @@ def main():
             last["losses"] = losses
             outer.step()
             return
-        for i in range(args.episodes):
+        for i in range(args.episodes if args.mode != "predict-batched" else 0):
             if args.mode == "interactive":   # the policy looks at 1..4 frames, then the adapted prediction on all 5
                 for s in range(1, 5):
                     model.get_next_action(episode(i, s))
             out = model.predict(episode(i))
             last["losses"] = {"pred_logits": out["pred_logits"]}
+        if args.mode == "predict-batched":
+            last["losses"] = {"pred_logits": model.predict(data)["pred_logits"]}
 
     def fence():
         if world > 1:
@@ -277,6 +279,7 @@ def main():
                                        args.queries, cfg["BLOCK_SIZE"])) if args.mode == "train" else
                                    ("%s %s, one episode at a time (%d episodes/GPU x 5 frames x 3x%dx%d), eval mode"
                                     % (CONFIGS[args.config][0], {"predict": "predict() (adapt + frame-0 prediction)",
+                                                                 "predict-batched": "predict() on all episodes of the batch at once",
                                                                  "interactive": "interactive episode (4 x get_next_action + predict)"}
                                        [args.mode], args.episodes, args.size, args.size)),
                        "mode": args.mode,

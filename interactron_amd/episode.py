@@ -138,6 +138,8 @@ class _Adaptive(_EpisodeModel):
 
     def predict(self, data):
         b, s, c, w, h = data["frames"].shape
+        if b > 1:
+            return self._predict_batched(data)
         img, mask = data["frames"].view(s, c, w, h), data["masks"].view(s, w, h)
         self._theta = get_parameters(self.detector)
         try:
@@ -150,6 +152,40 @@ class _Adaptive(_EpisodeModel):
         finally:
             set_parameters(self.detector, self._theta)
         return {k: v.unsqueeze(0) for k, v in post.items()}
+
+    def _predict_batched(self, data):
+        """predict() for b > 1 episodes at once (the reference's own predict only works for b = 1, its evaluators call
+        it episode by episode): the episodes are adapted together with per-episode fast weights, exactly as in
+        ``forward``; returns the same keys with shape [b, 1, ...]."""
+        b, s, c, w, h = data["frames"].shape
+        chunk = max(1, int(getattr(self.config, "EPISODE_CHUNK", 16)))
+        self._theta = theta = get_parameters(self.detector)
+        outs = []
+        try:
+            for e0 in range(0, b, chunk):
+                E = min(chunk, b - e0)
+                frames = data["frames"][e0:e0 + E].reshape(E * s, c, w, h)
+                masks = data["masks"][e0:e0 + E].reshape(E * s, w, h)
+                with torch.enable_grad():
+                    dtheta = [ops.BcastRows.apply(p.detach().reshape(-1), E).reshape((E,) + tuple(p.shape)).requires_grad_(True)
+                              for p in theta]
+                    set_parameters(self.detector, dtheta)
+                    nt = NestedTensor(frames, masks)
+                    nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
+                    pre = self.detector(nt)
+                    pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
+                    loss_map = self.fusion(pre)["loss"].reshape(E, -1)
+                    learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
+                    grads = torch.autograd.grad(learned, dtheta, allow_unused=True)
+                    set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                with torch.no_grad():
+                    first = NestedTensor(frames[0::s], masks[0::s])
+                    first.stem = nt.stem[0::s]
+                    outs.append(self.detector(first))
+                del dtheta, grads, pre, loss_map, learned
+        finally:
+            set_parameters(self.detector, theta)
+        return {k: torch.cat([o[k] for o in outs], 0).unsqueeze(1) for k in outs[0]}
 
     # Episodes of a batch are independent given theta (reference interactron.py:84 loops over them one by one).  On
     # MI355X a single 5-frame episode leaves most of the 256 CUs idle (M = 250 decoder rows, 1805 encoder rows), so the

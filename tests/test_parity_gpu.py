@@ -188,6 +188,21 @@ def test_episode_batched_equals_sequential_schedule():
         assert float((g0[k] - g1[k]).double().norm()) <= 1e-1 * n0 + 1e-7, (k, n0, n1)
 
 
+def test_batched_predict_equals_per_episode_predict():
+    """predict() on b > 1 episodes (per-episode fast weights, one batched pass) == the reference-shaped b = 1 calls."""
+    from interactron_amd import Config, build_model
+    data = to_gpu(synthetic_episodes(3, height=128, width=160, tag="predict-batch"))
+    m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", EPISODE_CHUNK=2)))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().eval()
+    together = m.predict(data)
+    for i in range(3):
+        one = m.predict({"frames": data["frames"][i:i + 1], "masks": data["masks"][i:i + 1]})
+        for k in ("pred_logits", "pred_boxes"):
+            assert together[k].shape[1:] == one[k].shape[1:]
+            torch.testing.assert_close(together[k][i:i + 1], one[k], atol=1e-3 * float(one[k].abs().max()) + 1e-4, rtol=1e-3)
+
+
 def test_config1_detr(golden, episode1):
     O = golden("golden_configs.pt")
     m = make("detr")
