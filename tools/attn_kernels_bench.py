@@ -15,7 +15,7 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 for (b, L, S) in [(128, 2060, 2060), (640, 361, 361), (640, 50, 361)]:
-    Sp = (S + 3) // 4 * 4
+    Sp = (S + 31) // 32 * 32 if os.environ.get("ALIGN", "1") == "1" else (S + 3) // 4 * 4
     rows = b * L
     t = [torch.randn(rows, Sp, device="cuda") for _ in range(7)]
     gb = rows * Sp * 4 / 1e9
