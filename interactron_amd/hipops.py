@@ -670,7 +670,7 @@ def manual_seed(seed):
 
 def _next_seed():
     _seed_state["counter"] += 1
-    return ((_seed_state["base"] << 32) ^ (_seed_state["counter"] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    return ((_seed_state["base"] << 32) ^ (_seed_state["counter"] * 0x9E3779B97F4A7C15)) & 0x7FFFFFFFFFFFFFFF   # (63 bits: torch.profiler cannot record larger Python ints)
 
 
 class _Dropout(Function):
