@@ -76,6 +76,10 @@ int ix_scale_f32(const float* x, float* out, int64_t n, float alpha, ix_stream_t
 int ix_scale_dev_f32(const float* x, const float* s, float* out, int64_t n, ix_stream_t stream);
 int ix_relu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
 int ix_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix_stream_t stream);
+/* dropout(relu(x)) in one pass (FFN of models/detr_models/transformer.py:158,229) and its backward
+   dx = dy * [y > 0] * scale, scale = 1 / (1 - p) */
+int ix_relu_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
+int ix_relu_bwd_scaled_f32(const float* dy, const float* y, float* dx, int64_t n, float scale, ix_stream_t stream);
 int ix_gelu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
 int ix_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, ix_stream_t stream);
 int ix_gelu_bwd_bwd_f32(const float* G, const float* dy, const float* x, float* grad_dy, float* grad_x, int64_t n,

@@ -159,7 +159,7 @@ class TransformerEncoderLayer(nn.Module):
         qk = ops.add(src, pos)
         a = self.self_attn(qk, qk, src, key_padding_mask, qk_same=True)
         src = self.norm1(ops.add(src, self.dropout1(a)))
-        f = self.linear2(self.dropout(ops.Relu.apply(self.linear1(src))))
+        f = self.linear2(ops.relu_dropout(self.linear1(src), self.dropout.p, self.dropout.training))
         return self.norm2(ops.add(src, self.dropout2(f)))
 
 
@@ -189,7 +189,7 @@ class TransformerDecoderLayer(nn.Module):
         q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
         c = self.multihead_attn(q, memory_key, memory, memory_key_padding_mask)
         tgt = self.norm2(ops.add(tgt, self.dropout2(c)))
-        f = self.linear2(self.dropout(ops.Relu.apply(self.linear1(tgt))))
+        f = self.linear2(ops.relu_dropout(self.linear1(tgt), self.dropout.p, self.dropout.training))
         return self.norm3(ops.add(tgt, self.dropout3(f)))
 
 

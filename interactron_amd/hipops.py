@@ -588,6 +588,50 @@ class ReluBwd(Function):
         return ReluBwd.call(G, y), None
 
 
+class ReluBwdScaled(Function):
+    """dy * [y > 0] * scale; linear in dy."""
+
+    @staticmethod
+    def forward(ctx, dy, y, scale):
+        dy, y = _req(dy), _req(y)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        out = torch.empty_like(dy)
+        _chk(_L().ix_relu_bwd_scaled_f32(dy.data_ptr(), y.data_ptr(), out.data_ptr(), dy.numel(), scale, _stream()),
+             "ix_relu_bwd_scaled_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        (y,) = ctx.saved_tensors
+        return ReluBwdScaled.call(G, y, ctx.scale), None, None
+
+
+class ReluDropout(Function):
+    """dropout(relu(x)) as one pass; y > 0 exactly where the relu and the mask both pass, so the backward is one pass
+    over (dy, y) with neither the mask hash nor x."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _req(x)
+        out = torch.empty_like(x)
+        _chk(_L().ix_relu_dropout_f32(x.data_ptr(), out.data_ptr(), x.numel(), p, seed, _stream()), "ix_relu_dropout_f32")
+        ctx.save_for_backward(out)
+        ctx.scale = 1.0 / (1.0 - p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ReluBwdScaled.call(g, y, ctx.scale), None, None
+
+
+def relu_dropout(x, p, training):
+    if not training or p <= 0.0:
+        return Relu.call(x)
+    return ReluDropout.call(x, float(p), _next_seed())
+
+
 class Gelu(Function):
     @staticmethod
     def forward(ctx, x):

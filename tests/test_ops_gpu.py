@@ -243,6 +243,21 @@ def test_elementwise(ops):
     check_op(lambda a: ops.ColSum.apply(a), lambda a: a.sum(0), [x], name="colsum")
 
 
+def test_relu_dropout_matches_relu_then_dropout(ops):
+    x = rnd(333, 257).cuda().requires_grad_(True)
+    g = rnd(333, 257, seed=2).cuda().requires_grad_(True)
+    res = []
+    for fused in (True, False):
+        ops.manual_seed(77)
+        y = ops.relu_dropout(x, 0.3, True) if fused else ops.dropout(ops.Relu.apply(x), 0.3, True)
+        (gx,) = torch.autograd.grad(y, x, g, create_graph=True)
+        (gg,) = torch.autograd.grad((gx * rnd(333, 257, seed=3).cuda()).sum(), g)
+        res.append((y, gx, gg))
+    for a, b in zip(res[0], res[1]):
+        close(a, b, 1e-6, "relu_dropout")
+    assert 0.25 < float((res[0][0] == 0).float().mean()) < 0.75
+
+
 def test_dropout_is_scaled_mask_and_self_adjoint(ops):
     x = torch.ones(400000).cuda().requires_grad_(True)
     y = ops._Dropout.apply(x, 0.1, 1234567)
