@@ -79,6 +79,8 @@ int ix_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix_st
 /* dropout(relu(x)) in one pass (FFN of models/detr_models/transformer.py:158,229) and its backward
    dx = dy * [y > 0] * scale, scale = 1 / (1 - p) */
 int ix_relu_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
+/* out = x + dropout(a): residual adds of the transformer blocks (transformer.py:157-160,222-231; gpt.py:75-77) */
+int ix_add_dropout_f32(const float* x, const float* a, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
 int ix_relu_bwd_scaled_f32(const float* dy, const float* y, float* dx, int64_t n, float scale, ix_stream_t stream);
 int ix_gelu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
 int ix_gelu_bwd_f32(const float* dy, const float* x, float* dx, int64_t n, ix_stream_t stream);

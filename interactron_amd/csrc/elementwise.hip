@@ -214,6 +214,27 @@ extern "C" int ix_relu_dropout_f32(const float* x, float* out, int64_t n, float 
     return IX_OK;
 }
 
+// x + dropout(a): the residual adds of the transformer blocks (transformer.py:157-160,222-231, gpt.py:75-77) in one pass
+__global__ void add_dropout_kernel(const float* __restrict__ x, const float* __restrict__ a, float* __restrict__ o, int64_t n,
+                                   uint32_t thresh, float scale, uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
+        const uint32_t r = mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull));
+        o[k] = x[k] + (r >= thresh ? a[k] * scale : 0.f);
+    }
+}
+
+extern "C" int ix_add_dropout_f32(const float* x, const float* a, float* out, int64_t n, float p, uint64_t seed,
+                                  hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && a && out, "ix_add_dropout_f32: null pointer");
+    IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_add_dropout_f32: p=%f outside [0,1)", p);
+    hipLaunchKernelGGL(add_dropout_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, a, out, n,
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+    IX_CHECK_LAUNCH("ix_add_dropout_f32");
+    return IX_OK;
+}
+
 extern "C" int ix_relu_bwd_scaled_f32(const float* dy, const float* y, float* dx, int64_t n, float scale, hipStream_t stream) {
     LAUNCH2("ix_relu_bwd_scaled_f32", dy, y, dx, n, stream, [scale] __device__(float g, float v) { return v > 0.f ? g * scale : 0.f; });
 }

@@ -158,9 +158,9 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, key_padding_mask, pos):
         qk = ops.add(src, pos)
         a = self.self_attn(qk, qk, src, key_padding_mask, qk_same=True)
-        src = self.norm1(ops.add(src, self.dropout1(a)))
+        src = self.norm1(ops.add_dropout(src, a, self.dropout1.p, self.dropout1.training))
         f = self.linear2(ops.relu_dropout(self.linear1(src), self.dropout.p, self.dropout.training))
-        return self.norm2(ops.add(src, self.dropout2(f)))
+        return self.norm2(ops.add_dropout(src, f, self.dropout2.p, self.dropout2.training))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -185,12 +185,12 @@ class TransformerDecoderLayer(nn.Module):
         groups = query_pos.shape[0] if query_pos.dim() == 2 else 1
         qk = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
         a = self.self_attn(qk, qk, tgt, None, qk_same=True)
-        tgt = self.norm1(ops.add(tgt, self.dropout1(a)))
+        tgt = self.norm1(ops.add_dropout(tgt, a, self.dropout1.p, self.dropout1.training))
         q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
         c = self.multihead_attn(q, memory_key, memory, memory_key_padding_mask)
-        tgt = self.norm2(ops.add(tgt, self.dropout2(c)))
+        tgt = self.norm2(ops.add_dropout(tgt, c, self.dropout2.p, self.dropout2.training))
         f = self.linear2(ops.relu_dropout(self.linear1(tgt), self.dropout.p, self.dropout.training))
-        return self.norm3(ops.add(tgt, self.dropout3(f)))
+        return self.norm3(ops.add_dropout(tgt, f, self.dropout3.p, self.dropout3.training))
 
 
 class TransformerEncoder(nn.Module):

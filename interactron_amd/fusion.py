@@ -43,7 +43,7 @@ class SelfAttention(nn.Module):
         k, q, v = self.key(x), self.query(x), self.value(x)
         y = ops.attention(q, k, v, B, H, T, T, hd, C, C, 0, 0, C, 0, 1.0 / math.sqrt(hd), None, self.attn_drop.p,
                           self.attn_drop.training)
-        return self.resid_drop(self.proj(y))
+        return self.proj(y)   # (resid_drop is applied fused with the residual add in Block.forward)
 
 
 class _Gelu(nn.Module):
@@ -61,8 +61,10 @@ class Block(nn.Module):
         self.mlp = nn.Sequential(Linear(d, 4 * d), _Gelu(), Linear(4 * d, d), Dropout(cfg.RESIDUAL_PDROP))
 
     def forward(self, x):
-        x = ops.add(x, self.attn(self.ln1(x)))
-        return ops.add(x, self.mlp(self.ln2(x)))
+        # x + dropout(branch) as one pass each (reference gpt.py:75-77; the dropouts are attn.resid_drop and mlp[3])
+        x = ops.add_dropout(x, self.attn(self.ln1(x)), self.attn.resid_drop.p, self.attn.resid_drop.training)
+        m = self.mlp[2](self.mlp[1](self.mlp[0](self.ln2(x))))
+        return ops.add_dropout(x, m, self.mlp[3].p, self.mlp[3].training)
 
 
 class GPT(nn.Module):

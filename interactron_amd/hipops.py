@@ -626,6 +626,31 @@ class ReluDropout(Function):
         return ReluBwdScaled.call(g, y, ctx.scale), None, None
 
 
+class AddDropout(Function):
+    """x + dropout(a) as one pass (residual connections)."""
+
+    @staticmethod
+    def forward(ctx, x, a, p, seed):
+        x, a = _req(x), _req(a)
+        assert x.shape == a.shape, (x.shape, a.shape)
+        ctx.p, ctx.seed = p, seed
+        out = torch.empty_like(x)
+        _chk(_L().ix_add_dropout_f32(x.data_ptr(), a.data_ptr(), out.data_ptr(), x.numel(), p, seed, _stream()),
+             "ix_add_dropout_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.needs_input_grad[0] else None), \
+            (_Dropout.call(g, ctx.p, ctx.seed) if ctx.needs_input_grad[1] else None), None, None
+
+
+def add_dropout(x, a, p, training):
+    if not training or p <= 0.0:
+        return add(x, a)
+    return AddDropout.call(x, a, float(p), _next_seed())
+
+
 def relu_dropout(x, p, training):
     if not training or p <= 0.0:
         return Relu.call(x)
