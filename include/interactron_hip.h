@@ -74,6 +74,9 @@ int ix_axpby_f32(const float* a, const float* b, float* out, int64_t n, float al
 int ix_mul_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
 int ix_scale_f32(const float* x, float* out, int64_t n, float alpha, ix_stream_t stream);
 int ix_scale_dev_f32(const float* x, const float* s, float* out, int64_t n, ix_stream_t stream);
+/* backward of relu(FrozenBN(x)) w.r.t. x in one pass: out = [y > 0] * g * scale[c] (models/detr_models/backbone.py:44-54) */
+int ix_relu_bwd_channel_scale_f32(const float* g, const float* y, const float* scale, float* out, int64_t n, int C,
+                                  ix_stream_t stream);
 int ix_relu_f32(const float* x, float* out, int64_t n, ix_stream_t stream);
 int ix_relu_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix_stream_t stream);
 /* dropout(relu(x)) in one pass (FFN of models/detr_models/transformer.py:158,229) and its backward

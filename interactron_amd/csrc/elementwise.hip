@@ -418,6 +418,31 @@ __global__ void channel_affine_kernel(const float* __restrict__ x, const float* 
     }
 }
 
+// out = [y > 0] * g * scale[c]: backward of relu(x*scale + shift) w.r.t. x in one pass (NHWC, C % 4 == 0)
+__global__ void relu_bwd_channel_scale_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                              const float* __restrict__ scale, float* __restrict__ o, int64_t n4, int C4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n4; k += stride) {
+        const float4 v = reinterpret_cast<const float4*>(g)[k], yy = reinterpret_cast<const float4*>(y)[k];
+        const float4 s = reinterpret_cast<const float4*>(scale)[(int)(k % C4)];
+        reinterpret_cast<float4*>(o)[k] = make_float4(yy.x > 0.f ? v.x * s.x : 0.f, yy.y > 0.f ? v.y * s.y : 0.f,
+                                                      yy.z > 0.f ? v.z * s.z : 0.f, yy.w > 0.f ? v.w * s.w : 0.f);
+    }
+}
+
+extern "C" int ix_relu_bwd_channel_scale_f32(const float* g, const float* y, const float* scale, float* out, int64_t n, int C,
+                                             hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(g && y && scale && out, "ix_relu_bwd_channel_scale_f32: null pointer");
+    IX_CHECK_ARG(C % 4 == 0 && n % C == 0, "ix_relu_bwd_channel_scale_f32: need C %% 4 == 0 and n %% C == 0 (C=%d)", C);
+    IX_CHECK_ARG(al16(g) && al16(y) && al16(out) && al16(scale), "ix_relu_bwd_channel_scale_f32: pointers must be 16-byte aligned");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(relu_bwd_channel_scale_kernel, dim3(ix_grid_1d(n4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, g, y, scale,
+                       out, n4, C / 4);
+    IX_CHECK_LAUNCH("ix_relu_bwd_channel_scale_f32");
+    return IX_OK;
+}
+
 // out = [relu]( x*scale[c] (+ shift[c]) (+ residual) ), x NHWC with C % 4 == 0.  shift / residual may be null.
 extern "C" int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual,
                                      float* out, int64_t n, int C, int relu, hipStream_t stream) {

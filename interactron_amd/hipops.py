@@ -798,6 +798,24 @@ class ChannelScale(Function):
         return ChannelScale.call(g, scale), None
 
 
+class ReluBwdChannelScale(Function):
+    """[y > 0] * g * scale[c]: linear in g, so it is its own second-order form."""
+
+    @staticmethod
+    def forward(ctx, g, y, scale):
+        g, y = _req(g), _req(y)
+        ctx.save_for_backward(y, scale)
+        out = torch.empty_like(g)
+        _chk(_L().ix_relu_bwd_channel_scale_f32(g.data_ptr(), y.data_ptr(), scale.data_ptr(), out.data_ptr(), g.numel(),
+                                                g.shape[-1], _stream()), "ix_relu_bwd_channel_scale_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        y, scale = ctx.saved_tensors
+        return ReluBwdChannelScale.call(G, y, scale), None, None
+
+
 class BnAct(Function):
     """y = [relu](x*scale[c] + shift[c] (+ residual)) on NHWC activations (FrozenBatchNorm2d folded)."""
 
@@ -815,6 +833,8 @@ class BnAct(Function):
     @staticmethod
     def backward(ctx, g):
         scale, y = ctx.saved_tensors
+        if ctx.relu and not ctx.has_res:   # one pass instead of relu-backward + channel scale
+            return (ReluBwdChannelScale.call(g, y, scale) if ctx.needs_input_grad[0] else None), None, None, None, None
         if ctx.relu:
             g = ReluBwd.call(g, y)
         gx = ChannelScale.call(g, scale) if ctx.needs_input_grad[0] else None
