@@ -74,3 +74,11 @@ def test_train_then_evaluate_drop_in(tmp_path):
     assert set(summary) == {"AP_50", "AP_75", "AP", "AP_small", "AP_medium", "AP_large"}
     res = json.load(open(ev.out_dir + "results.json"))
     assert {d["type"] for d in res["detections"]} <= {"tp", "fp", "fn"} and len(res["detections"]) >= 3
+    # non-interactive evaluation with several episodes per predict() call: every ground-truth box is still scored once
+    cfg.EVALUATOR.TYPE = "random_policy_evaluator"
+    counts = []
+    for bs in (1, 3):
+        cfg.EVALUATOR.BATCH_SIZE = bs
+        _, _, tp, fp, fn = build_evaluator(build_model(cfg.MODEL), cfg, load_checkpoint=True).evaluate()
+        counts.append(tp + fn)
+    assert counts[0] == counts[1] and counts[0] > 0
