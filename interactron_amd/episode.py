@@ -116,6 +116,7 @@ class _Adaptive(_EpisodeModel):
     """Shared body of interactron / interactron_random: learned-loss inner step + meta-gradient."""
 
     phase_times = None
+    _graphs = {}   # (replaced by a per-instance dict on first use; None = graph capture disabled after a failure)
 
     use_policy = False
 
@@ -373,11 +374,52 @@ class interactron(_Adaptive):
         self.path_storage = {}
         self.config = config
 
+    def _policy_logits(self, frames, masks):
+        with torch.no_grad():
+            pre = _lift(self.detector(NestedTensor(frames, masks)))
+            return self.fusion(pre)["actions"]
+
+    # The policy step is pure inference on fixed shapes (1..4 frames), ~1 500 launches of a few microseconds each: at one
+    # episode it is bound by the host issuing them.  In eval mode the launch sequence of each frame count is captured
+    # once into a HIP graph (static input buffers, weights by address) and replayed; any capture failure, training
+    # mode or a weight re-allocation falls back to eager launches.  POLICY_GRAPH: false in the config turns it off.
+    def _policy_graph(self, frames, masks):
+        key = (tuple(frames.shape), frames.device.index)
+        stamp = next(self.detector.parameters()).data_ptr()
+        if "_graphs" not in self.__dict__:
+            self._graphs = {}
+        ent = self._graphs.get(key)
+        if ent is None or ent[0] != stamp:
+            sf, sm = frames.clone(), masks.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):   # warm-up outside the capture (lazy initialisation, allocator pools)
+                self._policy_logits(sf, sm)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._policy_logits(sf, sm)
+            ent = self._graphs[key] = (stamp, graph, sf, sm, out)
+        _, graph, sf, sm, out = ent
+        sf.copy_(frames)
+        sm.copy_(masks)
+        graph.replay()
+        return out
+
     def get_next_action(self, data):
         b, s, c, w, h = data["frames"].shape
-        with torch.no_grad():
-            pre = _lift(self.detector(NestedTensor(data["frames"].view(b * s, c, w, h), data["masks"].view(b * s, w, h))))
-            actions = self.fusion(pre)["actions"]
+        frames, masks = data["frames"].view(b * s, c, w, h), data["masks"].view(b * s, w, h)
+        use_graph = (frames.is_cuda and not self.fusion.training and not self.detector.training
+                     and bool(getattr(self.config, "POLICY_GRAPH", True)) and self._graphs is not None)
+        actions = None
+        if use_graph:
+            try:
+                actions = self._policy_graph(frames, masks)
+            except RuntimeError:   # capture not possible here: stay eager from now on
+                self._graphs = None
+                torch.cuda.synchronize()
+        if actions is None:
+            actions = self._policy_logits(frames, masks)
         return actions[s - 1].argmax(dim=-1).item()
 
 

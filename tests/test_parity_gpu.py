@@ -203,6 +203,22 @@ def test_batched_predict_equals_per_episode_predict():
             torch.testing.assert_close(together[k][i:i + 1], one[k], atol=1e-3 * float(one[k].abs().max()) + 1e-4, rtol=1e-3)
 
 
+def test_policy_step_graph_replay_equals_eager():
+    """get_next_action replayed from a captured HIP graph (eval mode) picks the same action as eager launches."""
+    from interactron_amd import Config, build_model
+    data = to_gpu(synthetic_episodes(2, height=128, width=160, tag="policy-graph"))
+    m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron")))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().eval()
+    picks = {}
+    for use in (True, False, True):
+        m.config.POLICY_GRAPH = use
+        picks.setdefault(use, []).append([m.get_next_action({"frames": data["frames"][i:i + 1, :s], "masks": data["masks"][i:i + 1, :s]})
+                                           for i in range(2) for s in (1, 2, 3, 4)])
+    assert m._graphs is not None and len(m._graphs) == 4, "the policy step was not captured"
+    assert picks[True][0] == picks[False][0] == picks[True][1]
+
+
 def test_config1_detr(golden, episode1):
     O = golden("golden_configs.pt")
     m = make("detr")
