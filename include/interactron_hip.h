@@ -47,7 +47,7 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
 int ix_gemm_set_mode(int mode); /* 0: fp32 MFMA only; 1: bf16x6 (3-way bf16 split) kernel, one tile per workgroup;
                                    2: persistent bf16x6 kernel, 8 waves; 3 (default): persistent, 12 waves (two
                                    producer waves per SIMD); 4: as 3 with the compact LDS image and deferred C
-                                   stores (experiment, neutral).  Returns the previous mode. */
+                                   stores (experiment, neutral); 5: eight consumer waves (experiment, slower).  Returns the previous mode. */
 int ix_gemm_stats(double* flops, int64_t* launches, int reset);
 int ix_gemm_prof_enable(int on);
 int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2); /* [0] fp32-MFMA kernel, [1] bf16x6 kernel */

@@ -1052,15 +1052,19 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 // (tools/micro/store_overlap, tools/tile_fill_nt.py): a wave completes one 1-KB store per ~300 clocks however it is
 // issued, but only stalls when the NEXT store comes sooner -- MFMAs issue underneath.  Back to back the 16 stores of a
 // sub-tile stall a consumer ~4600 clocks per item (a whole K = 64 item is ~8000 clocks of MFMA).
-template <int BN, bool A_KC, bool B_KC, bool DEFER>
-__global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
+// NC = 8 (mode 5, experiment): eight consumer waves of (64 x 32) / (32 x 32) sub-tiles beside the eight producers
+// (four waves per SIMD, 128 registers each): two MFMA-issuing waves per SIMD.
+template <int BN, bool A_KC, bool B_KC, bool DEFER, int NC = 4>
+__global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
+    static_assert(NC == 4 || (NC == 8 && !DEFER && BN >= 64), "consumer wave count");
     constexpr int BM = X6_BT;
     constexpr int ROWB = DEFER ? 64 : X6_ROWB;
     constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 3 * (PLANE_A + PLANE_B);
-    constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
+    constexpr int WN = NC == 8 ? 32 : (BN >= 64 ? BN / 2 : 32), WM = BM * BN / (NC * WN), TM = WM / 32, TN = WN / 32;
+    constexpr int NWN = BN / WN;   // consumer waves along n
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
     constexpr int CP = DEFER ? WN : WN + 4, SROWS = DEFER ? WM : 32;
-    __shared__ __attribute__((aligned(16))) float cstrip[4][SROWS * CP];
+    __shared__ __attribute__((aligned(16))) float cstrip[NC][SROWS * CP];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int dbgn = 0;
@@ -1071,17 +1075,17 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p,
     if (w >= last) return;
     const bool staged = p.split_k == 1 && p.c_vec;
 
-    if (wave >= 8) {
-        x6q_produce<BN, BN, B_KC, true, DEFER>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - 512);
+    if (wave >= NC + 4) {
+        x6q_produce<BN, BN, B_KC, true, DEFER>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - (NC + 4) * 64);
         return;
     }
-    if (wave >= 4) {
-        x6q_produce<BN, BM, A_KC, false, DEFER>(p, w, stride, last, &lds[0][0], BUF, 0, tid - 256);
+    if (wave >= NC) {
+        x6q_produce<BN, BM, A_KC, false, DEFER>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64);
         return;
     }
 
     // ---------------------------------------------------- consumers ----------------------------------------------------
-    const int wm = BN >= 64 ? (wave >> 1) * WM : wave * WM, wn = BN >= 64 ? (wave & 1) * WN : 0;
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
     const int lrow = lane >> 5, lcol = lane & 31;
     // byte offset of this lane's 16-byte fragment chunk inside its row, for k-slice 0 / 1 (compact image: swizzled with
     // bits 2-3 of the row; the fragment row is wm|wn + 32 i + lcol with wm, wn multiples of 32)
@@ -1308,6 +1312,21 @@ static void launch_x6q_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipS
         hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, DEFER>), grid, dim3(768), 0, stream, a, items);
 }
 
+template <int BN>
+static void launch_x6q8_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true, false, 8>), grid, dim3(1024), 0, stream, a, items);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, false, false, 8>), grid, dim3(1024), 0, stream, a, items);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, true, false, 8>), grid, dim3(1024), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, false, 8>), grid, dim3(1024), 0, stream, a, items);
+}
+
 template <bool DEFER>
 static void launch_x6q(const GemmArgs& a, int bn, int a_kc, int b_kc, int items, hipStream_t stream) {
     if (bn == 128)
@@ -1411,7 +1430,7 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
 // from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
 extern "C" int ix_gemm_set_mode(int mode) {
     const int old = g_x6;
-    g_x6 = mode < 0 ? 0 : (mode > 4 ? 4 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
+    g_x6 = mode < 0 ? 0 : (mode > 5 ? 5 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
     return old;
 }
 
@@ -1583,7 +1602,14 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     g_launches += 1;
     if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
     prof_mark(stream);
-    if (use_x6 && g_x6 == 4 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+    if (use_x6 && g_x6 == 5 && bn >= 64 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30)) {
+        if (bn == 128)
+            launch_x6q8_bn<128>(a, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+        else
+            launch_x6q8_bn<64>(a, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    } else if (use_x6 && g_x6 == 5 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
+        launch_x6q<false>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
+    else if (use_x6 && g_x6 == 4 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
         launch_x6q<true>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
     else if (use_x6 && g_x6 == 3 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
         launch_x6q<false>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
