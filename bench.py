@@ -157,11 +157,12 @@ def main():
     from interactron_amd.synthetic import load_procedural, synthetic_episodes
     from interactron_amd.trainer import FlatOuterStep, init_distributed
 
-    rank, local, world = init_distributed()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    local = local % torch.cuda.device_count()   # (IX_DIST_BACKEND=gloo smoke runs put several ranks on one GPU)
+    # bind this rank's GPU BEFORE the process group exists: RCCL communicators are created on the current device
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # (gloo smoke runs: several ranks per GPU)
     torch.cuda.set_device(local)
+    rank, _, world = init_distributed()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     lib = _lib.load()
     if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
@@ -208,7 +209,10 @@ def main():
 
     def fence():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -292,7 +296,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 
