@@ -38,6 +38,8 @@ def init_distributed(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        if torch.cuda.is_available():   # RCCL communicators are created on the current device: bind it first
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("IX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
