@@ -34,11 +34,19 @@ class _EvaluatorBase:
         self.test_dataset = dataset if dataset is not None else self.dataset_cls(
             config.DATASET.TEST.IMAGE_ROOT, config.DATASET.TEST.ANNOTATION_ROOT, config.DATASET.TEST.MODE, transform=transform)
         self.config = config
-        self.device = "cpu"
+        # one process per GPU: bind this rank's device (LOCAL_RANK) before anything is moved or launched -- train.py
+        # builds the evaluator BEFORE the trainer, and an evaluator that caches the then-current device 0 uploads every
+        # rank's episodes to GPU 0 while the trainer later moves the model to cuda:LOCAL_RANK
         if torch.cuda.is_available():
-            self.device = torch.cuda.current_device()
-            self.model.to(self.device)
+            from ..trainer import init_distributed
+            init_distributed()
+            self.model.to(torch.cuda.current_device())
         self.out_dir = config.EVALUATOR.OUTPUT_DIRECTORY + "/" + datetime.now().strftime("%m-%d-%Y-%H:%M:%S") + "/"
+
+    @property
+    def device(self):
+        """Where the model lives NOW (never a cached index: the trainer may have moved the model since __init__)."""
+        return next(self.model.parameters()).device
 
     def _episodes(self):
         """Yields (data, predictions) per evaluated batch."""

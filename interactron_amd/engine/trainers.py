@@ -32,6 +32,7 @@ def _to_device(data, device):
 
 class _TrainerBase:
     fixed_lrs = None          # InteractronRandomTrainer hard-codes 1e-5 / 1e-4 (interactron_random_trainer.py:70-71)
+    shard_by_root = True      # multi-GPU: an episode goes to rank hash(initial_image_path) % world (see shard_batch)
     pass_train_flag = False   # ... and calls model(data, train=is_train) (:91)
 
     def __init__(self, model, config, evaluator=None, train_dataset=None, test_dataset=None):
@@ -83,6 +84,22 @@ class _TrainerBase:
     def _tokens_per_batch(self, data):
         return data["frames"].shape[0] * data["frames"].shape[1]
 
+    def _decay_lr(self, cfg, outer, global_tokens):
+        """Cosine schedule of the reference (interactron_trainer.py:113-127), counted in tokens of the GLOBAL batch so that
+        every rank -- including one whose shard of a short last batch is empty -- holds the same counter and therefore
+        the same learning rate (the replicas apply Adam independently; different rates would let them drift apart)."""
+        lr = self._base_lr(cfg)
+        if cfg.LR_DECAY:
+            self.tokens += global_tokens
+            if self.tokens < cfg.WARMUP_TOKENS:
+                mult = float(self.tokens) / float(max(1, cfg.WARMUP_TOKENS))
+            else:
+                prog = float(self.tokens - cfg.WARMUP_TOKENS) / float(max(1, cfg.FINAL_TOKENS - cfg.WARMUP_TOKENS))
+                mult = max(0.1, 0.5 * (1.0 + math.cos(math.pi * prog)))
+            lr = lr * mult
+            outer.lrs[-1] = lr          # the reference decays only the supervisor (fusion) optimiser
+        return lr
+
     def train(self):
         model, cfg = self.model, self.config.TRAINER
         outer = self._make_outer(cfg)
@@ -96,10 +113,14 @@ class _TrainerBase:
             tag = "Train" if is_train else "Test"
             loss_list = []
             for it, data in enumerate(loader):
-                data = _to_device(shard_batch(data, self.rank, self.world), self.device)
+                global_tokens = self._tokens_per_batch(data)   # of the GLOBAL batch: identical on every rank
+                data = _to_device(shard_batch(data, self.rank, self.world, by_root=self.shard_by_root), self.device)
                 if data["frames"].shape[0] == 0:    # a short last batch can leave a rank without episodes: it still
-                    if is_train:                    # has to take part in the gradient all-reduce
+                    if hasattr(model, "dp_idle_step"):   # has to take part in the reward exchange, the gradient
+                        model.dp_idle_step(data)         # all-reduce and the LR schedule
+                    if is_train:
                         outer.step()
+                        self._decay_lr(cfg, outer, global_tokens)
                     continue
                 _, losses = model(data, train=is_train) if self.pass_train_flag else model(data)
                 for name, comp in losses.items():
@@ -109,16 +130,7 @@ class _TrainerBase:
                 loss_list.append(total.item())
                 if is_train:
                     outer.step()   # all-reduce(SUM) of the flat grads + clip_grad_norm_ + Adam x2, grads zeroed
-                    lr = self._base_lr(cfg)
-                    if cfg.LR_DECAY:
-                        self.tokens += self._tokens_per_batch(data) * self.world
-                        if self.tokens < cfg.WARMUP_TOKENS:
-                            mult = float(self.tokens) / float(max(1, cfg.WARMUP_TOKENS))
-                        else:
-                            prog = float(self.tokens - cfg.WARMUP_TOKENS) / float(max(1, cfg.FINAL_TOKENS - cfg.WARMUP_TOKENS))
-                            mult = max(0.1, 0.5 * (1.0 + math.cos(math.pi * prog)))
-                        lr = lr * mult
-                        outer.lrs[-1] = lr          # the reference decays only the supervisor (fusion) optimiser
+                    lr = self._decay_lr(cfg, outer, global_tokens)
                     self.logger.add_value("{}/LR".format(tag), lr)
                     if self.rank == 0 and it % 10 == 0:
                         print("epoch %d iter %d: train loss %.5f. lr %e" % (state["epoch"], it, float(np.mean(loss_list)), lr))

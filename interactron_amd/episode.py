@@ -26,7 +26,7 @@ from .criterion import HungarianMatcher, SetCriterion
 from .detector import NestedTensor, build_detector
 from .fusion import DecoderTransformer, Transformer
 from .meta import get_parameters, set_parameters, sgd_step
-from .storage import PathStorage
+from .storage import PathStorage, best_path_labels, exchange_rewards
 from .synthetic import load_procedural
 
 
@@ -43,6 +43,9 @@ def build(config):
 def _load_detector_weights(detector, config):
     w = getattr(config, "WEIGHTS", None)
     if w in (None, "", "procedural", "__procedural__"):
+        import warnings
+        warnings.warn("MODEL.WEIGHTS is %r: the detector starts from RNG-free SYNTHETIC weights (bench / tests only) -- "
+                      "metrics and checkpoints of this run say nothing about the reference's models" % (w,), stacklevel=2)
         load_procedural(detector, "detector.")
         return
     if not os.path.exists(str(w)):
@@ -267,12 +270,11 @@ class _Adaptive(_EpisodeModel):
                 rewards = torch.stack(gts).tolist() if self.use_policy else None   # one D2H for all episodes
                 total = None
                 if self.use_policy:   # PathStorage bookkeeping on the host, in episode order; ONE upload of the labels
-                    best_host = []
-                    for i, t in enumerate(ep):
-                        store = self.path_storage.setdefault(data["initial_image_path"][t], PathStorage())
-                        actions = actions_host[t][:4]
-                        store.add_path(actions, rewards[i])
-                        best_host.append(store.get_label(actions))
+                    if "dp_index" in data:   # data parallel: replay the global batch's chunk (see _dp_chunk_labels)
+                        best_host = self._dp_chunk_labels(data, e0 // chunk, chunk, list(ep), rewards)
+                    else:
+                        best_host = best_path_labels(self.path_storage, [data["initial_image_path"][t] for t in ep],
+                                                     [actions_host[t][:4] for t in ep], rewards)
                     best_all = ops.h2d_async(torch.tensor(best_host, dtype=torch.long))
                     weight = torch.ones(4, device=frames.device)
                 for i, t in enumerate(ep):
@@ -301,12 +303,42 @@ class _Adaptive(_EpisodeModel):
                 total.backward()
                 pt.mark("8 first-order backward")
                 del attached, fast1, post1, total
+            if self.use_policy and "dp_index" in data:   # chunks this rank has no episodes in: still part of the exchange
+                for c in range((b + chunk - 1) // chunk, self._dp_chunks(data, chunk)):
+                    self._dp_chunk_labels(data, c, chunk, [], [])
         finally:
             set_parameters(self.detector, theta)
         predictions = {"pred_logits": torch.stack(logits_out, dim=0), "pred_boxes": torch.stack(boxes_out, dim=0)}
         losses = _mean_losses(det_losses, "loss_detector")
         losses.update(_mean_losses(sup_losses, "loss_supervisor"))
         return predictions, losses
+
+    # ---- PathStorage under data parallelism ----------------------------------------------------------------------
+    # The reference keeps ONE trie per root image and fills it episode after episode (models/interactron.py:109-115);
+    # with episodes r::W on rank r a root image's paths would be spread over the ranks' tries and the policy labels
+    # would depend on W.  Every rank therefore replays the WHOLE global batch in global order: roots and actions of all
+    # episodes come with the batch (trainer.shard_batch, by_root), the rewards of the other ranks' episodes by one
+    # all-reduce of a few floats per chunk.  Local chunk c on every rank covers the contiguous global positions
+    # [c*chunk*W, (c+1)*chunk*W), so replaying chunk after chunk IS the global order.
+    @staticmethod
+    def _dp_chunks(data, chunk):
+        W, B = data["dp_world"], len(data["dp_roots"])
+        return ((B + W - 1) // W + chunk - 1) // chunk
+
+    def _dp_chunk_labels(self, data, c, chunk, local, rewards):
+        W, B = data["dp_world"], len(data["dp_roots"])
+        lo, hi = min(B, c * chunk * W), min(B, (c + 1) * chunk * W)
+        mine = [data["dp_index"][t] - lo for t in local]
+        allr = exchange_rewards(rewards, mine, hi - lo)
+        return best_path_labels(self.path_storage, data["dp_roots"][lo:hi], data["dp_actions"][lo:hi], allr, set(mine))
+
+    def dp_idle_step(self, data):
+        """A rank whose shard of a (short) batch is empty: no forward, but it still takes part in the reward exchanges
+        and keeps its tries in step with the other ranks'."""
+        if self.use_policy and "dp_index" in data:
+            chunk = max(1, int(getattr(self.config, "EPISODE_CHUNK", 16)))
+            for c in range(self._dp_chunks(data, chunk)):
+                self._dp_chunk_labels(data, c, chunk, [], [])
 
     def _forward_sequential(self, data):
         """The reference's own task-by-task schedule (kept for EPISODE_CHUNK: 0 and as the cross-check of the
@@ -326,11 +358,13 @@ class _Adaptive(_EpisodeModel):
                 if self.use_policy:
                     first = {k: v[[0]] for k, v in post.items() if k in ("pred_logits", "pred_boxes")}
                     gt = _weighted(self.criterion(first, [labels[0]], background_c=0.1))
-                    iip = data["initial_image_path"][task]
-                    store = self.path_storage.setdefault(iip, PathStorage())
                     actions = data["actions"][task][:4].tolist()
-                    store.add_path(actions, torch.mean(gt).item())
-                    best = torch.tensor(store.get_label(actions), dtype=torch.long, device=gt.device)
+                    if "dp_index" in data:
+                        label = self._dp_chunk_labels(data, task, 1, [task], [torch.mean(gt).item()])[0]
+                    else:
+                        label = best_path_labels(self.path_storage, [data["initial_image_path"][task]], [actions],
+                                                 [torch.mean(gt).item()])[0]
+                    best = torch.tensor(label, dtype=torch.long, device=gt.device)
                     weight = torch.ones(4, device=gt.device)
                     sup["loss_path"], _ = ops.WeightedCE.apply(fusion_out["actions"].reshape(4, 4), best, weight)
                     sup["policy_reward"] = gt
@@ -349,6 +383,9 @@ class _Adaptive(_EpisodeModel):
                 _weighted(dl).backward()
                 logits_out.append(post1["pred_logits"].detach())
                 boxes_out.append(post1["pred_boxes"].detach())
+            if self.use_policy and "dp_index" in data:
+                for c in range(b, self._dp_chunks(data, 1)):
+                    self._dp_chunk_labels(data, c, 1, [], [])
         finally:
             set_parameters(self.detector, theta)
         predictions = {"pred_logits": torch.stack(logits_out, dim=0), "pred_boxes": torch.stack(boxes_out, dim=0)}
@@ -383,24 +420,49 @@ class interactron(_Adaptive):
     # episode it is bound by the host issuing them.  In eval mode the launch sequence of each frame count is captured
     # once into a HIP graph (static input buffers, weights by address) and replayed; any capture failure, training
     # mode or a weight re-allocation falls back to eager launches.  POLICY_GRAPH: false in the config turns it off.
+    def _graph_stamp(self):
+        """Addresses of everything a captured policy graph reads by pointer: all parameters and buffers of detector and
+        fusion plus the folded frozen-BN affines.  A re-homed parameter (FlatBuffers, .to()) or a rebuilt fold changes it."""
+        ptrs = [t.data_ptr() for t in self.detector.parameters()] + [t.data_ptr() for t in self.detector.buffers()]
+        ptrs += [t.data_ptr() for t in self.fusion.parameters()] + [t.data_ptr() for t in self.fusion.buffers()]
+        folds = [m._fold for m in self.detector.modules() if getattr(m, "_fold", None) is not None]
+        ptrs += [t.data_ptr() for f in folds for t in f[1]]
+        return hash(tuple(ptrs)), folds
+
+    def invalidate_graphs(self):
+        """Drop every captured policy graph (weights were reloaded / moved); the next eval call captures afresh."""
+        if self.__dict__.get("_graphs"):
+            self._graphs = {}
+
+    def load_state_dict(self, *args, **kwargs):
+        # load_state_dict copies IN PLACE (addresses unchanged) but FrozenBatchNorm2d drops its folded scale/shift, which
+        # a captured graph reads by address: replaying it afterwards would read freed memory
+        self.invalidate_graphs()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .float(): storage moves
+        self.invalidate_graphs()
+        return super()._apply(fn, *args, **kwargs)
+
     def _policy_graph(self, frames, masks):
         key = (tuple(frames.shape), frames.device.index)
-        stamp = next(self.detector.parameters()).data_ptr()
         if "_graphs" not in self.__dict__:
             self._graphs = {}
         ent = self._graphs.get(key)
+        stamp = self._graph_stamp()[0] if ent is not None else None
         if ent is None or ent[0] != stamp:
             sf, sm = frames.clone(), masks.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):   # warm-up outside the capture (lazy initialisation, allocator pools)
+            with torch.cuda.stream(side):   # warm-up outside the capture (lazy initialisation, allocator pools, BN folds)
                 self._policy_logits(sf, sm)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._policy_logits(sf, sm)
-            ent = self._graphs[key] = (stamp, graph, sf, sm, out)
-        _, graph, sf, sm, out = ent
+            stamp, folds = self._graph_stamp()   # (after the warm-up: the folds exist now; held alive with the graph)
+            ent = self._graphs[key] = (stamp, graph, sf, sm, out, folds)
+        _, graph, sf, sm, out, _ = ent
         sf.copy_(frames)
         sm.copy_(masks)
         graph.replay()
@@ -415,7 +477,10 @@ class interactron(_Adaptive):
         if use_graph:
             try:
                 actions = self._policy_graph(frames, masks)
-            except RuntimeError:   # capture not possible here: stay eager from now on
+            except RuntimeError as e:   # capture not possible here: stay eager from now on, and say so once
+                import warnings
+                warnings.warn("get_next_action: HIP-graph capture of the policy step failed (%s); continuing with eager "
+                              "launches for the rest of this process" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
                 self._graphs = None
                 torch.cuda.synchronize()
         if actions is None:

@@ -84,6 +84,12 @@ def _chk(rc, name):
 def _req(t, name="tensor"):
     if not t.is_cuda:
         raise _lib.HipLibraryError("%s must live on the GPU: the HIP path has no CPU fallback" % name)
+    if _dev[0] is not None and t.device.index != _dev[0]:
+        # one process per GPU: every launch goes on the stream of the device bound at the first launch; a tensor of
+        # another device would be dereferenced by kernels running there (memory fault), so it is refused here
+        raise _lib.HipLibraryError("%s lives on cuda:%d but this process computes on cuda:%d (one process per GPU: bind "
+                                   "the device with torch.cuda.set_device(LOCAL_RANK) before building the model)"
+                                   % (name, t.device.index, _dev[0]))
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32, got %s" % (name, t.dtype))
     return t if t.is_contiguous() else t.contiguous()

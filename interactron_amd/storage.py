@@ -39,6 +39,36 @@ class PathStorage:
         return actions
 
 
+def best_path_labels(path_storage, roots, actions, rewards, mine=None):
+    """The PathStorage bookkeeping of reference models/interactron.py:109-115 for a run of episodes, in order: add each
+    episode's (actions, reward) to the trie of its root image, then read that episode's label back.  ``mine`` (optional
+    set of positions) selects the episodes whose labels are returned -- under data parallelism every rank replays the
+    WHOLE global batch in global order (rewards of the other ranks' episodes arrive by ``exchange_rewards``) so that its
+    tries, and hence its labels, are exactly those of a single process; it needs labels only for its own episodes."""
+    labels = []
+    for i, (root, acts, rew) in enumerate(zip(roots, actions, rewards)):
+        store = path_storage.setdefault(root, PathStorage())
+        store.add_path(acts, rew)
+        if mine is None or i in mine:
+            labels.append(store.get_label(acts))
+    return labels
+
+
+def exchange_rewards(local_rewards, slots, total):
+    """Data-parallel hand-over of the per-episode rewards: this rank's ``local_rewards`` belong to positions ``slots`` of a
+    run of ``total`` episodes; returns all ``total`` rewards (list of float).  One tiny all-reduce (SUM of disjoint
+    one-hot placements) -- every rank of the group must call it the same number of times."""
+    import torch.distributed as dist
+    buf = torch.zeros(total, dtype=torch.float64)
+    for s, r in zip(slots, local_rewards):
+        buf[s] = r
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            buf = buf.cuda()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf.tolist()
+
+
 def collate_fn(batch):
     return {
         "frames": torch.stack([torch.stack(b["frames"]) for b in batch]),

@@ -16,11 +16,17 @@ import torch.distributed as dist
 ALIGN = 64  # elements; keeps every parameter view 256-byte aligned inside the flat buffer (float4 loads stay legal)
 
 
-def shard_batch(data, rank, world_size):
-    """Episodes ``rank::world_size`` of a collated batch (reference collate layout, utils/storage_utils.py:53-64)."""
+def shard_batch(data, rank, world_size, by_root=False):
+    """Episodes ``rank::world_size`` of a collated batch (reference collate layout, utils/storage_utils.py:53-64).
+
+    ``by_root``: also attach what keeps ``model.path_storage`` identical to a single process (reference
+    models/interactron.py:109-115 keys it by root image and fills it episode after episode): the root paths and actions
+    of the WHOLE batch plus this rank's positions in it (``dp_roots``, ``dp_actions``, ``dp_index``, ``dp_world``).  The
+    model then exchanges the per-episode rewards (a few floats per chunk) and replays the global batch in global order."""
     if world_size == 1:
         return data
-    idx = list(range(rank, data["frames"].shape[0], world_size))
+    total = data["frames"].shape[0]
+    idx = list(range(rank, total, world_size))
     out = {}
     for k, v in data.items():
         if torch.is_tensor(v):
@@ -29,6 +35,11 @@ def shard_batch(data, rank, world_size):
             out[k] = [v[i] for i in idx]
         else:
             out[k] = v
+    if by_root and "initial_image_path" in data and "actions" in data:
+        out["dp_roots"] = list(data["initial_image_path"])
+        out["dp_actions"] = data["actions"][:, :4].tolist()
+        out["dp_index"] = idx
+        out["dp_world"] = world_size
     return out
 
 
@@ -37,9 +48,11 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and torch.cuda.is_available():
+        # bind this rank's GPU first, whether or not the group exists yet: RCCL communicators are created on the current
+        # device, and everything built afterwards (evaluator, trainer, flat buffers) must land on cuda:LOCAL_RANK
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
-        if torch.cuda.is_available():   # RCCL communicators are created on the current device: bind it first
-            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or os.environ.get("IX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

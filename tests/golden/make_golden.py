@@ -52,9 +52,20 @@ def summarize(t, full_limit=70000, samples=256):
     return rec
 
 
-def grad_record(named):
-    return {k: (None if g is None else {"shape": tuple(g.shape), "norm": float(g.double().norm()),
-                                        "head": g.reshape(-1)[:8].clone()}) for k, g in named.items()}
+def grad_record(named, samples=256):
+    """Per gradient tensor: None flag, shape, L2 norm, the first 8 values and `samples` values on an even stride over
+    the whole tensor (a slice routed to the wrong place beyond element 8 changes the strided sample even when it
+    preserves the norm)."""
+    out = {}
+    for k, g in named.items():
+        if g is None:
+            out[k] = None
+            continue
+        flat = g.detach().reshape(-1)
+        idx = torch.linspace(0, flat.numel() - 1, min(samples, flat.numel())).long()
+        out[k] = {"shape": tuple(g.shape), "norm": float(g.double().norm()), "head": flat[:8].clone(),
+                  "idx": idx, "sample": flat[idx].clone()}
+    return out
 
 
 def install_reference(ref):
@@ -246,12 +257,15 @@ def main():
     # G11 / G12: predict and get_next_action
     pred = model.predict(data1)
     M["g11"] = {k: summarize(v) for k, v in pred.items()}
-    g12 = []
+    g12, g12_logits = [], []
+    hook = model.fusion.register_forward_hook(lambda mod, inp, out: g12_logits.append(out["actions"].detach().clone()))
     for s in range(1, 5):
         d = {"frames": data1["frames"][:, :s], "masks": data1["masks"][:, :s],
              "category_ids": [data1["category_ids"][0][:s]], "boxes": [data1["boxes"][0][:s]]}
         g12.append(model.get_next_action(d))
+    hook.remove()
     M["g12"] = g12
+    M["g12_logits"] = g12_logits   # the [4, 4] policy logits behind each int (row s-1 is the one argmax'ed)
     torch.save(M, os.path.join(args.out, "golden_model.pt"))
     print("wrote golden_model.pt")
     if args.skip_train:

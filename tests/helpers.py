@@ -17,7 +17,8 @@ def check_record(rec, t, atol=1e-5, rtol=1e-4, what=""):
 
 
 def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
-    """Compare a gradient against a ``grad_record`` entry (None flag, L2 norm, first 8 values).
+    """Compare a gradient against a ``grad_record`` entry (None flag, L2 norm, first 8 values, 256 values on an even
+    stride over the whole tensor -- a slice routed to the wrong place keeps the norm but not the strided sample).
 
     ``norm64``: the float64 (exact) norm of the same tensor from tests/golden/golden_train_f64.pt; when given, the
     tolerance is widened by 3x the reference's own float32 rounding error |rec.norm - norm64| on that tensor."""
@@ -42,6 +43,17 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     scale = max(rec["norm"] / max(g.numel(), 1) ** 0.5, 1e-12)
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
     assert err <= 20 * rel * scale + ref_noise + 1e-9, (what, err, scale)
+    if "sample" in rec:
+        # element-wise over the strided sample: per element 20 x rel x the tensor's RMS (float32 summation-order noise is
+        # relative to the tensor's scale, not to each element), and the sample as a whole within 4 x rel in L2
+        got = g.reshape(-1)[rec["idx"]].double()
+        ref = rec["sample"].double()
+        diff = got - ref
+        worst = diff.abs().max().item()
+        assert worst <= 20 * rel * scale + ref_noise + 1e-9, (what, "strided sample", worst, scale)
+        rn = float(ref.norm())
+        assert float(diff.norm()) <= 4 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9, \
+            (what, "strided sample L2", float(diff.norm()), rn)
 
 
 def image_key(t):
@@ -64,10 +76,15 @@ class ReferenceMatching:
     relative -- i.e. any difference is a tie, not an error -- and is then returned, so that the downstream gradient
     comparison is about arithmetic, not about tie-breaking."""
 
-    def __init__(self, recorded):
+    # Share of images whose own optimum may differ from the recorded assignment (always by a tie, see above) before the
+    # run is declared a failure: measured 0-3 % on the RNG-free weights; a matcher or cost-kernel bug flips most images.
+    MAX_FLIP_SHARE = 0.10
+
+    def __init__(self, recorded, max_flip_share=None):
         self.recorded = recorded
         self.flips = 0
         self.calls = 0
+        self.max_flip_share = self.MAX_FLIP_SHARE if max_flip_share is None else max_flip_share
 
     def __enter__(self):
         from interactron_amd import criterion as cr
@@ -101,3 +118,7 @@ class ReferenceMatching:
 
     def __exit__(self, *exc):
         self._cls.assign = self._orig
+        print("ReferenceMatching: %d of %d images matched differently from the reference (ties)" % (self.flips, self.calls))
+        if exc[0] is None:
+            assert self.flips <= self.max_flip_share * max(self.calls, 1) + 1, \
+                "HIP matcher disagrees with the reference's assignment on %d of %d images" % (self.flips, self.calls)

@@ -80,6 +80,36 @@ def test_config_coercion_rule(tmp_path):
         assert c.MODEL.NUM_CLASSES == 1235
 
 
+# the values the reference ships for the keys its factories switch on (utils/config_utils.py:53-113)
+SHIPPED = {"single_frame_baseline": ("detr", None, "random_policy_evaluator"),   # evaluation-only in the reference
+           "multi_frame_baseline": ("detr_multiframe", "direct_supervision", "random_policy_evaluator"),
+           "interactron_random": ("interactron_random", "interactron_random", "random_policy_evaluator"),
+           "interactron": ("interactron", "interactron", "interactive_evaluator")}
+
+
+@pytest.mark.parametrize("name", sorted(SHIPPED))
+def test_every_shipped_config_selects_a_valid_model_trainer_evaluator(name):
+    """Every configs/*.yaml (and its *_synthetic.yaml twin) must pass the factories' arg_check, name the reference's
+    types, fail loudly on a missing weight file, and the twin must differ from it in MODEL.WEIGHTS only."""
+    from interactron_amd import config as cfgmod
+    from interactron_amd import get_config
+    from interactron_amd.episode import _load_detector_weights
+    c = get_config(os.path.join(ROOT, "configs", name + ".yaml"))
+    s = get_config(os.path.join(ROOT, "configs", name + "_synthetic.yaml"))
+    for cfg in (c, s):
+        cfgmod.arg_check(cfg.MODEL.TYPE, cfgmod.MODEL_TYPES, "model")
+        trainer = cfg.TRAINER.TYPE if hasattr(cfg, "TRAINER") else None
+        if trainer is not None:
+            cfgmod.arg_check(trainer, ["direct_supervision", "interactron_random", "interactron"], "supervisor")
+        cfgmod.arg_check(cfg.EVALUATOR.TYPE, ["random_policy_evaluator", "interactive_evaluator"], "evaluator")
+        assert (cfg.MODEL.TYPE, trainer, cfg.EVALUATOR.TYPE) == SHIPPED[name]
+    a, b = c.dictionarize(), s.dictionarize()
+    assert b["MODEL"].pop("WEIGHTS") == "procedural" and a["MODEL"].pop("WEIGHTS").startswith("pretrained_weights/")
+    assert a == b
+    with pytest.raises(FileNotFoundError):
+        _load_detector_weights(torch.nn.Linear(1, 1), c.MODEL)
+
+
 def test_path_storage_matches_reference_script(golden):
     from interactron_amd.storage import PathStorage
     g = golden("golden_small.pt")["g14"]
@@ -169,3 +199,88 @@ def test_flat_gradient_allreduce_world_size_2_gloo():
     (l0, r0, seg), (l1, r1, _) = out[0], out[1]
     assert torch.allclose(r0, l0 + l1) and torch.equal(r0, r1)   # SUM (not mean), identical on every rank
     assert seg[0][0] == 0 and seg[0][1] == seg[1][0] and seg[1][1] == r0.numel()
+
+
+# ---- PathStorage under data parallelism: world_size 2 over gloo == one process ---------------------------------------
+def _dp_script():
+    """Three global batches of 5 / 5 / 3 episodes with repeated root images and deterministic rewards (a short last
+    batch leaves rank 1 of the last chunk with fewer episodes)."""
+    rng = np.random.default_rng(5)
+    batches = []
+    for n in (5, 5, 3):
+        roots = ["root%d" % int(r) for r in rng.integers(0, 3, n)]
+        actions = torch.from_numpy(rng.integers(0, 4, (n, 5)))
+        rewards = [float(x) for x in rng.uniform(0.5, 3.0, n)]
+        batches.append((roots, actions, rewards))
+    return batches
+
+
+def _dp_labels_single(chunk):
+    from interactron_amd.storage import best_path_labels
+    storage, labels = {}, []
+    for roots, actions, rewards in _dp_script():
+        for e0 in range(0, len(roots), chunk):   # the episode-batched step replays chunk by chunk, in order
+            sl = slice(e0, e0 + chunk)
+            labels.append(best_path_labels(storage, roots[sl], actions[sl, :4].tolist(), rewards[sl]))
+    return [l for c in labels for l in c], storage
+
+
+def _dp_worker(rank, world, port, chunk, out):
+    import torch.distributed as dist
+    from interactron_amd.episode import _Adaptive
+    from interactron_amd.trainer import shard_batch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Host:   # the host-side half of _Adaptive.forward: chunk loop + reward exchange, no GPU work
+        path_storage = {}
+        _dp_chunks = staticmethod(_Adaptive._dp_chunks)
+        _dp_chunk_labels = _Adaptive._dp_chunk_labels
+
+    host, got = Host(), {}
+    for roots, actions, rewards in _dp_script():
+        data = {"frames": torch.zeros(len(roots), 5, 1), "actions": actions, "initial_image_path": roots}
+        d = shard_batch(data, rank, world, by_root=True)
+        b = d["frames"].shape[0]
+        mine = d["dp_index"]
+        for e0 in range(0, b, chunk):
+            ep = list(range(e0, min(b, e0 + chunk)))
+            lab = host._dp_chunk_labels(d, e0 // chunk, chunk, ep, [rewards[mine[t]] for t in ep])
+            for t, l in zip(ep, lab):
+                got[(len(got), mine[t])] = l
+        for c in range((b + chunk - 1) // chunk, host._dp_chunks(d, chunk)):
+            host._dp_chunk_labels(d, c, chunk, [], [])
+    out[rank] = (list(got.items()), {k: v.get_label([0, 1, 2, 3]) if _has(v, [0, 1, 2, 3]) else None
+                                     for k, v in host.path_storage.items()})
+    dist.destroy_process_group()
+
+
+def _has(store, path):
+    node = store.root
+    for a in path:
+        if a not in node.children:
+            return False
+        node = node.children[a]
+    return True
+
+
+@pytest.mark.parametrize("chunk", [1, 2])
+def test_path_storage_world_size_2_gloo_equals_single_process(chunk):
+    """Ranks run episodes r::2 of every batch and exchange only the rewards; their policy labels and tries must be
+    those of one process that saw the whole batch in order (reference models/interactron.py:109-115)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_dp_worker, args=(world, port, chunk, out), nprocs=world, join=True)
+    # single-process reference with the chunk size the two ranks TOGETHER cover per pass (chunk * world global episodes)
+    want, storage = _dp_labels_single(chunk * world)
+    per_batch, k = [], 0
+    for roots, _, _ in _dp_script():
+        per_batch.append(want[k:k + len(roots)])
+        k += len(roots)
+    seen = {0: iter(out[0][0]), 1: iter(out[1][0])}
+    for bi, (roots, _, _) in enumerate(_dp_script()):
+        for g in range(len(roots)):
+            (_, gi), lab = next(seen[g % world])
+            assert gi == g and lab == per_batch[bi][g], (bi, g, lab, per_batch[bi][g])
+    assert set(out[0][1]) == set(out[1][1]) == set(storage)   # every rank holds every root's trie
+    assert out[0][1] == out[1][1]

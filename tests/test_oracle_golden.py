@@ -181,5 +181,6 @@ def test_g11_g12_predict_and_policy(golden, det, episode1):
         check_record(rec, pred[k], atol=2e-4, rtol=1e-3, what="g11/" + k)
     for s in range(1, 5):
         dd = {"frames": episode1["frames"][:, :s], "masks": episode1["masks"][:, :s]}
-        a, _ = oe.interactron_next_action(det, fus, dd, CFG)
+        a, logits = oe.interactron_next_action(det, fus, dd, CFG)
         assert a == M["g12"][s - 1]
+        torch.testing.assert_close(logits.reshape(4, 4), M["g12_logits"][s - 1].reshape(4, 4), atol=2e-5, rtol=1e-4)

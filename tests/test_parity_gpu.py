@@ -55,6 +55,83 @@ def rec_tol(rec):
     return 1e-3 * float(ref.abs().max()) + 1e-4
 
 
+def _g2_inputs():
+    import numpy as np
+    from interactron_amd.synthetic import hash_normal, hash_uniform
+    logits = torch.from_numpy((hash_normal("g2/logits", 5 * 50 * 1236) * 2.0).astype(np.float32)).reshape(5, 50, 1236)
+    boxes = torch.from_numpy(np.concatenate([hash_uniform("g2/c", 500, 0.2, 0.8).reshape(250, 2),
+                                             hash_uniform("g2/wh", 500, 0.05, 0.5).reshape(250, 2)], 1)
+                             .astype(np.float32)).reshape(5, 50, 4)
+    return logits, boxes
+
+
+def test_g1_pairwise_giou_through_the_cost_kernel(golden):
+    """G1 (reference box_ops.generalized_box_iou, [50, 7]) read back out of the HIP cost kernel: with the class and L1
+    weights at zero and the GIoU weight at -1 the cost matrix IS the pairwise GIoU (matcher.py:63-70)."""
+    from interactron_amd import hipops as ops
+    g = golden("golden_small.pt")["g1"]
+    pred, tgt = g["pred"].cuda(), g["tgt"].cuda()
+    logits = torch.zeros(50, 1236, device="cuda")
+    ids = torch.zeros(7, dtype=torch.int64, device="cuda")
+    cost = ops.match_cost(logits, pred, ids, tgt, 0.0, 0.0, -1.0)
+    torch.testing.assert_close(cost.cpu(), g["giou"], atol=2e-6, rtol=1e-5)
+
+
+def test_g2_hungarian_indices_bit_exact_through_the_hip_matcher(golden):
+    """The product matcher (HIP cost kernel -> pinned D2H -> ix_lsap_f32) on the reference's G2 inputs: the int64 index
+    pairs must EQUAL the reference's (matcher.py:54-77 + scipy) for all five images -- an empty image, and repeated
+    ground-truth boxes whose cost columns tie exactly."""
+    from interactron_amd import HungarianMatcher
+    g = golden("golden_small.pt")["g2"]
+    logits, boxes = _g2_inputs()
+    targets = [{"labels": t["labels"].cuda(), "boxes": t["boxes"].cuda()} for t in g["targets"]]
+    got = HungarianMatcher(1.0, 5.0, 2.0)({"pred_logits": logits.cuda(), "pred_boxes": boxes.cuda()}, targets)
+    assert len(got) == 5
+    for i, ((a, b), (ra, rb)) in enumerate(zip(got, g["indices"])):
+        assert a.dtype == torch.int64 and b.dtype == torch.int64 and not a.is_cuda
+        assert torch.equal(a, ra) and torch.equal(b, rb), ("image %d" % i, a, ra, b, rb)
+    # one image at a time (the per-episode call shape of the sequential schedule) gives the same pairs
+    for i in range(5):
+        (a, b), = HungarianMatcher(1.0, 5.0, 2.0)({"pred_logits": logits[i:i + 1].cuda(), "pred_boxes": boxes[i:i + 1].cuda()},
+                                                  targets[i:i + 1])
+        assert torch.equal(a, g["indices"][i][0]) and torch.equal(b, g["indices"][i][1])
+
+
+def test_g3_set_criterion_losses_and_gradients(golden):
+    """SetCriterion on the G2 inputs with the HIP matcher's OWN assignment (no pinning): five loss scalars and the
+    gradients w.r.t. logits and boxes against the reference's (detr.py:111-265, background_c = 0.1)."""
+    from interactron_amd import HungarianMatcher, SetCriterion
+    G = golden("golden_small.pt")
+    logits, boxes = _g2_inputs()
+    targets = [{"labels": t["labels"].cuda(), "boxes": t["boxes"].cuda()} for t in G["g2"]["targets"]]
+    crit = SetCriterion(1235, HungarianMatcher(1.0, 5.0, 2.0), {"loss_ce": 1, "loss_bbox": 5, "loss_giou": 2}, 0.1,
+                        ["labels", "boxes", "cardinality"]).cuda()
+    lg, bx = logits.cuda().requires_grad_(True), boxes.cuda().requires_grad_(True)
+    losses = crit({"pred_logits": lg, "pred_boxes": bx}, targets, background_c=0.1)
+    (losses["loss_ce"] + 5 * losses["loss_giou"] + 2 * losses["loss_bbox"]).backward()
+    assert list(losses) == list(G["g3"]["losses"])
+    for k, v in G["g3"]["losses"].items():
+        torch.testing.assert_close(losses[k].detach().cpu(), v, atol=1e-5, rtol=1e-5, msg=lambda m: k + ": " + m)
+    check_record(G["g3"]["grad_logits"], lg.grad, atol=1e-8, rtol=1e-4, what="g3/grad_logits")
+    torch.testing.assert_close(bx.grad.cpu(), G["g3"]["grad_boxes"], atol=1e-7, rtol=1e-4)
+
+
+def test_g10_clipped_sgd_bit_exact(golden):
+    """The fused multi-tensor inner step on the reference's G10 tensors (meta_utils.py:135-142: clipped elements, a None
+    gradient): p - clamp(lr g, +-0.01) is one multiply, one clamp and one subtract per element, so the float32 results
+    must be bit-identical."""
+    import numpy as np
+    from interactron_amd.meta import sgd_step
+    from interactron_amd.synthetic import hash_normal
+    g = golden("golden_small.pt")["g10"]
+    p = [torch.from_numpy(hash_normal("g10/p%d" % i, n).astype(np.float32)).cuda() for i, n in enumerate((1000, 37, 4096))]
+    gr = [torch.from_numpy((hash_normal("g10/g%d" % i, n) * 12.0).astype(np.float32)).cuda() for i, n in enumerate((1000, 37, 4096))]
+    gr[1] = None
+    out = sgd_step(p, gr, 1e-3)
+    for a, b in zip(out, g["out"]):
+        assert torch.equal(a.cpu(), b)
+
+
 def test_g7_detector_forward(golden, interactron_model, episode1):
     from interactron_amd import NestedTensor
     M = golden("golden_model.pt")
@@ -95,6 +172,10 @@ def test_g11_g12_predict_and_next_action(golden, interactron_model, episode1):
     for s in range(1, 5):
         d = {"frames": episode1["frames"][:, :s], "masks": episode1["masks"][:, :s]}
         assert interactron_model.get_next_action(d) == M["g12"][s - 1]
+        # ... and the [4, 4] policy logits behind the int (captured from the reference's fusion by a forward hook)
+        ref = M["g12_logits"][s - 1].reshape(4, 4)
+        got = interactron_model._policy_logits(d["frames"][0], d["masks"][0]).reshape(4, 4)
+        torch.testing.assert_close(got.cpu(), ref, atol=1e-3 * float(ref.abs().max()) + 1e-4, rtol=1e-3)
 
 
 def test_g13_g16_meta_train_step_and_outer_update(golden):

@@ -17,6 +17,8 @@ def train():
     manual_seed(42)   # dropout stream of the HIP kernels
     args = get_args()
     cfg = get_config(args.config_file)
+    from interactron_amd.trainer import init_distributed
+    init_distributed()   # torchrun: binds cuda:LOCAL_RANK and creates the RCCL group before anything touches the GPU
     model = build_model(cfg.MODEL)
     evaluator = build_evaluator(model, cfg)
     trainer = build_trainer(model, cfg, evaluator=evaluator)
