@@ -128,6 +128,42 @@ int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, 
                              const float* gamma, const float* mean, const float* rstd, float* grad_dy, float* grad_x,
                              float* grad_gamma, int64_t rows, int D, int groups, ix_stream_t stream);
 
+/* ---- flash-style attention (no [L, S] tensor in HBM) ------------------------------------------------------------
+ * O = dropout(softmax(scale Q K^T + key bias)) V per (batch, head), and its first and second derivative, with the
+ * bf16x6 arithmetic of ix_gemm_f32 (fp32 operands split exactly into three bf16 planes, six MFMA terms per product).
+ * Replaces the same reference lines as the ix_attn_prob_* family: `att = softmax(q k^T / sqrt(hd)); att = drop(att);
+ * y = att v` of models/gpt.py:39-57 and nn.MultiheadAttention's core in models/detr_models/transformer.py:148-161,
+ * 211-232, plus autograd's first / second derivative of them (models/interactron.py:99-123).
+ *
+ * ix_attn_split_f32: fp32 activations x [n][R][ld] (head h = columns off + h*hd .. + hd) -> bf16 planes (h, m, l) in
+ *   row layout  row_planes [3][n*H][Rp][hd]   (operand of products that contract over d) and / or
+ *   tr  layout  tr_planes  [3][n*H][hd][Rp]   (operand of products that contract over rows; rows permuted within
+ *   16-groups to the MFMA accumulator order).  Rp = R rounded up to 128, padded rows are zero.  Either output may be null.
+ * ix_attn_bias_f32: key_padding_mask uint8 [n][mask_ld] (nonzero = ignore; null = none) -> additive bias [n][Sb],
+ *   Sb >= S (the kernels want S rounded up to 128): 0 for valid keys, -inf for masked keys and the tail.
+ * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers).
+ *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key). */
+int ix_attn_split_f32(const float* x, void* row_planes, void* tr_planes, int n, int R, int Rp, int64_t ld, int off, int H,
+                      int hd, ix_stream_t stream);
+int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, int Sb, int64_t mask_ld, ix_stream_t stream);
+int ix_flash_fwd_f32(const void* q_row, const void* k_row, const void* v_tr, const float* bias, float* out, float* lse,
+                     int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_out, int off_out, float scale,
+                     float p_drop, uint64_t seed, ix_stream_t stream);
+
+/* ix_attn_rowdot_f32: t[bh][q] = sum_d a[q, h, d] b[q, h, d] over heads of two [n][L][ld] activations (delta = dO . O).
+ * ix_flash_bwd_f32: (gq, gk, gv) of the attention core from (q, k, v, dO) planes + lse + delta; probabilities are
+ *   recomputed tile by tile.  gq (may be null) is written by query-owning workgroups, gk + gv (both or neither) by
+ *   key-owning ones; outputs are [n][L|S][ld_*] with head h at off_* + h*hd (so gq and gk may share one packed buffer).
+ * ix_flash_dropmask_f32: the kernels' dropout mask as a tensor m[BH][L][S] (1/keep or 0) -- tests only. */
+int ix_attn_rowdot_f32(const float* a, const float* b, float* t, int n, int H, int L, int Lp, int hd, int64_t lda, int offa,
+                       int64_t ldb, int offb, ix_stream_t stream);
+int ix_flash_bwd_f32(const void* q_row, const void* q_tr, const void* do_row, const void* do_tr, const void* k_row,
+                     const void* k_tr, const void* v_row, const float* bias, const float* lse, const float* delta, float* gq,
+                     float* gk, float* gv, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_q, int off_q,
+                     int64_t ld_k, int off_k, int64_t ld_v, int off_v, float scale, float p_drop, uint64_t seed,
+                     ix_stream_t stream);
+int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
+
 /* ---- set criterion ---------------------------------------------------------------------------------------
  * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the
  * scipy.optimize.linear_sum_assignment call of matcher.py:76; weighted CE: detr.py:111-132; box losses:

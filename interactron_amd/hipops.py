@@ -408,6 +408,121 @@ class AttentionCoreBwd(Function):
         return grad_q, grad_k, grad_v, None, None, grad_do, None, None, None, None
 
 
+# ---------------------------------------------------------------------------------------------------------
+# flash-style attention core (csrc/flash.hip): no [L, S] tensor in HBM
+# ---------------------------------------------------------------------------------------------------------
+def _pad128(R):
+    return (R + 127) // 128 * 128
+
+
+def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True):
+    """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> (row planes, tr planes): flat bf16 tensors
+    [3][n*H][Rp][hd] / [3][n*H][hd][Rp] (see csrc/flash.hip), Rp = R rounded up to 128."""
+    x = _req(x, "attention operand")
+    Rp = _pad128(R)
+    numel = 3 * n * H * Rp * hd
+    rowp = torch.empty(numel, dtype=torch.bfloat16, device=x.device) if row else None
+    trp = torch.empty(numel, dtype=torch.bfloat16, device=x.device) if tr else None
+    _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, trp.data_ptr() if tr else None, n, R, Rp, ld,
+                                off, H, hd, _stream()), "ix_attn_split_f32")
+    return rowp, trp
+
+
+def attn_bias(mask, n, S, device):
+    """additive key bias [n, Sp]: 0 valid / -inf masked or tail (Sp = S rounded up to 128); mask uint8 [n, S] or None."""
+    Sb = _pad128(S)
+    bias = torch.empty(n, Sb, dtype=torch.float32, device=device)
+    _chk(_L().ix_attn_bias_f32(mask.data_ptr() if mask is not None else None, bias.data_ptr(), n, S, Sb,
+                               mask.shape[-1] if mask is not None else 0, _stream()), "ix_attn_bias_f32")
+    return bias
+
+
+def flash_dropmask(BH, L, S, p, seed, device="cuda"):
+    """The flash kernels' dropout mask as a tensor [BH, L, S] (1/keep or 0) -- for tests."""
+    m = torch.empty(BH, L, S, dtype=torch.float32, device=device)
+    _chk(_L().ix_flash_dropmask_f32(m.data_ptr(), BH, L, S, p, seed, _stream()), "ix_flash_dropmask_f32")
+    return m
+
+
+def flash_forward(q, k, v, g, mask, p, seed):
+    """-> (out [n, L, H*hd], lse [n*H, Lp] (+inf beyond L), operand planes) for geometry g (AttnGeom)."""
+    dev = q.device
+    pl = {}
+    pl["qr"], pl["qt"] = attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
+    pl["kr"], pl["kt"] = attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
+    pl["vr"], pl["vt"] = attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
+    pl["bias"] = attn_bias(mask, g.n, g.S, dev)
+    Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
+    out = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
+    lse = torch.full((g.n * g.heads, Lp), float("inf"), dtype=torch.float32, device=dev)   # +inf: P = 0 for padded queries
+    _chk(_L().ix_flash_fwd_f32(pl["qr"].data_ptr(), pl["kr"].data_ptr(), pl["vt"].data_ptr(), pl["bias"].data_ptr(),
+                               out.data_ptr(), lse.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed,
+                               _stream()), "ix_flash_fwd_f32")
+    return out, lse, pl
+
+
+def flash_supported(g):
+    return g.hd in (32, 64) and g.q_ld % 4 == 0 and g.k_ld % 4 == 0 and g.v_ld % 4 == 0 and g.q_off % 4 == 0 \
+        and g.k_off % 4 == 0 and g.v_off % 4 == 0 and g.n * g.heads <= 65535
+
+
+class FlashAttention(Function):
+    """out[b,l,h*hd+:] = dropout(softmax(scale q k^T [+ key mask])) v per (batch, head) without [L, S] tensors in HBM
+    (csrc/flash.hip).  Saves q, k, v, out, the row normalisers and the bf16 operand planes."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, g, mask, p, seed):
+        q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
+        out, lse, pl = flash_forward(q, k, v, g, mask, p, seed)
+        ctx.g, ctx.p, ctx.seed, ctx.pl = g, p, seed, pl
+        ctx.same_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape   # packed [q | k] projection buffer
+        ctx.save_for_backward(q, k, v, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, out, lse = ctx.saved_tensors
+        gq, gk, gv = FlashAttentionBwd.call(q, k, v, out, lse, do, ctx.g, ctx.p, ctx.seed, ctx.pl, ctx.same_qk)
+        return gq, gk, gv, None, None, None, None
+
+
+class FlashAttentionBwd(Function):
+    """(gq, gk, gv) of FlashAttention; gq / gk come back in the layout of the packed q / k projection buffers (one shared
+    buffer when q and k are the same tensor: autograd then has nothing to add)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, out, lse, do, g, p, seed, pl, same_qk):
+        do = _req(do.contiguous(), "attention dO")
+        dev = q.device
+        Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
+        dor, dot = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd)
+        delta = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)
+        _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
+                                     _stream()), "ix_attn_rowdot_f32")
+        # gradient buffers in the operands' own (packed) layouts; columns of other heads' / other tensors stay zero
+        full = lambda t, ld, off: ld == E and off == 0
+        packed = same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]   # [q | k] buffer: fully covered
+        gq = (torch.empty if packed or full(q, g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
+        gk = gq if same_qk else (torch.empty if full(k, g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
+        gv = (torch.empty if full(v, g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
+        _chk(_L().ix_flash_bwd_f32(pl["qr"].data_ptr(), pl["qt"].data_ptr(), dor.data_ptr(), dot.data_ptr(), pl["kr"].data_ptr(),
+                                   pl["kt"].data_ptr(), pl["vr"].data_ptr(), pl["bias"].data_ptr(), lse.data_ptr(),
+                                   delta.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
+                                   g.hd, g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, g.scale, p, seed, _stream()),
+             "ix_flash_bwd_f32")
+        ctx.g, ctx.p, ctx.seed, ctx.same_qk = g, p, seed, same_qk
+        ctx.pl = dict(pl, dor=dor, dot=dot, delta=delta)
+        ctx.save_for_backward(q, k, v, out, lse, do)
+        if same_qk:   # one buffer carries both gradients: hand it to q, nothing to k
+            return gq, None, gv
+        return gq, gk, gv
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hq, hk, hv):
+        raise NotImplementedError("flash attention double backward")
+
+
 def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, scale, mask, p, training):
     """Scaled-dot-product attention out of packed projection buffers (see attention_scores / attention_apply for the
     layouts); `mask`: optional uint8 key-padding mask [nbatch, S]."""

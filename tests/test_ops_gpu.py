@@ -484,3 +484,100 @@ def test_episode_batched_conv(ops):
             out = [F.conv2d(x[e * per:(e + 1) * per].permute(0, 3, 1, 2), w[e], None, stride, pad, dil) for e in range(E)]
             return torch.cat(out).permute(0, 2, 3, 1)
         check_op(lambda x, w: ops.conv2d_nhwc(x, w, stride, pad, dil), ref, [x, w], name="batched conv k%d s%d d%d" % (k, stride, dil))
+
+
+# ---- flash-style attention (csrc/flash.hip) ---------------------------------------------------------------------------
+def _ref_attention(q, k, v, H, scale, mask):
+    n, L, E = q.shape
+    S, hd = k.shape[1], E // H
+    qh, kh, vh = (t.double().view(n, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ vh).transpose(1, 2).reshape(n, L, E), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("n,H,L,S,hd,masked", [(2, 8, 361, 361, 32, True), (2, 8, 50, 361, 32, True), (1, 8, 300, 300, 64, False),
+                                                (2, 8, 50, 50, 32, False), (1, 2, 517, 2060, 64, False), (3, 4, 37, 130, 64, True)])
+def test_flash_forward_against_float64(ops, n, H, L, S, hd, masked):
+    E = H * hd
+    q, k, v = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
+    q[0, 0] *= 6.0   # one sharply peaked row
+    mask = None
+    if masked:
+        mask = torch.zeros(n, S, dtype=torch.uint8)
+        mask[0, S - 7:] = 1
+        mask[-1, 3:9] = 1
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    out, lse, _ = ops.flash_forward(q.cuda(), k.cuda(), v.cuda(), g, mask.cuda() if masked else None, 0.0, 0)
+    ref, ref_lse = _ref_attention(q, k, v, H, scale, mask)
+    close(out, ref, 2e-5, "flash forward")
+    close(lse.view(n, H, -1)[:, :, :L], ref_lse, 2e-6, "flash lse")
+
+
+def _ref_attention_drop(q, k, v, H, scale, mask, drop):
+    """float64 attention with an explicit dropout mask tensor [n*H, L, S] (values 1/keep or 0)."""
+    n, L, E = q.shape
+    S, hd = k.shape[1], E // H
+    qh, kh, vh = (t.view(n, -1, H, hd).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * scale
+    if mask is not None:
+        s = s.masked_fill(mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    if drop is not None:
+        p = p * drop.view(n, H, L, S)
+    return (p @ vh).transpose(1, 2).reshape(n, L, E)
+
+
+@pytest.mark.parametrize("n,H,L,S,hd,masked,pdrop", [(2, 8, 50, 361, 32, True, 0.0), (1, 4, 200, 200, 64, False, 0.0),
+                                                      (2, 2, 70, 130, 32, True, 0.1), (1, 2, 300, 517, 64, False, 0.1),
+                                                      (2, 4, 130, 37, 64, True, 0.25)])
+def test_flash_attention_first_order_against_float64(ops, n, H, L, S, hd, masked, pdrop):
+    """Forward and backward of the flash node against float64 autograd of the plain formula, with the kernels' own
+    dropout mask (ix_flash_dropmask_f32) applied as a tensor on the reference side."""
+    E = H * hd
+    q, k, v = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
+    mask = None
+    if masked:
+        mask = torch.zeros(n, S, dtype=torch.uint8)
+        mask[0, S - 7:] = 1
+        mask[-1, 3:9] = 1
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    seed = 0x1234567
+    drop = ops.flash_dropmask(n * H, L, S, pdrop, seed).cpu().double() if pdrop > 0 else None
+    if drop is not None:
+        share = float((drop == 0).double().mean())
+        assert abs(share - pdrop) < 0.02, share
+    xh = [t.cuda().requires_grad_(True) for t in (q, k, v)]
+    xr = [t.double().requires_grad_(True) for t in (q, k, v)]
+    oh = ops.FlashAttention.apply(xh[0], xh[1], xh[2], g, mask.cuda() if masked else None, pdrop, seed)
+    orf = _ref_attention_drop(xr[0], xr[1], xr[2], H, scale, mask, drop)
+    close(oh, orf, 2e-5, "flash forward")
+    gy = rnd(n, L, E, seed=5)
+    gh = torch.autograd.grad(oh, xh, gy.cuda())
+    gr = torch.autograd.grad(orf, xr, gy.double())
+    for name, a, b in zip("qkv", gh, gr):
+        close(a, b, 3e-5, "flash grad " + name)
+
+
+def test_flash_attention_packed_qk_buffer(ops):
+    """q and k read out of one [n, L, 2E] projection buffer (nn.MultiheadAttention self-attention with q = k input):
+    the gradient comes back as ONE buffer of that shape."""
+    n, H, L, hd = 2, 8, 77, 32
+    E = H * hd
+    qk, v = rnd(n, L, 2 * E, seed=1), rnd(n, L, E, seed=2)
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, L, hd, 2 * E, 2 * E, 0, E, E, 0, scale)
+    qkh, vh = qk.cuda().requires_grad_(True), v.cuda().requires_grad_(True)
+    out = ops.FlashAttention.apply(qkh, qkh, vh, g, None, 0.0, 0)
+    qkr, vr = qk.double().requires_grad_(True), v.double().requires_grad_(True)
+    ref = _ref_attention_drop(qkr[..., :E], qkr[..., E:], vr, H, scale, None, None)
+    close(out, ref, 2e-5, "packed forward")
+    gy = rnd(n, L, E, seed=9)
+    gh = torch.autograd.grad(out, [qkh, vh], gy.cuda())
+    gr = torch.autograd.grad(ref, [qkr, vr], gy.double())
+    close(gh[0], gr[0], 3e-5, "packed grad qk")
+    close(gh[1], gr[1], 3e-5, "packed grad v")
