@@ -163,6 +163,17 @@ int ix_flash_bwd_f32(const void* q_row, const void* q_tr, const void* do_row, co
                      int64_t ld_k, int off_k, int64_t ld_v, int off_v, float scale, float p_drop, uint64_t seed,
                      ix_stream_t stream);
 int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
+/* ix_flash_bwd_bwd_f32: double backward -- gradients (dq, dk, dv, ddo) of sum(hq.gq + hk.gk + hv.gv) w.r.t. (q, k, v, dO)
+ *   for the cotangents (hq, hk, hv) of ix_flash_bwd_f32's outputs.  `planes` is a HOST array of 14 device pointers to the
+ *   operand planes written by ix_attn_split_f32, in the order
+ *       q_row q_tr hq_row hq_tr do_row do_tr | k_row k_tr hk_row hk_tr v_row v_tr hv_row hv_tr.
+ *   Outputs in the operands' layouts: dq [n][L][ld_q] at off_q + h*hd, dk / dv [n][S][..], ddo [n][L][ld_do].
+ *   `workspace` (device, caller-owned): ix_workspace_bytes_flash_bwd_bwd(n, H, L) bytes for the per-row statistics. */
+int ix_flash_bwd_bwd_f32(const void* const* planes, const float* bias, const float* lse, const float* delta, float* dq,
+                         float* dk, float* dv, float* ddo, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_q,
+                         int off_q, int64_t ld_k, int off_k, int64_t ld_v, int off_v, int64_t ld_do, int off_do, float scale,
+                         float p_drop, uint64_t seed, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out_host);
 
 /* ---- set criterion ---------------------------------------------------------------------------------------
  * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the

@@ -25,6 +25,7 @@
 //   tr  layout  [plane][batch*head][hd][Rp]   bf16   rows permuted within 16-groups             (contraction over rows)
 //   Rp = R rounded up to 128 (zero rows); keys are walked in tiles of 32 up to ceil(S / 32) * 32.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -836,5 +837,462 @@ extern "C" int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_dro
     hipLaunchKernelGGL(flash_dropmask_kernel, dim3(ix_div_up(S, 256), L, BH), dim3(256), 0, stream, m, L, S, thr16, inv_keep,
                        (unsigned)seed, (unsigned)(seed >> 32));
     IX_CHECK_LAUNCH("ix_flash_dropmask_f32");
+    return IX_OK;
+}
+
+// ============================================================================================================
+// Double backward: the backward above as a function (q, k, v, dO) -> (gQ, gK, gV), differentiated once more.  With
+// cotangents (hq, hk, hv) of (gQ, gK, gV), scale c, and P, M, gy, t, gs as above:
+//     G  = c (hq k^T + q hk^T)            = dL/d gs                HD = dO hv^T             = dL/d Pd
+//     u_i = sum_j P_ij G_ij               HgD = M o P o (G - u)    = dL/d gd
+//     HY = G (gy - t) - gy u + M o HD     w_i = sum_j P_ij HY_ij   HS = P o (HY - w)        = dL/d S
+//     dq = c (gs hk + HS k)     dk = c (gs^T hq + HS^T q)     dv = HgD^T dO     ddO = Pd hv + HgD v
+// Three passes, all recomputing the [L, S] tiles from the operand planes: (1) query-owning, row statistics
+//     u_i,  w_i = sum_j P G gy - 2 t u + sum_j Pd HD        (HY is linear in u, sum_j P gy = t)
+// (2) query-owning, dq and ddO;  (3) key-owning, dk and dv.
+// ============================================================================================================
+struct FlashBBArgs {
+    const unsigned short *q_row, *q_tr, *hq_row, *hq_tr, *do_row, *do_tr;                    // query side
+    const unsigned short *k_row, *k_tr, *hk_row, *hk_tr, *v_row, *v_tr, *hv_row, *hv_tr;    // key side
+    const float *bias, *lse, *delta;   // [n][Sp], [BH][Lp], [BH][Lp]
+    float *u, *w;                      // [BH][Lp] each (workspace)
+    float *dq, *ddo, *dk, *dv;
+    int64_t ld_q, ld_k, ld_v, ld_do;
+    int off_q, off_k, off_v, off_do;
+    int H, L, Lp, S, Sp;
+    int64_t q_plane, k_plane;
+    float scale, scale_log2e;
+    unsigned thr16;
+    float inv_keep;
+    unsigned seed_lo, seed_hi;
+};
+
+#define FL_ROWFRAG(DST, BASE, OFF, ROWIDX, KS)                                                                         \
+    _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) DST[pl_] = *reinterpret_cast<const u32x4*>(                    \
+        (BASE) + (OFF) + pl_ * G::RPLANE + (ROWIDX) * G::RROW + ((KS) * 16 + 8 * a) * 2);
+#define FL_SPLIT16(PLANES, X)                                                                                          \
+    _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {              \
+        unsigned hh_, mm_, ll_;                                                                                        \
+        fl_split3(X[8 * s2_ + 2 * j_], X[8 * s2_ + 2 * j_ + 1], hh_, mm_, ll_);                                        \
+        PLANES[s2_][0][j_] = hh_; PLANES[s2_][1][j_] = mm_; PLANES[s2_][2][j_] = ll_;                                  \
+    }
+// ACC[db] += X^T[d, row] . PLANES[row, col]   for the tr segment at OFF
+#define FL_STAGE2(ACC, BASE, OFF, ROWIDX, PLANES)                                                                      \
+    _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_) _Pragma("unroll") for (int db_ = 0; db_ < NDB; ++db_) {         \
+        u32x4 tf_[3];                                                                                                  \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) tf_[pl_] = *reinterpret_cast<const u32x4*>(                \
+            (BASE) + (OFF) + pl_ * G::TPLANE + (db_ * 32 + (ROWIDX)) * G::TROW + (s2_ * 16 + 8 * a) * 2);              \
+        FL_MMA6(ACC[db_], tf_, PLANES[s2_])                                                                            \
+    }
+// Staging registers as a compile-time list (no arrays: an indexed array of in-flight loads is easily demoted to scratch
+// memory or to an LDS copy by the compiler), visited with compile-time indices.
+template <int N>
+struct FlRegs {
+    uint4 v;
+    FlRegs<N - 1> r;
+};
+template <>
+struct FlRegs<0> {};
+template <int I, int N, class F>
+__device__ __forceinline__ void fl_each(FlRegs<N>& s, F&& f) {
+    f(std::integral_constant<int, I>(), s.v);
+    if constexpr (N > 1) fl_each<I + 1>(s.r, f);
+}
+// global -> staging registers -> LDS for the units FIRST .. FIRST + COUNT - 1 (unit = one plane of one segment = 4 HD
+// 16-byte chunks: one chunk per thread at HD 64, two units per pass at HD 32 -- an odd unit out is copied twice).
+// SRC / DST are expressions in seg_ (segment), pl_ (plane), c_ (chunk).
+#define FL_NREGS(COUNT) (HD == 64 ? (COUNT) : ((COUNT) + 1) / 2)
+#define FL_STAGE_LOAD(REGS, FIRST, COUNT, SRC)                                                                         \
+    fl_each<0>(REGS, [&](auto I_, uint4& v_) {                                                                          \
+        constexpr int i_ = decltype(I_)::value;                                                                        \
+        const int u_ = (FIRST) + (HD == 64 ? i_ : min(2 * i_ + (tid >> 7), (COUNT) - 1));                              \
+        const int c_ = HD == 64 ? tid : (tid & 127);                                                                   \
+        const int seg_ = u_ / 3, pl_ = u_ % 3;                                                                         \
+        v_ = *reinterpret_cast<const uint4*>(SRC);                                                                     \
+    });
+#define FL_STAGE_STORE(REGS, FIRST, COUNT, DST)                                                                        \
+    fl_each<0>(REGS, [&](auto I_, uint4& v_) {                                                                          \
+        constexpr int i_ = decltype(I_)::value;                                                                        \
+        const int u_ = (FIRST) + (HD == 64 ? i_ : min(2 * i_ + (tid >> 7), (COUNT) - 1));                              \
+        const int c_ = HD == 64 ? tid : (tid & 127);                                                                   \
+        const int seg_ = u_ / 3, pl_ = u_ % 3;                                                                         \
+        *reinterpret_cast<uint4*>(DST) = v_;                                                                           \
+    });
+
+// passes 1 and 2 (query-owning).
+// STATS (pass 1): only u, w are produced; four row segments, double-buffered LDS, one barrier per tile.
+// pass 2: row + tr segments fill the LDS once, so a tile is two phases around two barriers -- phase 1 forms the four
+// [key, query] tiles out of the ROW region while the next tile's rows are in flight, phase 2 runs the four output
+// products out of the TR region while the next tile's tr operands are in flight; each region is refilled right after
+// the barrier that ends its phase, from one shared set of staging registers.
+template <int HD, bool DROP, bool STATS>
+__global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashBBArgs p) {
+    constexpr int NKS = HD / 16, NDB = HD / 32;
+    typedef FlSeg<HD> G;
+    // row segments k, hk, v, hv; then (pass 2) tr segments hk, k, hv, v
+    constexpr int OFF_K = 0, OFF_HK = G::RBYTES, OFF_V = 2 * G::RBYTES, OFF_HV = 3 * G::RBYTES;
+    constexpr int OFF_HKT = 4 * G::RBYTES, OFF_KT = OFF_HKT + G::TBYTES, OFF_HVT = OFF_KT + G::TBYTES, OFF_VT = OFF_HVT + G::TBYTES;
+    constexpr int BYTES = STATS ? 4 * G::RBYTES : 4 * G::RBYTES + 4 * G::TBYTES;
+    constexpr int NBUF = STATS ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsq[NBUF][BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, a = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ntiles = (p.S + 31) / 32;
+    const int64_t kro = (int64_t)bh * p.Sp * HD, kto = (int64_t)bh * HD * p.Sp;
+    const float* bias = p.bias + (int64_t)b * p.Sp;
+
+    u32x4 qf[NKS][3], hqf[NKS][3], df[NKS][3];
+    {
+        const int64_t o = ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                qf[ks][pl] = *reinterpret_cast<const u32x4*>(p.q_row + o + pl * p.q_plane + ks * 16);
+                hqf[ks][pl] = *reinterpret_cast<const u32x4*>(p.hq_row + o + pl * p.q_plane + ks * 16);
+                df[ks][pl] = *reinterpret_cast<const u32x4*>(p.do_row + o + pl * p.q_plane + ks * 16);
+            }
+    }
+    const int64_t so = (int64_t)bh * p.Lp + q0 + lq;
+    const float lse2 = p.lse[so] * FL_LOG2E, dl = p.delta[so];
+    float uu = 0.f, ww = 0.f, aa = 0.f, bq = 0.f;
+    if (!STATS) { uu = p.u[so]; ww = p.w[so]; }
+    const unsigned rid = (unsigned)(bh * p.L + q0 + lq);
+    f32x16 dq[NDB], ddo[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[db][r] = 0.f; ddo[db][r] = 0.f; }
+
+    FlRegs<FL_NREGS(12)> sv;
+#define FLB_SRC(T0)                                                                                                    \
+    (seg_ == 0 ? p.k_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
+   : seg_ == 1 ? p.hk_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
+   : seg_ == 2 ? p.v_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
+   : seg_ == 3 ? p.hv_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
+   : seg_ == 4 ? p.hk_tr + kto + pl_ * p.k_plane + (T0) + G::tr_src(c_, p.Sp)                                          \
+   : seg_ == 5 ? p.k_tr + kto + pl_ * p.k_plane + (T0) + G::tr_src(c_, p.Sp)                                           \
+   : seg_ == 6 ? p.hv_tr + kto + pl_ * p.k_plane + (T0) + G::tr_src(c_, p.Sp)                                          \
+               : p.v_tr + kto + pl_ * p.k_plane + (T0) + G::tr_src(c_, p.Sp))
+#define FLB_DST(BUF)                                                                                                   \
+    (seg_ < 4 ? (BUF) + seg_ * G::RBYTES + pl_ * G::RPLANE + G::row_dst(c_)                                            \
+              : (BUF) + 4 * G::RBYTES + (seg_ - 4) * G::TBYTES + pl_ * G::TPLANE + G::tr_dst(c_))
+    FL_STAGE_LOAD(sv, 0, 12, FLB_SRC(0))
+    FL_STAGE_STORE(sv, 0, 12, FLB_DST(ldsq[0]))
+    if (!STATS) {
+        FL_STAGE_LOAD(sv, 12, 12, FLB_SRC(0))
+        FL_STAGE_STORE(sv, 12, 12, FLB_DST(ldsq[0]))
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        unsigned char* lds = ldsq[STATS ? (t & 1) : 0];
+        const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
+        f32x4 kb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kb[g] = *reinterpret_cast<const f32x4*>(bias + t0 + 8 * g + 4 * a);
+        FL_STAGE_LOAD(sv, 0, 12, FLB_SRC(tn))
+        // ---- the four [key, query] tiles ----
+        f32x16 s, gd, gg, hd_;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; gd[r] = 0.f; gg[r] = 0.f; hd_[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 kf[3], hkf[3], vf[3], hvf[3];
+            FL_ROWFRAG(kf, lds, OFF_K, lq, ks)
+            FL_ROWFRAG(hkf, lds, OFF_HK, lq, ks)
+            FL_ROWFRAG(vf, lds, OFF_V, lq, ks)
+            FL_ROWFRAG(hvf, lds, OFF_HV, lq, ks)
+            FL_MMA6(s, kf, qf[ks])
+            FL_MMA6(gd, vf, df[ks])
+            FL_MMA6(gg, kf, hqf[ks])
+            FL_MMA6(hd_, hvf, df[ks])
+            FL_MMA6(gg, hkf, qf[ks])
+        }
+        float pr[16], mk[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pr[r] = exp2f(s[r] * p.scale_log2e + kb[r >> 2][r & 3] - lse2);
+            mk[r] = 1.f;
+        }
+        if (DROP) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int key = t0 + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * a;
+                const unsigned hsh = fl_hash(p.seed_lo, p.seed_hi, rid, (unsigned)key >> 1);
+                mk[2 * i] = (hsh & 0xffffu) >= p.thr16 ? p.inv_keep : 0.f;
+                mk[2 * i + 1] = (hsh >> 16) >= p.thr16 ? p.inv_keep : 0.f;
+            }
+        }
+        if (STATS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float G_ = gg[r] * p.scale, gy = mk[r] * gd[r], pg = pr[r] * G_;
+                uu += pg;
+                aa += pg * gy;
+                bq += pr[r] * mk[r] * hd_[r];
+            }
+            FL_STAGE_STORE(sv, 0, 12, FLB_DST(ldsq[(t + 1) & 1]))
+            __syncthreads();
+        } else {
+            __syncthreads();   // (A) every wave has formed its tiles: the ROW region is free, the TR region is complete
+            FL_STAGE_STORE(sv, 0, 12, FLB_DST(lds))
+            FL_STAGE_LOAD(sv, 12, 12, FLB_SRC(tn))
+            float x[16];
+            u32x4 pp[2][3];
+            // gs = P (gy - t)                                   dq += hk^T gs
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = pr[r] * (mk[r] * gd[r] - dl);
+            FL_SPLIT16(pp, x)
+            FL_STAGE2(dq, lds, OFF_HKT, lq, pp)
+            // HS = P (G (gy - t) - gy u + M HD - w)             dq += k^T HS
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float G_ = gg[r] * p.scale, gy = mk[r] * gd[r];
+                x[r] = pr[r] * (G_ * (gy - dl) - gy * uu + mk[r] * hd_[r] - ww);
+            }
+            FL_SPLIT16(pp, x)
+            FL_STAGE2(dq, lds, OFF_KT, lq, pp)
+            // Pd = M P                                          ddO += hv^T Pd
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r];
+            FL_SPLIT16(pp, x)
+            FL_STAGE2(ddo, lds, OFF_HVT, lq, pp)
+            // HgD = M P (G - u)                                 ddO += v^T HgD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r] * (gg[r] * p.scale - uu);
+            FL_SPLIT16(pp, x)
+            FL_STAGE2(ddo, lds, OFF_VT, lq, pp)
+            __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
+            FL_STAGE_STORE(sv, 12, 12, FLB_DST(lds))
+        }
+    }
+#undef FLB_SRC
+#undef FLB_DST
+    const int q = q0 + lq;
+    if (STATS) {
+        uu += __shfl_xor(uu, 32, 64);
+        aa += __shfl_xor(aa, 32, 64);
+        bq += __shfl_xor(bq, 32, 64);
+        if (a == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
+            p.u[so] = uu;
+            p.w[so] = aa - 2.f * dl * uu + bq;
+        }
+        return;
+    }
+    if (q < p.L) {
+        float* d1 = p.dq + ((int64_t)b * p.L + q) * p.ld_q + p.off_q + h * HD + 4 * a;
+        float* d2 = p.ddo + ((int64_t)b * p.L + q) * p.ld_do + p.off_do + h * HD + 4 * a;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v.x = dq[db][4 * g] * p.scale; v.y = dq[db][4 * g + 1] * p.scale; v.z = dq[db][4 * g + 2] * p.scale; v.w = dq[db][4 * g + 3] * p.scale;
+                *reinterpret_cast<f32x4*>(d1 + db * 32 + 8 * g) = v;
+                v.x = ddo[db][4 * g]; v.y = ddo[db][4 * g + 1]; v.z = ddo[db][4 * g + 2]; v.w = ddo[db][4 * g + 3];
+                *reinterpret_cast<f32x4*>(d2 + db * 32 + 8 * g) = v;
+            }
+    }
+}
+
+// pass 3 (key-owning): dk, dv.  Tiles [query, key]: lane = key, registers = queries.  Same two-phase tile as pass 2.
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashBBArgs p) {
+    constexpr int NKS = HD / 16, NDB = HD / 32;
+    typedef FlSeg<HD> G;
+    // row segments q, hq, dO; tr segments hq, q, dO; statistics lse, delta, u, w [32] each (part of the TR phase)
+    constexpr int OFF_Q = 0, OFF_HQ = G::RBYTES, OFF_D = 2 * G::RBYTES;
+    constexpr int OFF_HQT = 3 * G::RBYTES, OFF_QT = OFF_HQT + G::TBYTES, OFF_DT = OFF_QT + G::TBYTES, OFF_ST = OFF_DT + G::TBYTES;
+    constexpr int BYTES = OFF_ST + 512;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lk = lane & 31, a = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int ntiles = (p.L + 31) / 32;
+    const int64_t qro = (int64_t)bh * p.Lp * HD, qto = (int64_t)bh * HD * p.Lp, sto = (int64_t)bh * p.Lp;
+
+    u32x4 kf[NKS][3], hkf[NKS][3], vf[NKS][3], hvf[NKS][3];
+    {
+        const int64_t o = ((int64_t)bh * p.Sp + k0 + lk) * HD + 8 * a;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                kf[ks][pl] = *reinterpret_cast<const u32x4*>(p.k_row + o + pl * p.k_plane + ks * 16);
+                hkf[ks][pl] = *reinterpret_cast<const u32x4*>(p.hk_row + o + pl * p.k_plane + ks * 16);
+                vf[ks][pl] = *reinterpret_cast<const u32x4*>(p.v_row + o + pl * p.k_plane + ks * 16);
+                hvf[ks][pl] = *reinterpret_cast<const u32x4*>(p.hv_row + o + pl * p.k_plane + ks * 16);
+            }
+    }
+    const float kbias = p.bias[(int64_t)b * p.Sp + k0 + lk];
+    const int key = k0 + lk;
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+    FlRegs<FL_NREGS(9)> sv;
+    float sst = 0.f;   // staged statistics: threads 0..127 carry lse | delta | u | w of the next tile
+#define FLC_SRC(T0)                                                                                                    \
+    (seg_ == 0 ? p.q_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
+   : seg_ == 1 ? p.hq_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
+   : seg_ == 2 ? p.do_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
+   : seg_ == 3 ? p.hq_tr + qto + pl_ * p.q_plane + (T0) + G::tr_src(c_, p.Lp)                                          \
+   : seg_ == 4 ? p.q_tr + qto + pl_ * p.q_plane + (T0) + G::tr_src(c_, p.Lp)                                           \
+               : p.do_tr + qto + pl_ * p.q_plane + (T0) + G::tr_src(c_, p.Lp))
+#define FLC_DST                                                                                                        \
+    (seg_ < 3 ? lds + seg_ * G::RBYTES + pl_ * G::RPLANE + G::row_dst(c_)                                              \
+              : lds + 3 * G::RBYTES + (seg_ - 3) * G::TBYTES + pl_ * G::TPLANE + G::tr_dst(c_))
+#define FLC_STAT_LOAD(T0)                                                                                              \
+    if (tid < 128) {                                                                                                   \
+        const float* sp_ = tid < 32 ? p.lse : tid < 64 ? p.delta : tid < 96 ? p.u : p.w;                               \
+        sst = sp_[sto + (T0) + (tid & 31)];                                                                            \
+    }
+    FL_STAGE_LOAD(sv, 0, 9, FLC_SRC(0))
+    FL_STAGE_STORE(sv, 0, 9, FLC_DST)
+    FL_STAGE_LOAD(sv, 9, 9, FLC_SRC(0))
+    FLC_STAT_LOAD(0)
+    FL_STAGE_STORE(sv, 9, 9, FLC_DST)
+    if (tid < 128) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
+        FL_STAGE_LOAD(sv, 0, 9, FLC_SRC(tn))
+        f32x16 s, gd, gg, hd_;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; gd[r] = 0.f; gg[r] = 0.f; hd_[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            u32x4 qa[3], hqa[3], da[3];
+            FL_ROWFRAG(qa, lds, OFF_Q, lk, ks)
+            FL_ROWFRAG(hqa, lds, OFF_HQ, lk, ks)
+            FL_ROWFRAG(da, lds, OFF_D, lk, ks)
+            FL_MMA6(s, qa, kf[ks])
+            FL_MMA6(gd, da, vf[ks])
+            FL_MMA6(gg, hqa, kf[ks])
+            FL_MMA6(hd_, da, hvf[ks])
+            FL_MMA6(gg, qa, hkf[ks])
+        }
+        __syncthreads();   // (A) the ROW region is free, the TR region (and the statistics) are complete
+        FL_STAGE_STORE(sv, 0, 9, FLC_DST)
+        FL_STAGE_LOAD(sv, 9, 9, FLC_SRC(tn))
+        FLC_STAT_LOAD(tn)
+        // statistics of this lane's 16 queries: register r <-> query t0 + (r & 3) + 8 (r >> 2) + 4 a; read per use
+#define FLC_ST(WHICH, R) (reinterpret_cast<const float*>(lds + OFF_ST + (WHICH) * 128)[((R) & 3) + 8 * ((R) >> 2) + 4 * a])
+        float pr[16], mk[16], x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pr[r] = exp2f(s[r] * p.scale_log2e + kbias - FLC_ST(0, r) * FL_LOG2E);
+            mk[r] = 1.f;
+            if (DROP) {
+                const int q = t0 + (r & 3) + 8 * (r >> 2) + 4 * a;
+                const unsigned hsh = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q), (unsigned)key >> 1);
+                mk[r] = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= p.thr16 ? p.inv_keep : 0.f;
+            }
+        }
+        u32x4 pp[2][3];
+        // gs                                                     dk += hq^T gs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = pr[r] * (mk[r] * gd[r] - FLC_ST(1, r));
+        FL_SPLIT16(pp, x)
+        FL_STAGE2(dk, lds, OFF_HQT, lk, pp)
+        // HS                                                     dk += q^T HS
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float G_ = gg[r] * p.scale, gy = mk[r] * gd[r];
+            x[r] = pr[r] * (G_ * (gy - FLC_ST(1, r)) - gy * FLC_ST(2, r) + mk[r] * hd_[r] - FLC_ST(3, r));
+        }
+        FL_SPLIT16(pp, x)
+        FL_STAGE2(dk, lds, OFF_QT, lk, pp)
+        // HgD                                                    dv += dO^T HgD
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r] * (gg[r] * p.scale - FLC_ST(2, r));
+        FL_SPLIT16(pp, x)
+        FL_STAGE2(dv, lds, OFF_DT, lk, pp)
+#undef FLC_ST
+        __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
+        FL_STAGE_STORE(sv, 9, 9, FLC_DST)
+        if (tid < 128) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
+    }
+#undef FLC_SRC
+#undef FLC_DST
+#undef FLC_STAT_LOAD
+    if (key < p.S) {
+        float* d1 = p.dk + ((int64_t)b * p.S + key) * p.ld_k + p.off_k + h * HD + 4 * a;
+        float* d2 = p.dv + ((int64_t)b * p.S + key) * p.ld_v + p.off_v + h * HD + 4 * a;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+                v.x = dk[db][4 * g] * p.scale; v.y = dk[db][4 * g + 1] * p.scale; v.z = dk[db][4 * g + 2] * p.scale; v.w = dk[db][4 * g + 3] * p.scale;
+                *reinterpret_cast<f32x4*>(d1 + db * 32 + 8 * g) = v;
+                v.x = dv[db][4 * g]; v.y = dv[db][4 * g + 1]; v.z = dv[db][4 * g + 2]; v.w = dv[db][4 * g + 3];
+                *reinterpret_cast<f32x4*>(d2 + db * 32 + 8 * g) = v;
+            }
+    }
+}
+
+// planes: HOST array of 14 device pointers in the order
+//   q_row q_tr hq_row hq_tr do_row do_tr | k_row k_tr hk_row hk_tr v_row v_tr hv_row hv_tr
+extern "C" int ix_flash_bwd_bwd_f32(const void* const* planes, const float* bias, const float* lse, const float* delta,
+                                    float* dq, float* dk, float* dv, float* ddo, int n, int H, int L, int Lp, int S, int Sp,
+                                    int hd, int64_t ld_q, int off_q, int64_t ld_k, int off_k, int64_t ld_v, int off_v,
+                                    int64_t ld_do, int off_do, float scale, float p_drop, uint64_t seed, void* workspace,
+                                    size_t workspace_bytes, hipStream_t stream) {
+    if (n <= 0 || L <= 0 || S <= 0) return IX_OK;
+    IX_CHECK_ARG(planes && bias && lse && delta && dq && dk && dv && ddo, "ix_flash_bwd_bwd_f32: null pointer");
+    for (int i = 0; i < 14; ++i) IX_CHECK_ARG(planes[i] != nullptr, "ix_flash_bwd_bwd_f32: operand plane %d is null", i);
+    IX_CHECK_ARG(hd == 32 || hd == 64, "ix_flash_bwd_bwd_f32: head dim %d (32 or 64)", hd);
+    IX_CHECK_ARG(Lp % 128 == 0 && Sp % 128 == 0 && Lp >= L && Sp >= S, "ix_flash_bwd_bwd_f32: bad padded sizes");
+    IX_CHECK_ARG(ld_q % 4 == 0 && ld_k % 4 == 0 && ld_v % 4 == 0 && ld_do % 4 == 0 && off_q % 4 == 0 && off_k % 4 == 0 &&
+                 off_v % 4 == 0 && off_do % 4 == 0, "ix_flash_bwd_bwd_f32: output rows must be 16-byte aligned");
+    IX_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ix_flash_bwd_bwd_f32: p=%f outside [0,1)", p_drop);
+    IX_CHECK_ARG((int64_t)n * H * L < ((int64_t)1 << 32) && n * H <= 65535, "ix_flash_bwd_bwd_f32: too many rows");
+    const size_t need = (size_t)2 * n * H * Lp * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        ix_set_error("ix_flash_bwd_bwd_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+        return IX_ERR_WORKSPACE;
+    }
+    FlashBBArgs a;
+    const unsigned short* const* pp = reinterpret_cast<const unsigned short* const*>(planes);
+    a.q_row = pp[0]; a.q_tr = pp[1]; a.hq_row = pp[2]; a.hq_tr = pp[3]; a.do_row = pp[4]; a.do_tr = pp[5];
+    a.k_row = pp[6]; a.k_tr = pp[7]; a.hk_row = pp[8]; a.hk_tr = pp[9]; a.v_row = pp[10]; a.v_tr = pp[11];
+    a.hv_row = pp[12]; a.hv_tr = pp[13];
+    a.bias = bias; a.lse = lse; a.delta = delta;
+    a.u = (float*)workspace; a.w = a.u + (size_t)n * H * Lp;
+    a.dq = dq; a.ddo = ddo; a.dk = dk; a.dv = dv;
+    a.ld_q = ld_q; a.ld_k = ld_k; a.ld_v = ld_v; a.ld_do = ld_do;
+    a.off_q = off_q; a.off_k = off_k; a.off_v = off_v; a.off_do = off_do;
+    a.H = H; a.L = L; a.Lp = Lp; a.S = S; a.Sp = Sp;
+    a.q_plane = (int64_t)n * H * Lp * hd; a.k_plane = (int64_t)n * H * Sp * hd;
+    a.scale = scale; a.scale_log2e = scale * FL_LOG2E;
+    a.thr16 = (unsigned)((double)p_drop * 65536.0 + 0.5);
+    a.inv_keep = a.thr16 ? 65536.f / (float)(65536u - a.thr16) : 1.f;
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    const dim3 gq((L + 127) / 128, n * H), gk((S + 127) / 128, n * H), blk(256);
+#define FL_BB_LAUNCH(HD_, DR_)                                                                         \
+    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true>), gq, blk, 0, stream, a);                    \
+    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false>), gq, blk, 0, stream, a);                   \
+    hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);
+    if (hd == 64) {
+        if (a.thr16) { FL_BB_LAUNCH(64, true) } else { FL_BB_LAUNCH(64, false) }
+    } else {
+        if (a.thr16) { FL_BB_LAUNCH(32, true) } else { FL_BB_LAUNCH(32, false) }
+    }
+#undef FL_BB_LAUNCH
+    IX_CHECK_LAUNCH("ix_flash_bwd_bwd_f32");
+    return IX_OK;
+}
+
+extern "C" int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out) {
+    IX_CHECK_ARG(out && n >= 0 && H >= 0 && L >= 0, "ix_workspace_bytes_flash_bwd_bwd: bad args");
+    *out = (size_t)2 * n * H * ((L + 127) / 128 * 128) * sizeof(float);
     return IX_OK;
 }

@@ -411,6 +411,12 @@ class AttentionCoreBwd(Function):
 # ---------------------------------------------------------------------------------------------------------
 # flash-style attention core (csrc/flash.hip): no [L, S] tensor in HBM
 # ---------------------------------------------------------------------------------------------------------
+# "flash": csrc/flash.hip (no [L, S] tensor in HBM; head dims 32 / 64); "materialised": the AttentionCore node above (scores
+# and probabilities as [n, H, L, S] tensors).  IX_ATTENTION in the environment overrides the default (A/B runs).
+import os as _os
+ATTENTION_IMPL = _os.environ.get("IX_ATTENTION", "flash")
+
+
 def _pad128(R):
     return (R + 127) // 128 * 128
 
@@ -520,7 +526,38 @@ class FlashAttentionBwd(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, hq, hk, hv):
-        raise NotImplementedError("flash attention double backward")
+        """Double backward: (dq, dk, dv, ddO) for the cotangents of (gq, gk, gv); three passes of csrc/flash.hip."""
+        q, k, v, out, lse, do = ctx.saved_tensors
+        g, pl, dev = ctx.g, ctx.pl, q.device
+        Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
+        zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)
+        hq = _req(hq.contiguous()) if hq is not None else zeros(q)
+        if ctx.same_qk:
+            hk = hq          # one cotangent buffer [q | k] for the packed gradient buffer
+        else:
+            hk = _req(hk.contiguous()) if hk is not None else zeros(k)
+        hv = _req(hv.contiguous()) if hv is not None else zeros(v)
+        hqr, hqt = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
+        hkr, hkt = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
+        hvr, hvt = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
+        order = [pl["qr"], pl["qt"], hqr, hqt, pl["dor"], pl["dot"], pl["kr"], pl["kt"], hkr, hkt, pl["vr"], pl["vt"], hvr, hvt]
+        planes = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in order])
+        full = lambda ld, off: ld == E and off == 0
+        packed = ctx.same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]
+        dq = (torch.empty if packed or full(g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
+        dk = dq if ctx.same_qk else (torch.empty if full(g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
+        dv = (torch.empty if full(g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
+        ddo = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
+        need = ctypes.c_size_t()
+        _chk(_L().ix_workspace_bytes_flash_bwd_bwd(g.n, g.heads, g.L, ctypes.byref(need)), "ix_workspace_bytes_flash_bwd_bwd")
+        ws = torch.empty(need.value // 4, dtype=torch.float32, device=dev)
+        _chk(_L().ix_flash_bwd_bwd_f32(planes, pl["bias"].data_ptr(), lse.data_ptr(), pl["delta"].data_ptr(), dq.data_ptr(),
+                                       dk.data_ptr(), dv.data_ptr(), ddo.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp, g.hd,
+                                       g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, E, 0, g.scale, ctx.p, ctx.seed,
+                                       ws.data_ptr(), need.value, _stream()), "ix_flash_bwd_bwd_f32")
+        need_in = ctx.needs_input_grad
+        return (dq if need_in[0] else None, (None if ctx.same_qk else dk) if need_in[1] else None, dv if need_in[2] else None,
+                None, None, ddo if need_in[5] else None, None, None, None, None, None)
 
 
 def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, scale, mask, p, training):
@@ -528,7 +565,10 @@ def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, 
     layouts); `mask`: optional uint8 key-padding mask [nbatch, S]."""
     p = float(p) if training else 0.0
     g = AttnGeom(nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, v_off, float(scale))
-    return AttentionCore.call(q, k, v, g, mask, p, _next_seed() if p > 0.0 else 0)
+    seed = _next_seed() if p > 0.0 else 0
+    if ATTENTION_IMPL == "flash" and flash_supported(g):
+        return FlashAttention.call(q, k, v, g, mask, p, seed)
+    return AttentionCore.call(q, k, v, g, mask, p, seed)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -581,3 +581,60 @@ def test_flash_attention_packed_qk_buffer(ops):
     gr = torch.autograd.grad(ref, [qkr, vr], gy.double())
     close(gh[0], gr[0], 3e-5, "packed grad qk")
     close(gh[1], gr[1], 3e-5, "packed grad v")
+
+
+@pytest.mark.parametrize("n,H,L,S,hd,masked,pdrop", [(2, 4, 50, 90, 32, True, 0.0), (1, 2, 150, 150, 64, False, 0.0),
+                                                      (2, 2, 70, 130, 32, True, 0.1), (1, 2, 130, 200, 64, False, 0.1)])
+def test_flash_attention_second_order_against_float64(ops, n, H, L, S, hd, masked, pdrop):
+    """The double backward of the flash node (three recompute passes) against float64 autograd: gradients of a random
+    functional of (gq, gk, gv) with respect to q, k, v AND the incoming dO."""
+    E = H * hd
+    q, k, v = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
+    mask = None
+    if masked:
+        mask = torch.zeros(n, S, dtype=torch.uint8)
+        mask[0, S - 7:] = 1
+        mask[-1, 3:9] = 1
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    seed = 0x7654321
+    drop = ops.flash_dropmask(n * H, L, S, pdrop, seed).cpu().double() if pdrop > 0 else None
+    gy = rnd(n, L, E, seed=5)
+    ws = [rnd(n, L, E, seed=6), rnd(n, S, E, seed=7), rnd(n, S, E, seed=8)]
+
+    def second(dev, dt, fn):
+        x = [t.to(dev, dt).requires_grad_(True) for t in (q, k, v)]
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        out = fn(*x)
+        g1 = torch.autograd.grad(out, x, gyd, create_graph=True)
+        s = sum((a * w.to(dev, dt)).sum() for a, w in zip(g1, ws))
+        return g1, torch.autograd.grad(s, x + [gyd])
+
+    g1h, g2h = second("cuda", torch.float32,
+                      lambda a, b, c: ops.FlashAttention.apply(a, b, c, g, mask.cuda() if masked else None, pdrop, seed))
+    g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, mask, drop))
+    for name, a, b in zip("qkv", g1h, g1r):
+        close(a, b, 3e-5, "flash grad " + name)
+    for name, a, b in zip(["q", "k", "v", "dO"], g2h, g2r):
+        close(a, b, 6e-5, "flash second-order " + name)
+
+
+def test_flash_attention_second_order_packed_qk(ops):
+    n, H, L, hd = 2, 4, 77, 32
+    E = H * hd
+    qk, v = rnd(n, L, 2 * E, seed=1), rnd(n, L, E, seed=2)
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, L, hd, 2 * E, 2 * E, 0, E, E, 0, scale)
+    gy, w1, w2 = rnd(n, L, E, seed=9), rnd(n, L, 2 * E, seed=10), rnd(n, L, E, seed=11)
+
+    def second(dev, dt, fn):
+        a, b = qk.to(dev, dt).requires_grad_(True), v.to(dev, dt).requires_grad_(True)
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        g1 = torch.autograd.grad(fn(a, b), [a, b], gyd, create_graph=True)
+        s = (g1[0] * w1.to(dev, dt)).sum() + (g1[1] * w2.to(dev, dt)).sum()
+        return torch.autograd.grad(s, [a, b, gyd])
+
+    gh = second("cuda", torch.float32, lambda a, b: ops.FlashAttention.apply(a, a, b, g, None, 0.0, 0))
+    gr = second("cpu", torch.float64, lambda a, b: _ref_attention_drop(a[..., :E], a[..., E:], b, H, scale, None, None))
+    for name, a, b in zip(["qk", "v", "dO"], gh, gr):
+        close(a, b, 6e-5, "packed second-order " + name)
