@@ -129,51 +129,58 @@ int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, 
                              float* grad_gamma, int64_t rows, int D, int groups, ix_stream_t stream);
 
 /* ---- flash-style attention (no [L, S] tensor in HBM) ------------------------------------------------------------
- * O = dropout(softmax(scale Q K^T + key bias)) V per (batch, head), and its first and second derivative, with the
- * bf16x6 arithmetic of ix_gemm_f32 (fp32 operands split exactly into three bf16 planes, six MFMA terms per product).
+ * O = dropout(softmax(scale Q K^T + key bias)) V per (batch, head), and its first and second derivative, in fp32-grade
+ * arithmetic on the 16-bit matrix cores (exact operand splits: two fp16 planes with a per-32-row power-of-two scale for
+ * the products that contract over the head dim, three bf16 planes for the products that contract over tokens).
  * Replaces the same reference lines as the ix_attn_prob_* family: `att = softmax(q k^T / sqrt(hd)); att = drop(att);
  * y = att v` of models/gpt.py:39-57 and nn.MultiheadAttention's core in models/detr_models/transformer.py:148-161,
  * 211-232, plus autograd's first / second derivative of them (models/interactron.py:99-123).
  *
- * ix_attn_split_f32: fp32 activations x [n][R][ld] (head h = columns off + h*hd .. + hd) -> bf16 planes (h, m, l) in
- *   row layout  row_planes [3][n*H][Rp][hd]   (operand of products that contract over d) and / or
- *   tr  layout  tr_planes  [3][n*H][hd][Rp]   (operand of products that contract over rows; rows permuted within
- *   16-groups to the MFMA accumulator order).  Rp = R rounded up to 128, padded rows are zero.  Either output may be null.
+ * ix_attn_split_f32: fp32 activations x [n][R][ld] (head h = columns off + h*hd .. + hd) ->
+ *   row_planes  [2][n*H][Rp][hd] fp16 (h, l of x * 2^e) + row_unscale [n*H][Rp/32] f32 (2^-e per block of 32 rows), and/or
+ *   tr_planes   [3][n*H][hd][Rp] bf16 (h, m, l; rows permuted within 16-groups to the MFMA accumulator order).
+ *   Rp = R rounded up to 128, padded rows are zero.  row_planes + row_unscale, or tr_planes, may be null.
+ * struct ix_attn_planes: the three pointers of one operand, as the entry points below take them (members an entry
+ *   point does not read may be null: forward reads q.row, k.row, v.tr).
  * ix_attn_bias_f32: key_padding_mask uint8 [n][mask_ld] (nonzero = ignore; null = none) -> additive bias [n][Sb],
  *   Sb >= S (the kernels want S rounded up to 128): 0 for valid keys, -inf for masked keys and the tail.
- * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers).
- *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key). */
-int ix_attn_split_f32(const float* x, void* row_planes, void* tr_planes, int n, int R, int Rp, int64_t ld, int off, int H,
-                      int hd, ix_stream_t stream);
-int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, int Sb, int64_t mask_ld, ix_stream_t stream);
-int ix_flash_fwd_f32(const void* q_row, const void* k_row, const void* v_tr, const float* bias, float* out, float* lse,
-                     int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_out, int off_out, float scale,
-                     float p_drop, uint64_t seed, ix_stream_t stream);
-
-/* ix_attn_rowdot_f32: t[bh][q] = sum_d a[q, h, d] b[q, h, d] over heads of two [n][L][ld] activations (delta = dO . O).
- * ix_flash_bwd_f32: (gq, gk, gv) of the attention core from (q, k, v, dO) planes + lse + delta; probabilities are
- *   recomputed tile by tile.  gq (may be null) is written by query-owning workgroups, gk + gv (both or neither) by
- *   key-owning ones; outputs are [n][L|S][ld_*] with head h at off_* + h*hd (so gq and gk may share one packed buffer).
+ * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; the
+ *   caller pre-fills +inf so that padded query rows count as P = 0 in the derivative kernels).
+ *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key).
+ * ix_attn_rowdot_f32: t[bh][q] = sum_d a[q, h, d] b[q, h, d] over heads of two [n][L][ld] activations (delta = dO . O).
+ * ix_flash_bwd_f32: (gq, gk, gv) from the planes of (q, k, v, dO) + lse + delta; probabilities are recomputed tile by
+ *   tile.  gq (may be null) is written by query-owning workgroups, gk + gv (both or neither) by key-owning ones; outputs
+ *   are [n][L|S][ld_*] with head h at off_* + h*hd (so gq and gk may share one packed buffer).
+ * ix_flash_bwd_bwd_f32: double backward -- gradients (dq, dk, dv, ddo) of sum(hq.gq + hk.gk + hv.gv) w.r.t. (q, k, v, dO)
+ *   for the cotangents (hq, hk, hv) of ix_flash_bwd_f32's outputs (all seven operands need row + tr planes).
+ *   `workspace` (device, caller-owned): ix_workspace_bytes_flash_bwd_bwd(n, H, L) bytes for the per-row statistics.
  * ix_flash_dropmask_f32: the kernels' dropout mask as a tensor m[BH][L][S] (1/keep or 0) -- tests only. */
+struct ix_attn_planes {
+    const void* row;
+    const float* unscale;
+    const void* tr;
+};
+int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int n, int R, int Rp, int64_t ld,
+                      int off, int H, int hd, ix_stream_t stream);
+int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, int Sb, int64_t mask_ld, ix_stream_t stream);
+int ix_flash_fwd_f32(const struct ix_attn_planes* q, const struct ix_attn_planes* k, const struct ix_attn_planes* v,
+                     const float* bias, float* out, float* lse, int n, int H, int L, int Lp, int S, int Sp, int hd,
+                     int64_t ld_out, int off_out, float scale, float p_drop, uint64_t seed, ix_stream_t stream);
 int ix_attn_rowdot_f32(const float* a, const float* b, float* t, int n, int H, int L, int Lp, int hd, int64_t lda, int offa,
                        int64_t ldb, int offb, ix_stream_t stream);
-int ix_flash_bwd_f32(const void* q_row, const void* q_tr, const void* do_row, const void* do_tr, const void* k_row,
-                     const void* k_tr, const void* v_row, const float* bias, const float* lse, const float* delta, float* gq,
+int ix_flash_bwd_f32(const struct ix_attn_planes* q, const struct ix_attn_planes* k, const struct ix_attn_planes* v,
+                     const struct ix_attn_planes* d_out, const float* bias, const float* lse, const float* delta, float* gq,
                      float* gk, float* gv, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_q, int off_q,
                      int64_t ld_k, int off_k, int64_t ld_v, int off_v, float scale, float p_drop, uint64_t seed,
                      ix_stream_t stream);
-int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
-/* ix_flash_bwd_bwd_f32: double backward -- gradients (dq, dk, dv, ddo) of sum(hq.gq + hk.gk + hv.gv) w.r.t. (q, k, v, dO)
- *   for the cotangents (hq, hk, hv) of ix_flash_bwd_f32's outputs.  `planes` is a HOST array of 14 device pointers to the
- *   operand planes written by ix_attn_split_f32, in the order
- *       q_row q_tr hq_row hq_tr do_row do_tr | k_row k_tr hk_row hk_tr v_row v_tr hv_row hv_tr.
- *   Outputs in the operands' layouts: dq [n][L][ld_q] at off_q + h*hd, dk / dv [n][S][..], ddo [n][L][ld_do].
- *   `workspace` (device, caller-owned): ix_workspace_bytes_flash_bwd_bwd(n, H, L) bytes for the per-row statistics. */
-int ix_flash_bwd_bwd_f32(const void* const* planes, const float* bias, const float* lse, const float* delta, float* dq,
+int ix_flash_bwd_bwd_f32(const struct ix_attn_planes* q, const struct ix_attn_planes* k, const struct ix_attn_planes* v,
+                         const struct ix_attn_planes* d_out, const struct ix_attn_planes* hq, const struct ix_attn_planes* hk,
+                         const struct ix_attn_planes* hv, const float* bias, const float* lse, const float* delta, float* dq,
                          float* dk, float* dv, float* ddo, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_q,
                          int off_q, int64_t ld_k, int off_k, int64_t ld_v, int off_v, int64_t ld_do, int off_do, float scale,
                          float p_drop, uint64_t seed, void* workspace, size_t workspace_bytes, ix_stream_t stream);
 int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out_host);
+int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
 
 /* ---- set criterion ---------------------------------------------------------------------------------------
  * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the

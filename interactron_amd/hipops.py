@@ -421,17 +421,32 @@ def _pad128(R):
     return (R + 127) // 128 * 128
 
 
+class _PlanesC(ctypes.Structure):   # struct ix_attn_planes of include/interactron_hip.h
+    _fields_ = [("row", ctypes.c_void_p), ("unscale", ctypes.c_void_p), ("tr", ctypes.c_void_p)]
+
+
+class AttnPlanes:
+    """One attention operand as the flash kernels read it: fp16 row planes [2][n*H][Rp][hd] with their block unscale factors
+    [n*H][Rp/32], and bf16 tr planes [3][n*H][hd][Rp] (csrc/flash.hip); ``ref`` is the C view handed to the library."""
+
+    def __init__(self, row, unscale, tr):
+        self.row, self.unscale, self.tr = row, unscale, tr
+        self.c = _PlanesC(row.data_ptr() if row is not None else None, unscale.data_ptr() if unscale is not None else None,
+                          tr.data_ptr() if tr is not None else None)
+        self.ref = ctypes.byref(self.c)
+
+
 def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True):
-    """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> (row planes, tr planes): flat bf16 tensors
-    [3][n*H][Rp][hd] / [3][n*H][hd][Rp] (see csrc/flash.hip), Rp = R rounded up to 128."""
+    """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> AttnPlanes (Rp = R rounded up to 128)."""
     x = _req(x, "attention operand")
     Rp = _pad128(R)
-    numel = 3 * n * H * Rp * hd
-    rowp = torch.empty(numel, dtype=torch.bfloat16, device=x.device) if row else None
-    trp = torch.empty(numel, dtype=torch.bfloat16, device=x.device) if tr else None
-    _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, trp.data_ptr() if tr else None, n, R, Rp, ld,
-                                off, H, hd, _stream()), "ix_attn_split_f32")
-    return rowp, trp
+    dev = x.device
+    rowp = torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if row else None
+    us = torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=dev) if row else None
+    trp = torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev) if tr else None
+    _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if row else None,
+                                trp.data_ptr() if tr else None, n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_f32")
+    return AttnPlanes(rowp, us, trp)
 
 
 def attn_bias(mask, n, S, device):
@@ -450,20 +465,18 @@ def flash_dropmask(BH, L, S, p, seed, device="cuda"):
     return m
 
 
-def flash_forward(q, k, v, g, mask, p, seed):
+def flash_forward(q, k, v, g, mask, p, seed, need_backward=True):
     """-> (out [n, L, H*hd], lse [n*H, Lp] (+inf beyond L), operand planes) for geometry g (AttnGeom)."""
     dev = q.device
-    pl = {}
-    pl["qr"], pl["qt"] = attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
-    pl["kr"], pl["kt"] = attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
-    pl["vr"], pl["vt"] = attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
-    pl["bias"] = attn_bias(mask, g.n, g.S, dev)
+    pl = {"q": attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr=need_backward),
+          "k": attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr=need_backward),
+          "v": attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=need_backward),
+          "bias": attn_bias(mask, g.n, g.S, dev)}
     Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
     out = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
     lse = torch.full((g.n * g.heads, Lp), float("inf"), dtype=torch.float32, device=dev)   # +inf: P = 0 for padded queries
-    _chk(_L().ix_flash_fwd_f32(pl["qr"].data_ptr(), pl["kr"].data_ptr(), pl["vt"].data_ptr(), pl["bias"].data_ptr(),
-                               out.data_ptr(), lse.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed,
-                               _stream()), "ix_flash_fwd_f32")
+    _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(),
+                               g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_f32")
     return out, lse, pl
 
 
@@ -474,12 +487,12 @@ def flash_supported(g):
 
 class FlashAttention(Function):
     """out[b,l,h*hd+:] = dropout(softmax(scale q k^T [+ key mask])) v per (batch, head) without [L, S] tensors in HBM
-    (csrc/flash.hip).  Saves q, k, v, out, the row normalisers and the bf16 operand planes."""
+    (csrc/flash.hip).  Saves q, k, v, out, the row normalisers and the 16-bit operand planes."""
 
     @staticmethod
     def forward(ctx, q, k, v, g, mask, p, seed):
         q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
-        out, lse, pl = flash_forward(q, k, v, g, mask, p, seed)
+        out, lse, pl = flash_forward(q, k, v, g, mask, p, seed, need_backward=not isinstance(ctx, _NullCtx))
         ctx.g, ctx.p, ctx.seed, ctx.pl = g, p, seed, pl
         ctx.same_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape   # packed [q | k] projection buffer
         ctx.save_for_backward(q, k, v, out, lse)
@@ -492,6 +505,17 @@ class FlashAttention(Function):
         return gq, gk, gv, None, None, None, None
 
 
+def _grad_buffers(g, q, k, v, same_qk):
+    """Gradient buffers in the operands' own (packed) layouts; columns that belong to other tensors stay zero."""
+    E, dev = g.heads * g.hd, q.device
+    full = lambda ld, off: ld == E and off == 0
+    packed = same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]   # [q | k] buffer: fully covered
+    gq = (torch.empty if packed or full(g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
+    gk = gq if same_qk else (torch.empty if full(g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
+    gv = (torch.empty if full(g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
+    return gq, gk, gv
+
+
 class FlashAttentionBwd(Function):
     """(gq, gk, gv) of FlashAttention; gq / gk come back in the layout of the packed q / k projection buffers (one shared
     buffer when q and k are the same tensor: autograd then has nothing to add)."""
@@ -501,23 +525,17 @@ class FlashAttentionBwd(Function):
         do = _req(do.contiguous(), "attention dO")
         dev = q.device
         Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
-        dor, dot = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd)
+        dop = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd)
         delta = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)
         _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
                                      _stream()), "ix_attn_rowdot_f32")
-        # gradient buffers in the operands' own (packed) layouts; columns of other heads' / other tensors stay zero
-        full = lambda t, ld, off: ld == E and off == 0
-        packed = same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]   # [q | k] buffer: fully covered
-        gq = (torch.empty if packed or full(q, g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
-        gk = gq if same_qk else (torch.empty if full(k, g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
-        gv = (torch.empty if full(v, g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
-        _chk(_L().ix_flash_bwd_f32(pl["qr"].data_ptr(), pl["qt"].data_ptr(), dor.data_ptr(), dot.data_ptr(), pl["kr"].data_ptr(),
-                                   pl["kt"].data_ptr(), pl["vr"].data_ptr(), pl["bias"].data_ptr(), lse.data_ptr(),
+        gq, gk, gv = _grad_buffers(g, q, k, v, same_qk)
+        _chk(_L().ix_flash_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, dop.ref, pl["bias"].data_ptr(), lse.data_ptr(),
                                    delta.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
                                    g.hd, g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, g.scale, p, seed, _stream()),
              "ix_flash_bwd_f32")
         ctx.g, ctx.p, ctx.seed, ctx.same_qk = g, p, seed, same_qk
-        ctx.pl = dict(pl, dor=dor, dot=dot, delta=delta)
+        ctx.pl = dict(pl, do=dop, delta=delta)
         ctx.save_for_backward(q, k, v, out, lse, do)
         if same_qk:   # one buffer carries both gradients: hand it to q, nothing to k
             return gq, None, gv
@@ -537,21 +555,16 @@ class FlashAttentionBwd(Function):
         else:
             hk = _req(hk.contiguous()) if hk is not None else zeros(k)
         hv = _req(hv.contiguous()) if hv is not None else zeros(v)
-        hqr, hqt = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
-        hkr, hkt = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
-        hvr, hvt = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
-        order = [pl["qr"], pl["qt"], hqr, hqt, pl["dor"], pl["dot"], pl["kr"], pl["kt"], hkr, hkt, pl["vr"], pl["vt"], hvr, hvt]
-        planes = (ctypes.c_void_p * 14)(*[t.data_ptr() for t in order])
-        full = lambda ld, off: ld == E and off == 0
-        packed = ctx.same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]
-        dq = (torch.empty if packed or full(g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
-        dk = dq if ctx.same_qk else (torch.empty if full(g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
-        dv = (torch.empty if full(g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
+        hqp = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
+        hkp = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
+        hvp = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
+        dq, dk, dv = _grad_buffers(g, q, k, v, ctx.same_qk)
         ddo = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
         need = ctypes.c_size_t()
         _chk(_L().ix_workspace_bytes_flash_bwd_bwd(g.n, g.heads, g.L, ctypes.byref(need)), "ix_workspace_bytes_flash_bwd_bwd")
         ws = torch.empty(need.value // 4, dtype=torch.float32, device=dev)
-        _chk(_L().ix_flash_bwd_bwd_f32(planes, pl["bias"].data_ptr(), lse.data_ptr(), pl["delta"].data_ptr(), dq.data_ptr(),
+        _chk(_L().ix_flash_bwd_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["do"].ref, hqp.ref, hkp.ref, hvp.ref,
+                                       pl["bias"].data_ptr(), lse.data_ptr(), pl["delta"].data_ptr(), dq.data_ptr(),
                                        dk.data_ptr(), dv.data_ptr(), ddo.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp, g.hd,
                                        g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, E, 0, g.scale, ctx.p, ctx.seed,
                                        ws.data_ptr(), need.value, _stream()), "ix_flash_bwd_bwd_f32")

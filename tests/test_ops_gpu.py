@@ -20,6 +20,14 @@ def ops():
     return hipops
 
 
+@pytest.fixture()
+def materialised(ops):
+    """Tests of the materialised attention node (AttentionCore, [L, S] tensors in HBM): route ops.attention to it."""
+    old, ops.ATTENTION_IMPL = ops.ATTENTION_IMPL, "materialised"
+    yield
+    ops.ATTENTION_IMPL = old
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed + sum(shape) * 7919)
     return torch.randn(*shape, generator=g) * scale
@@ -130,7 +138,7 @@ def test_packed_qk_projection_offsets(ops):
 
 @pytest.mark.parametrize("n,H,L,S,hd,masked", [(2, 8, 50, 361, 32, True), (3, 4, 37, 37, 64, False), (2, 2, 70, 130, 32, True),
                                                (1, 2, 9, 2500, 32, True)])   # last: rows beyond the register-resident kernels
-def test_attention_core_against_float64(ops, n, H, L, S, hd, masked):
+def test_attention_core_against_float64(ops, materialised, n, H, L, S, hd, masked):
     """The one-node attention (scores -> softmax -> apply, no dropout) and its hand-written double backward."""
     E = H * hd
     scale = 1.0 / math.sqrt(hd)
@@ -152,7 +160,7 @@ def test_attention_core_against_float64(ops, n, H, L, S, hd, masked):
     check_op(hip, ref, [rnd(n, L, E), rnd(n, S, E), rnd(n, S, E)], name="attention core")
 
 
-def test_attention_core_packed_qk_and_dropout_match_node_by_node(ops):
+def test_attention_core_packed_qk_and_dropout_match_node_by_node(ops, materialised):
     """With dropout the fused node must reproduce the node-by-node graph (same seed -> same mask) at every
     derivative level: output, gradients, and the gradient of a functional of the gradients."""
     n, H, L, hd, p = 2, 4, 45, 32, 0.2
@@ -511,7 +519,7 @@ def test_flash_forward_against_float64(ops, n, H, L, S, hd, masked):
         mask[-1, 3:9] = 1
     scale = 1.0 / math.sqrt(hd)
     g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
-    out, lse, _ = ops.flash_forward(q.cuda(), k.cuda(), v.cuda(), g, mask.cuda() if masked else None, 0.0, 0)
+    out, lse, _ = ops.flash_forward(q.cuda(), k.cuda(), v.cuda(), g, mask.cuda() if masked else None, 0.0, 0, need_backward=False)
     ref, ref_lse = _ref_attention(q, k, v, H, scale, mask)
     close(out, ref, 2e-5, "flash forward")
     close(lse.view(n, H, -1)[:, :, :L], ref_lse, 2e-6, "flash lse")

@@ -1,4 +1,5 @@
-"""Times the flash attention kernels against the materialised attention node on the step's shapes (tuning aid)."""
+"""Times the flash attention kernels (forward / backward / double backward) against the materialised attention node on
+the training step's shapes (tuning aid).  usage: python tools/flash_bench.py [fusion|encoder|cross|b800]"""
 import math
 import sys
 import time
@@ -8,8 +9,11 @@ import torch
 sys.path.insert(0, ".")
 from interactron_amd import hipops as ops  # noqa: E402
 
+SHAPES = {"fusion": (16, 8, 2060, 2060, 64), "encoder": (80, 8, 361, 361, 32), "cross": (80, 8, 50, 361, 32),
+          "self50": (80, 8, 50, 50, 32), "b800": (2, 8, 12755, 12755, 64), "enc800": (10, 8, 2500, 2500, 32)}
 
-def timeit(fn, it=10):
+
+def timeit(fn, it=5):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -19,29 +23,37 @@ def timeit(fn, it=10):
     return (time.perf_counter() - t0) / it * 1e3
 
 
-for n, H, L, S, hd, p in [(16, 8, 2060, 2060, 64, 0.0), (16, 8, 2060, 2060, 64, 0.1), (80, 8, 361, 361, 32, 0.1),
-                          (80, 8, 50, 361, 32, 0.1), (2, 8, 12755, 12755, 64, 0.1)]:
+def run(name, p=0.1):
+    n, H, L, S, hd = SHAPES[name]
     E = H * hd
-    q, k, v = (torch.randn(n, R, E, device="cuda") for R in (L, S, S))
+    prod = 2.0 * n * H * L * S * hd   # one [L, S] x hd product
     g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, 1.0 / math.sqrt(hd))
-    flops = 4.0 * n * H * L * S * hd
-    t_split = timeit(lambda: ops.attn_split(q, n, L, E, 0, H, hd))
-    qr, qt = ops.attn_split(q, n, L, E, 0, H, hd)
-    kr, kt = ops.attn_split(k, n, S, E, 0, H, hd)
-    vr, vt = ops.attn_split(v, n, S, E, 0, H, hd)
-    bias = ops.attn_bias(None, n, S, q.device)
-    Lp, Sp = ops._pad128(L), ops._pad128(S)
-    out = torch.empty(n, L, E, device="cuda")
-    lse = torch.empty(n * H, Lp, device="cuda")
-
-    def fwd():
-        ops._chk(ops._L().ix_flash_fwd_f32(qr.data_ptr(), kr.data_ptr(), vt.data_ptr(), bias.data_ptr(), out.data_ptr(),
-                                           lse.data_ptr(), n, H, L, Lp, S, Sp, hd, E, 0, g.scale, p, 1234, ops._stream()), "fwd")
-    t_f = timeit(fwd)
-    line = "n=%d H=%d L=%d S=%d hd=%d p=%.1f: split %.3f ms, flash fwd %.3f ms = %.1f TFLOP/s fp32-eq" % (
-        n, H, L, S, hd, p, t_split, t_f, flops / t_f / 1e9)
-    if n * H * L * S * 4 < 8e9:
-        with torch.no_grad():
-            t_m = timeit(lambda: ops.AttentionCore.forward(ops._NullCtx(), q, k, v, g, None, p, 1234))
-        line += "; materialised fwd %.3f ms" % t_m
+    res = {}
+    for impl in ("flash", "materialised"):
+        if impl == "materialised" and n * H * L * S * 4 > 6e9:
+            continue
+        ops.ATTENTION_IMPL = impl
+        q, k, v = (torch.randn(n, R, E, device="cuda", requires_grad=True) for R in (L, S, S))
+        gy = torch.randn(n, L, E, device="cuda", requires_grad=True)
+        ws = [torch.randn_like(t) for t in (q, k, v)]
+        node = ops.FlashAttention if impl == "flash" else ops.AttentionCore
+        out = node.apply(q, k, v, g, None, p, 77)
+        t_f = timeit(lambda: node.apply(q, k, v, g, None, p, 77))
+        g1 = torch.autograd.grad(out, [q, k, v], gy, create_graph=True)
+        t_b = timeit(lambda: torch.autograd.grad(out, [q, k, v], gy, retain_graph=True))
+        s = sum((a * w).sum() for a, w in zip(g1, ws))
+        t_bb = timeit(lambda: torch.autograd.grad(s, [q, k, v, gy], retain_graph=True))
+        res[impl] = (t_f, t_b, t_bb)
+        del out, g1, s
+        torch.cuda.empty_cache()
+    f = res["flash"]
+    line = "%-8s p=%.1f flash: fwd %.3f ms (%.0f TF/s of 2 products), bwd %.3f (%.0f of 7), bwd_bwd %.3f (%.0f of 22)" % (
+        name, p, f[0], 2 * prod / f[0] / 1e9, f[1], 7 * prod / f[1] / 1e9, f[2], 22 * prod / f[2] / 1e9)
+    if "materialised" in res:
+        m = res["materialised"]
+        line += " | materialised: %.3f / %.3f / %.3f" % m
     print(line, flush=True)
+
+
+for name in (sys.argv[1:] or ["fusion", "encoder", "cross", "self50"]):
+    run(name)
