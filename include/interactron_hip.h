@@ -51,6 +51,8 @@ int ix_gemm_set_mode(int mode); /* 0: fp32 MFMA only; 1: bf16x6 (3-way bf16 spli
 int ix_gemm_stats(double* flops, int64_t* launches, int reset);
 int ix_gemm_prof_enable(int on);
 int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2); /* [0] fp32-MFMA kernel, [1] bf16x6 kernel */
+int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3); /* [2] = flash attention kernels (ix_flash_*) */
+int ix_flash_stats(double* flops, int64_t* launches, int reset);     /* algorithmic FLOPs / launches of ix_flash_* */
 int ix_gemm_prof_read(double* total_ms, int64_t* pairs);
 int ix_gemm_prof_dump(const char* path_host); /* per-launch CSV (shape, tile, split, ms); call before ix_gemm_prof_read */
 

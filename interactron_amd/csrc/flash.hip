@@ -43,6 +43,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// v_exp_f32 directly: exp2f() wraps it in denormal-range handling (4 more instructions per element), and every use here
+// either has a non-positive argument or is multiplied into a sum where a flushed 2^-126 does not matter
+#define fl_exp2(X) __builtin_amdgcn_exp2f(X)
 #define FL_LOG2E 1.4426950408889634f
 #define FL_LN2 0.6931471805599453f
 
@@ -402,19 +405,21 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        const float alpha = fl_exp2(m - mn);
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            x[r] = exp2f(x[r] - mn);
+            x[r] = fl_exp2(x[r] - mn);
             ps += x[r];
         }
         l = l * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // (a row maximum moved somewhere in this wave: rare after the first tiles)
 #pragma unroll
-        for (int db = 0; db < NDB; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
         if (DROP) {
             float mk[16];
             FL_MASK_KEYS_IN_REGS(mk, rid, t0)
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
         if (DROP) { FL_MASK_KEYS_IN_REGS(mk, rid, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            x[r] = exp2f(s[r] * cs + kb[r >> 2][r & 3] - lse2) * (gd[r] * cg * mk[r] - dl);
+            x[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2) * (gd[r] * cg * mk[r] - dl);
         u32x4 pp[2][3];
         FL_SPLIT16(pp, x)
         // ---- gQ^T[d, query] += K^T[d, key] gs^T[key, query] ----
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
         if (DROP) { FL_MASK_QUERIES_IN_REGS(mk, key, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pr = exp2f(s[r] * cs + kbias - FLK_ST(0, r) * FL_LOG2E);
+            const float pr = fl_exp2(s[r] * cs + kbias - FLK_ST(0, r) * FL_LOG2E);
             pd[r] = mk[r] != 0.f ? pr : 0.f;                              // (x 1/keep at the end, on gV)
             gs[r] = pr * (gd[r] * cg * mk[r] - FLK_ST(1, r));
         }
@@ -764,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
         float pr[16], mk[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pr[r] = exp2f(s[r] * cs + kb[r >> 2][r & 3] - lse2);
+            pr[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2);
             mk[r] = 1.f;
             g1[r] = g1[r] * c1 + g2[r] * c3;   // G
             gd[r] *= cg;
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
         float pr[16], mk[16], x[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pr[r] = exp2f(s[r] * cs + kbias - FLC_ST(0, r) * FL_LOG2E);
+            pr[r] = fl_exp2(s[r] * cs + kbias - FLC_ST(0, r) * FL_LOG2E);
             mk[r] = 1.f;
             g1[r] = g1[r] * c1 + g2[r] * c3;   // G
             gd[r] *= cg;
@@ -991,6 +996,8 @@ static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, in
     return IX_OK;
 }
 #define FL_OUT_OK(LD, OFF) ((LD) % 4 == 0 && (OFF) % 4 == 0)
+// algorithmic FLOPs of ONE [L, S] x hd product over all (batch, head) pairs -- the unit the launch statistics count in
+#define FL_PRODUCT_FLOPS (2.0 * (double)n * (double)H * (double)L * (double)S * (double)hd)
 #define FL_DISPATCH(KERNEL, GRID)                                                                      \
     if (hd == 64) {                                                                                    \
         if (a.thr16) hipLaunchKernelGGL((KERNEL<64, true>), GRID, dim3(256), 0, stream, a);            \
@@ -1014,7 +1021,9 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.v_tr = (const unsigned short*)v->tr;
     a.o1 = out; a.ld1 = ld_out; a.off1 = off_out; a.lse = lse;
     dim3 grid((L + 127) / 128, n * H);
+    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, 1);
     FL_DISPATCH(flash_fwd_kernel, grid)
+    ix_prof_end(stream);
     IX_CHECK_LAUNCH("ix_flash_fwd_f32");
     return IX_OK;
 }
@@ -1038,13 +1047,17 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.v_row = (const unsigned short*)v->row; a.v_us = v->unscale;
     a.lse = const_cast<float*>(lse); a.delta = delta;
     a.o1 = gq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = gk; a.ld2 = ld_k; a.off2 = off_k; a.o3 = gv; a.ld3 = ld_v; a.off3 = off_v;
-    if (gq) {
+    if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
+        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, 2);
         FL_DISPATCH(flash_bwd_q_kernel, grid)
+        ix_prof_end(stream);
     }
-    if (gk && gv) {
+    if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
+        ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, 3);
         FL_DISPATCH(flash_bwd_kv_kernel, grid)
+        ix_prof_end(stream);
     }
     IX_CHECK_LAUNCH("ix_flash_bwd_f32");
     return IX_OK;
@@ -1080,10 +1093,17 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     a.o1 = dq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = dk; a.ld2 = ld_k; a.off2 = off_k;
     a.o3 = dv; a.ld3 = ld_v; a.off3 = off_v; a.o4 = ddo; a.ld4 = ld_do; a.off4 = off_do;
     const dim3 gq((L + 127) / 128, n * H), gk((S + 127) / 128, n * H), blk(256);
+    // products per pass (G counts twice: hq k^T + q hk^T): statistics 5; dq + ddO 5 + 4; dk + dv 5 + 3
 #define FL_BB_LAUNCH(HD_, DR_)                                                                         \
+    ix_prof_begin(stream, 2, 5.0 * FL_PRODUCT_FLOPS, 4);                                               \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true>), gq, blk, 0, stream, a);                    \
+    ix_prof_end(stream);                                                                               \
+    ix_prof_begin(stream, 2, 9.0 * FL_PRODUCT_FLOPS, 5);                                               \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false>), gq, blk, 0, stream, a);                   \
-    hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);
+    ix_prof_end(stream);                                                                               \
+    ix_prof_begin(stream, 2, 8.0 * FL_PRODUCT_FLOPS, 6);                                               \
+    hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);                         \
+    ix_prof_end(stream);
     if (hd == 64) {
         if (a.thr16) { FL_BB_LAUNCH(64, true) } else { FL_BB_LAUNCH(64, false) }
     } else {

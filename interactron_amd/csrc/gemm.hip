@@ -1416,9 +1416,12 @@ static int64_t g_launches = 0;
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_ev;
 static size_t g_ev_used = 0;
-struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; };
+struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; double flops = 0.0; };   // bm 2002: a flash attention launch
 static std::vector<ProfRec> g_rec;
+static double g_flash_flops = 0.0;
+static int64_t g_flash_launches = 0;
 
+extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3);
 extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
     if (flops) *flops = g_flops;
     if (launches) *launches = g_launches;
@@ -1451,7 +1454,7 @@ extern "C" int ix_gemm_prof_dump(const char* path) {
         float t = 0.f;
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
         const ProfRec& r = g_rec[i / 2];
-        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%.6f\n", r.M, r.N, r.K, r.nbatch, r.a_kc, r.b_kc, r.bm, r.split, t);
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%.6f\n", r.M, r.N, r.K, r.nbatch, r.a_kc, r.b_kc, r.bm, r.split, t);   // (tile 2002: flash attention launch, K = its kind tag)
     }
     fclose(f);
     return IX_OK;
@@ -1460,23 +1463,45 @@ extern "C" int ix_gemm_prof_dump(const char* path) {
 // Per kernel kind (index 0: fp32-MFMA kernel, 1: bf16x6 kernel): summed event time (ms), executed algorithmic FLOPs and
 // launch count of the profiled launches.  Host arrays of 2.  Call before ix_gemm_prof_read (which clears the records).
 extern "C" int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2) {
-    double ms[2] = {0, 0}, fl[2] = {0, 0};
-    int64_t n[2] = {0, 0};
-    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
-        hipEventSynchronize(g_ev[i + 1]);
-        float t = 0.f;
-        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
-        const ProfRec& r = g_rec[i / 2];
-        const int k = r.bm == 1128 ? 1 : 0;
-        ms[k] += t;
-        fl[k] += 2.0 * r.M * (double)r.N * (double)r.K * (double)r.nbatch;
-        n[k] += 1;
-    }
+    double ms[3], fl[3];
+    int64_t n[3];
+    const int rc = ix_prof_kinds3(ms, fl, n);
     for (int k = 0; k < 2; ++k) {
         if (ms2) ms2[k] = ms[k];
         if (flops2) flops2[k] = fl[k];
         if (launches2) launches2[k] = n[k];
     }
+    return rc;
+}
+
+// As ix_gemm_prof_kinds with a third slot: [0] fp32-MFMA contraction kernel, [1] bf16x6 contraction kernel, [2] flash
+// attention kernels.  Host arrays of 3.
+extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
+    double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0};
+    int64_t n[3] = {0, 0, 0};
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        const ProfRec& r = g_rec[i / 2];
+        const int k = r.bm == 2002 ? 2 : (r.bm == 1128 ? 1 : 0);
+        ms[k] += t;
+        fl[k] += r.flops;
+        n[k] += 1;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (ms3) ms3[k] = ms[k];
+        if (flops3) flops3[k] = fl[k];
+        if (launches3) launches3[k] = n[k];
+    }
+    return IX_OK;
+}
+
+// Executed algorithmic FLOPs and launch count of the flash attention kernels since the last reset (always on).
+extern "C" int ix_flash_stats(double* flops, int64_t* launches, int reset) {
+    if (flops) *flops = g_flash_flops;
+    if (launches) *launches = g_flash_launches;
+    if (reset) { g_flash_flops = 0.0; g_flash_launches = 0; }
     return IX_OK;
 }
 
@@ -1508,6 +1533,18 @@ static inline void prof_mark(hipStream_t stream) {
     }
     hipEventRecord(g_ev[g_ev_used++], stream);
 }
+
+// The same per-launch event bracket for the flash attention kernels (csrc/flash.hip): kind 2, `flops` = algorithmic
+// (fp32-equivalent) FLOPs of the launch, products = [L, S] x hd products it evaluates (encoded in the record's K).
+void ix_prof_begin(hipStream_t stream, int kind, double flops, int tag) {
+    if (kind == 2) { g_flash_flops += flops; g_flash_launches += 1; }
+    if (!g_prof_on) return;
+    ProfRec r = {0, 0, tag, 0, 0, 0, 2000 + kind, 1};
+    r.flops = flops;
+    g_rec.push_back(r);
+    prof_mark(stream);
+}
+void ix_prof_end(hipStream_t stream) { prof_mark(stream); }
 
 extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
@@ -1600,7 +1637,11 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
     g_launches += 1;
-    if (g_prof_on) g_rec.push_back({M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split});
+    if (g_prof_on) {
+        ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split};
+        r.flops = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+        g_rec.push_back(r);
+    }
     prof_mark(stream);
     if (use_x6 && g_x6 == 5 && bn >= 64 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30)) {
         if (bn == 128)
