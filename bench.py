@@ -13,9 +13,14 @@ region; inputs are resident in HBM when it starts.
 Multi-GPU: one process per GPU (torchrun env), every rank runs its own ``--episodes`` episodes (weak scaling), the
 only collective is the meta-gradient all-reduce.
 
+``python bench.py --gpus N`` works with or without torchrun: without a RANK in the environment the process starts the N
+ranks itself (before it touches the GPU) and relays rank 0's line.
+
 Output: ONE JSON line on rank 0 with frames/sec (= 5 * episodes * ranks * steps / seconds), a ``roofline`` object for
-the dominant kernel (the MFMA contraction kernel behind every Linear / conv / attention product) and a
-``cpu_baseline`` object (the CPU oracle, oracle/episode.py, timed on this box's host cores on one episode).
+the dominant kernel (the MFMA contraction kernel behind every Linear / conv product; the flash attention kernels are
+listed beside it), a ``cpu_baseline`` object (the CPU oracle, oracle/episode.py, on this box's host cores: 1 warm-up + 3
+timed episodes, median), an ``n800`` object (the north-star 5 x 3x800x800 episodes, same step, measured in the same
+process after the headline) and, for N > 1, ``rccl_ranks`` / ``allreduce`` (the meta-gradient all-reduce timed alone).
 """
 import argparse
 import ctypes
@@ -96,9 +101,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, size, config="interactron"):
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(cfg, size, config="interactron", timed=3):
     """The CPU oracle (a from-scratch PyTorch-CPU restatement of the reference path, pinned to fixtures captured from
-    the imported reference) on ONE synthetic episode of the same workload, all host cores."""
+    the imported reference) on synthetic episodes of the same workload, all usable host cores: one warm-up episode, then
+    `timed` timed ones (one episode = one meta-train pass of the same model, 5 frames); the median is reported."""
     import torch
     from interactron_amd.synthetic import procedural_state_dict, synthetic_episodes
     from oracle import detector as od, episode as oe, fusion as of
@@ -113,62 +129,65 @@ def cpu_baseline(cfg, size, config="interactron"):
                procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, style).items()}).items()}
         if style == "decoder" and "pos_embed" not in fus:
             fus["pos_embed"] = of.decoder_fusion_pos_embed()
-    data = synthetic_episodes(1, height=size, width=size, tag="bench-r0")
     random.seed(0)
-    t0 = time.perf_counter()
-    if config == "single_frame_baseline":
-        oe.detr_train_forward(det, data)
-        fn = "detr_train_forward"
-    elif config == "multi_frame_baseline":
-        oe.multiframe_forward(det, fus, data, cfg)
-        fn = "multiframe_forward"
-    else:
-        oe.interactron_forward(det, fus, data, cfg, {}, style)
-        fn = "interactron_forward"
-    dt = time.perf_counter() - t0
-    return {"value": 5.0 / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 training episode (5 frames, %dx%d, fp32) through oracle/episode.py:%s, no warm-up, %.1f s"
-                      % (size, size, fn, dt)}
+    times = []
+    for i in range(1 + timed):
+        data = synthetic_episodes(1, height=size, width=size, tag="bench-cpu%d" % i)
+        t0 = time.perf_counter()
+        if config == "single_frame_baseline":
+            oe.detr_train_forward(det, data)
+            fn = "detr_train_forward"
+        elif config == "multi_frame_baseline":
+            oe.multiframe_forward(det, fus, data, cfg)
+            fn = "multiframe_forward"
+        else:
+            oe.interactron_forward(det, fus, data, cfg, {}, style)
+            fn = "interactron_forward"
+        times.append(time.perf_counter() - t0)
+    timed_s = sorted(times[1:])
+    med = timed_s[len(timed_s) // 2]
+    return {"value": 5.0 / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d training episodes (5 frames, %dx%d, fp32) through oracle/episode.py:%s after 1 warm-up episode, "
+                      "median %.2f s (each: %s) on %d threads of %s"
+                      % (timed, size, size, fn, med, ", ".join("%.2f" % t for t in times[1:]), cores, cpu_model_name())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=300, help="frame height = width (300 = reference data, 800 = north-star)")
-    ap.add_argument("--queries", type=int, default=50)
-    ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
-    ap.add_argument("--config", default="interactron", choices=sorted(CONFIGS),
-                    help="which reference config's training step to run (default: the headline meta-train step)")
-    ap.add_argument("--mode", default="train", choices=["train", "predict", "interactive", "predict-batched"],
-                    help="train (default, the headline): meta-train step; predict: model.predict per episode (eval adapt, "
-                         "reference interactron.py:31-59); interactive: predict + 4 x get_next_action per episode (SURVEY 8d iii)")
-    ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
-    args = ap.parse_args()
+def launch_ranks(args):
+    """``python bench.py --gpus N`` without a torchrun environment: start the N ranks as child processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything in this process touches the GPU,
+    relay rank 0's JSON line and fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        sys.exit(1)
 
+
+def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline, tag):
+    """Build the model of `--config` at frame size `size`, run `warmup` + `steps` steps of `--mode`, return the metrics
+    of the timed steps (max over ranks) and, from one extra profiled step, the per-kernel roofline numbers."""
     import torch
     import torch.distributed as dist
     from interactron_amd import Config, build_model
-    from interactron_amd import _lib
     from interactron_amd.synthetic import load_procedural, synthetic_episodes
-    from interactron_amd.trainer import FlatOuterStep, init_distributed
+    from interactron_amd.trainer import FlatOuterStep
+    lib, dev, rank, world, local = ctx["lib"], ctx["dev"], ctx["rank"], ctx["world"], ctx["local"]
 
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    # bind this rank's GPU BEFORE the process group exists: RCCL communicators are created on the current device
-    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # (gloo smoke runs: several ranks per GPU)
-    torch.cuda.set_device(local)
-    rank, _, world = init_distributed()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    dev = torch.device("cuda", local)
-    lib = _lib.load()
-    if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
-        lib.ix_gemm_set_mode(int(os.environ["IX_GEMM_MODE"]))
-
-    cfg, tokens = model_cfg(args.size, args.queries, args.chunk, CONFIGS[args.config][1])
+    cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1])
     model = build_model(Config(**cfg))
     if hasattr(model, "fusion"):
         load_procedural(model.fusion, "fusion.")
@@ -177,16 +196,14 @@ def main():
         outer = FlatOuterStep(model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
     else:   # configs/single_frame_baseline.yaml: one Adam over the whole DETR (direct-supervision trainer)
         outer = FlatOuterStep(model, max_norm=1.0, groups=[list(model.parameters())], lrs=[1e-5])
-    data = to_gpu(synthetic_episodes(args.episodes, height=args.size, width=args.size, tag="bench-r%d" % rank), dev)
+    data = to_gpu(synthetic_episodes(episodes, height=size, width=size, tag="%s-r%d" % (tag, rank)), dev)
     random.seed(1234 + rank)
-
     last = {}
 
     def episode(i, frames=None):
-        d = {"frames": data["frames"][i:i + 1, :frames], "masks": data["masks"][i:i + 1, :frames],
-             "category_ids": [data["category_ids"][i][:frames]], "boxes": [data["boxes"][i][:frames]],
-             "actions": data["actions"][i:i + 1], "initial_image_path": [data["initial_image_path"][i]]}
-        return d
+        return {"frames": data["frames"][i:i + 1, :frames], "masks": data["masks"][i:i + 1, :frames],
+                "category_ids": [data["category_ids"][i][:frames]], "boxes": [data["boxes"][i][:frames]],
+                "actions": data["actions"][i:i + 1], "initial_image_path": [data["initial_image_path"][i]]}
 
     if args.mode != "train":   # evaluation modes: one episode at a time, as the reference evaluators call them
         assert args.config in ("interactron", "interactron_random") or args.mode == "predict"
@@ -198,7 +215,7 @@ def main():
             last["losses"] = losses
             outer.step()
             return
-        for i in range(args.episodes if args.mode != "predict-batched" else 0):
+        for i in range(episodes if args.mode != "predict-batched" else 0):
             if args.mode == "interactive":   # the policy looks at 1..4 frames, then the adapted prediction on all 5
                 for s in range(1, 5):
                     model.get_next_action(episode(i, s))
@@ -215,70 +232,168 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     lib.ix_gemm_stats(None, None, 1)
+    lib.ix_flash_stats(None, None, 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     dt = time.perf_counter() - t0
-    flops, launches = ctypes.c_double(), ctypes.c_int64()
+    flops, launches, fflops, flaunches = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
     lib.ix_gemm_stats(ctypes.byref(flops), ctypes.byref(launches), 1)
+    lib.ix_flash_stats(ctypes.byref(fflops), ctypes.byref(flaunches), 1)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    res = {"seconds": dt, "steps": steps, "episodes": episodes, "frames_per_s": 5.0 * episodes * world * steps / dt,
+           "ms_per_step": dt * 1e3 / steps, "block_size": cfg["BLOCK_SIZE"], "cfg": cfg,
+           "gemm_gflop_per_step": flops.value / 1e9 / steps, "gemm_launches_per_step": launches.value / steps,
+           "attention_gflop_per_step": fflops.value / 1e9 / steps, "attention_launches_per_step": flaunches.value / steps,
+           "allreduce": None, "roofline": None}
 
-    roofline = None
-    if not args.no_roofline:
-        # HIP-event pair around every launch of the contraction kernel on its own stream, one extra step of the same
-        # workload (kept out of the timed region so the events do not perturb `value`).
+    if world > 1 and args.mode == "train":
+        # the step's single data-path collective, timed by itself: 5 all-reduces of the flat gradient buffer, fenced
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            outer.flat.all_reduce_grads()
+        fence()
+        ar = (time.perf_counter() - t0) / 5
+        nbytes = outer.flat.grads.numel() * 4
+        outer.flat.grads.zero_()
+        res["allreduce"] = {"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks": world,
+                            "bytes": nbytes, "ms": ar * 1e3,
+                            "bus_GBps": 2.0 * (world - 1) / world * nbytes / ar / 1e9}
+
+    if want_roofline:
+        # HIP-event pair around every launch of the contraction and attention kernels on their own stream, one extra step
+        # of the same workload (kept out of the timed region so the events do not perturb `value`).
         lib.ix_gemm_prof_enable(1)
-        lib.ix_gemm_stats(None, None, 1)
         step()
         torch.cuda.synchronize()
-        ms, pairs = ctypes.c_double(), ctypes.c_int64()
         if args.gemm_csv and rank == 0:
             lib.ix_gemm_prof_dump(args.gemm_csv.encode())
-        kms, kfl, kn = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)()
-        lib.ix_gemm_prof_kinds(kms, kfl, kn)
+        kms, kfl, kn = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+        lib.ix_prof_kinds3(kms, kfl, kn)
+        fms, ffl, fmf, fn = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_int64 * 7)()
+        lib.ix_prof_flash(fms, ffl, fmf, fn)
+        ms, pairs = ctypes.c_double(), ctypes.c_int64()
         lib.ix_gemm_prof_read(ctypes.byref(ms), ctypes.byref(pairs))
-        pf, pl = ctypes.c_double(), ctypes.c_int64()
-        lib.ix_gemm_stats(ctypes.byref(pf), ctypes.byref(pl), 1)
         lib.ix_gemm_prof_enable(0)
-        # dominant kernel = the bf16x6 contraction kernel (fp32 operands split 3-way into bf16, 6 bf16 MFMAs per fp32
-        # multiply-add).  `achieved` is ALGORITHMIC (fp32-equivalent) FLOP/s of its launches; `peak` is the most that
-        # scheme can deliver on the bf16 matrix cores, 2500 / 6.  The fp32-MFMA kernel (small-K products) is listed beside it.
-        k = 1 if kms[1] >= kms[0] else 0
-        tf = [kfl[i] / (kms[i] * 1e-3) / 1e12 if kms[i] > 0 else 0.0 for i in range(2)]
-        peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if k == 1 else FP32_MFMA_PEAK_TFLOPS
-        kname = "gemm_f32_bf16x6_p12_kernel" if k == 1 else "gemm_f32_mfma_kernel"
-        roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak, "traffic": pmc_traffic(kname),
-                    "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
-                    "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
-                    "note": "achieved = fp32-equivalent algorithmic FLOP/s; executed bf16 MFMA rate = 6x that "
-                            "(%.0f of %.0f TFLOP/s).  The peak assumes 2.4 GHz: back to back this kernel holds the package at "
-                            "its 1400 W cap and the shader clock at 1.4-1.8 GHz (profiles/README.md, power probe)"
-                            % (6 * tf[1], BF16_MFMA_PEAK_TFLOPS),
-                    "fp32_mfma_kernel": {"achieved": tf[0], "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf[0] / FP32_MFMA_PEAK_TFLOPS,
-                                         "launches_per_step": int(kn[0]), "kernel_ms_per_step": kms[0]},
-                    "all_contractions": {"achieved": pf.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
-                                         "gflop_per_step": pf.value / 1e9, "kernel_ms_per_step": ms.value,
-                                         "launches_per_step": int(pl.value)}}
+        res["roofline"] = build_roofline(list(kms), list(kfl), list(kn), list(fms), list(ffl), list(fmf), list(fn))
 
     bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
     assert not bad, "non-finite losses after the timed steps: %s" % bad
+    del model, outer, data
+    torch.cuda.empty_cache()
+    return res
+
+
+FLASH_KERNELS = ["all", "flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_kernel", "flash_bb_q_kernel<stats>",
+                 "flash_bb_q_kernel", "flash_bb_kv_kernel"]
+
+
+def build_roofline(kms, kfl, kn, fms, ffl, fmf, fn):
+    """`roofline` object for the dominant kernel = the bf16x6 contraction kernel (fp32 operands split 3-way into bf16, 6
+    bf16 MFMAs per fp32 multiply-add).  `achieved` is ALGORITHMIC (fp32-equivalent) FLOP/s of its launches; `peak` is the
+    most that scheme can deliver on the bf16 matrix cores, 2500 / 6.  The fp32-MFMA kernel (small-K products) and the
+    flash attention kernels (3 fp16 / 6 bf16 MFMA terms per product, executed rate against the 2500 TFLOP/s peak) are
+    listed beside it."""
+    tf = [kfl[i] / (kms[i] * 1e-3) / 1e12 if kms[i] > 0 else 0.0 for i in range(3)]
+    k = 1 if kms[1] >= kms[0] else 0
+    peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if k == 1 else FP32_MFMA_PEAK_TFLOPS
+    kname = "gemm_f32_bf16x6_p12_kernel" if k == 1 else "gemm_f32_mfma_kernel"
+    attn = {"kernel_ms_per_step": fms[0], "launches_per_step": int(fn[0]), "gflop_per_step": ffl[0] / 1e9,
+            "achieved": ffl[0] / (fms[0] * 1e-3) / 1e12 if fms[0] > 0 else 0.0, "unit": "TFLOP/s (fp32-equivalent, algorithmic)",
+            "executed_mfma_tflops": fmf[0] / (fms[0] * 1e-3) / 1e12 if fms[0] > 0 else 0.0, "mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+            "mfma_frac": fmf[0] / (fms[0] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS if fms[0] > 0 else 0.0,
+            "kernels": {FLASH_KERNELS[i]: {"ms_per_step": fms[i], "launches": int(fn[i]),
+                                           "achieved": ffl[i] / (fms[i] * 1e-3) / 1e12,
+                                           "mfma_frac": fmf[i] / (fms[i] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+                        for i in range(1, 7) if fms[i] > 0}}
+    total_ms = kms[0] + kms[1] + fms[0]
+    total_fl = kfl[0] + kfl[1] + ffl[0]
+    return {"bound": "mfma", "kernel": kname, "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak,
+            "traffic": pmc_traffic(kname), "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
+            "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
+            "note": "achieved = fp32-equivalent algorithmic FLOP/s; executed bf16 MFMA rate = 6x that "
+                    "(%.0f of %.0f TFLOP/s).  The peak assumes 2.4 GHz: back to back this kernel holds the package at "
+                    "its 1400 W cap and the shader clock at 1.4-1.8 GHz (profiles/README.md, power probe)"
+                    % (6 * tf[1], BF16_MFMA_PEAK_TFLOPS),
+            "fp32_mfma_kernel": {"achieved": tf[0], "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf[0] / FP32_MFMA_PEAK_TFLOPS,
+                                 "launches_per_step": int(kn[0]), "kernel_ms_per_step": kms[0]},
+            "attention_kernels": attn,
+            "all_mfma_kernels": {"achieved": total_fl / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0,
+                                 "gflop_per_step": total_fl / 1e9, "kernel_ms_per_step": total_ms}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=300, help="frame height = width (300 = reference data, 800 = north-star)")
+    ap.add_argument("--queries", type=int, default=50)
+    ap.add_argument("--episodes", type=int, default=16, help="episodes per GPU per step (reference configs/interactron.yaml BATCH_SIZE: 16)")
+    ap.add_argument("--config", default="interactron", choices=sorted(CONFIGS),
+                    help="which reference config's training step to run (default: the headline meta-train step)")
+    ap.add_argument("--mode", default="train", choices=["train", "predict", "interactive", "predict-batched"],
+                    help="train (default, the headline): meta-train step; predict: model.predict per episode (eval adapt, "
+                         "reference interactron.py:31-59); interactive: predict + 4 x get_next_action per episode (SURVEY 8d iii)")
+    ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
+    ap.add_argument("--n800-episodes", type=int, default=4,
+                    help="episodes per GPU per step of the north-star sub-measurement (5 x 3x800x800 frames each; 0 = skip it)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:   # plain `python bench.py --gpus N`: become the launcher (no GPU call yet)
+        return launch_ranks(args)
+
+    import torch
+    import torch.distributed as dist
+    from interactron_amd import _lib
+    from interactron_amd.trainer import init_distributed
+
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    # bind this rank's GPU BEFORE the process group exists: RCCL communicators are created on the current device
+    local = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()   # (gloo smoke runs: several ranks per GPU)
+    torch.cuda.set_device(local)
+    rank, _, world = init_distributed()
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (torchrun --nproc-per-node must match)" % (args.gpus, world)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+    if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
+        lib.ix_gemm_set_mode(int(os.environ["IX_GEMM_MODE"]))
+    ctx = {"lib": lib, "dev": dev, "rank": rank, "world": world, "local": local}
+
+    head = run_workload(args, args.size, args.episodes, args.chunk, args.steps, args.warmup, ctx, not args.no_roofline, "bench")
+    # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755, SURVEY 0 row 4),
+    # measured in the same process after the headline: same step definition, fewer episodes per pass, its own warm-up.
+    n800 = None
+    if args.size == 300 and args.mode == "train" and args.config == "interactron" and args.n800_episodes > 0:
+        r8 = run_workload(args, 800, args.n800_episodes, args.n800_episodes, 3, 1, ctx, not args.no_roofline, "bench800")
+        n800 = {"workload": "%d episodes/GPU x 5 frames x 3x800x800, Q=%d, fusion T=%d, same step as the headline"
+                            % (args.n800_episodes, args.queries, r8["block_size"]),
+                "value": r8["frames_per_s"], "unit": "frames/s", "steps": 3, "warmup": 1, "ms_per_step": r8["ms_per_step"],
+                "episodes_per_gpu": args.n800_episodes, "gemm_gflop_per_step": r8["gemm_gflop_per_step"],
+                "attention_gflop_per_step": r8["attention_gflop_per_step"], "roofline": r8["roofline"]}
+
     if rank == 0:
-        frames = 5.0 * args.episodes * world * args.steps
+        from interactron_amd import hipops
+        cfg = head["cfg"]
         line = {
-            "metric": "frames/sec (5-frame episodes)", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps,
+            "metric": "frames/sec (5-frame episodes)", "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
-                                    "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode"
+                                    "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode "
+                                    "(dropout on; model-level parity is pinned in eval mode, the dropout kernels op by op)"
                                     % (CONFIGS[args.config][0], CONFIGS[args.config][1], args.episodes, args.size, args.size,
                                        args.queries, cfg["BLOCK_SIZE"])) if args.mode == "train" else
                                    ("%s %s, one episode at a time (%d episodes/GPU x 5 frames x 3x%dx%d), eval mode"
@@ -286,17 +401,22 @@ def main():
                                                                  "predict-batched": "predict() on all episodes of the batch at once",
                                                                  "interactive": "interactive episode (4 x get_next_action + predict)"}
                                        [args.mode], args.episodes, args.size, args.size)),
-                       "mode": args.mode,
-                       "episodes_per_gpu": args.episodes, "frame_size": args.size, "parallelism": "dp%d" % world},
-            "gemm_gflop_per_step": flops.value / 1e9 / args.steps, "gemm_launches_per_step": launches.value / args.steps,
-            "roofline": roofline,
+                       "mode": args.mode, "episodes_per_gpu": args.episodes, "frame_size": args.size,
+                       "attention": hipops.ATTENTION_IMPL, "parallelism": "dp%d" % world},
+            "gemm_gflop_per_step": head["gemm_gflop_per_step"], "gemm_launches_per_step": head["gemm_launches_per_step"],
+            "attention_gflop_per_step": head["attention_gflop_per_step"],
+            "roofline": head["roofline"],
             "cpu_baseline": None,
+            "n800": n800,
+            "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,
+            "allreduce": head["allreduce"],
         }
         if not args.no_cpu_baseline and world == 1 and args.mode == "train":
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
         print(json.dumps(line), flush=True)
     if world > 1:
-        fence()
+        dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -53,6 +53,10 @@ int ix_gemm_prof_enable(int on);
 int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2); /* [0] fp32-MFMA kernel, [1] bf16x6 kernel */
 int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3); /* [2] = flash attention kernels (ix_flash_*) */
 int ix_flash_stats(double* flops, int64_t* launches, int reset);     /* algorithmic FLOPs / launches of ix_flash_* */
+int ix_prof_flash(double* ms7, double* flops7, double* mfma_flops7, int64_t* launches7); /* profiled flash launches by
+                                   kernel: [0] all, [1] forward, [2] backward-q, [3] backward-kv, [4] statistics,
+                                   [5] second-order q, [6] second-order kv; mfma_flops = FLOPs of the issued matrix
+                                   instructions (3 fp16 / 6 bf16 terms per product) */
 int ix_gemm_prof_read(double* total_ms, int64_t* pairs);
 int ix_gemm_prof_dump(const char* path_host); /* per-launch CSV (shape, tile, split, ms); call before ix_gemm_prof_read */
 

@@ -31,7 +31,7 @@ void ix_set_error(const char* fmt, ...);
     } while (0)
 
 // launch statistics / per-launch HIP-event brackets shared by the contraction and attention kernels (gemm.hip)
-void ix_prof_begin(hipStream_t stream, int kind, double flops, int tag);
+void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops, int tag);
 void ix_prof_end(hipStream_t stream);
 
 static inline int ix_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

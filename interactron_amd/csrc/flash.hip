@@ -1021,7 +1021,7 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.v_tr = (const unsigned short*)v->tr;
     a.o1 = out; a.ld1 = ld_out; a.off1 = off_out; a.lse = lse;
     dim3 grid((L + 127) / 128, n * H);
-    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, 1);
+    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 1);
     FL_DISPATCH(flash_fwd_kernel, grid)
     ix_prof_end(stream);
     IX_CHECK_LAUNCH("ix_flash_fwd_f32");
@@ -1049,13 +1049,13 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.o1 = gq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = gk; a.ld2 = ld_k; a.off2 = off_k; a.o3 = gv; a.ld3 = ld_v; a.off3 = off_v;
     if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, 2);
+        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 2);
         FL_DISPATCH(flash_bwd_q_kernel, grid)
         ix_prof_end(stream);
     }
     if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, 3);
+        ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * 6) * FL_PRODUCT_FLOPS, 3);
         FL_DISPATCH(flash_bwd_kv_kernel, grid)
         ix_prof_end(stream);
     }
@@ -1095,13 +1095,13 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     const dim3 gq((L + 127) / 128, n * H), gk((S + 127) / 128, n * H), blk(256);
     // products per pass (G counts twice: hq k^T + q hk^T): statistics 5; dq + ddO 5 + 4; dk + dv 5 + 3
 #define FL_BB_LAUNCH(HD_, DR_)                                                                         \
-    ix_prof_begin(stream, 2, 5.0 * FL_PRODUCT_FLOPS, 4);                                               \
+    ix_prof_begin(stream, 2, 5.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);                      \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true>), gq, blk, 0, stream, a);                    \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 9.0 * FL_PRODUCT_FLOPS, 5);                                               \
+    ix_prof_begin(stream, 2, 9.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 6) * FL_PRODUCT_FLOPS, 5);              \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false>), gq, blk, 0, stream, a);                   \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 8.0 * FL_PRODUCT_FLOPS, 6);                                               \
+    ix_prof_begin(stream, 2, 8.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 6) * FL_PRODUCT_FLOPS, 6);              \
     hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);                         \
     ix_prof_end(stream);
     if (hd == 64) {

@@ -1416,7 +1416,7 @@ static int64_t g_launches = 0;
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_ev;
 static size_t g_ev_used = 0;
-struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; double flops = 0.0; };   // bm 2002: a flash attention launch
+struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; double flops = 0.0, mfma_flops = 0.0; };   // bm 2002: a flash attention launch
 static std::vector<ProfRec> g_rec;
 static double g_flash_flops = 0.0;
 static int64_t g_flash_launches = 0;
@@ -1497,6 +1497,33 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
     return IX_OK;
 }
 
+// Profiled flash attention launches by kernel tag (1 forward, 2 backward-q, 3 backward-kv, 4 statistics, 5 second-order q,
+// 6 second-order kv): summed event time (ms), algorithmic FLOPs, FLOPs of the matrix instructions actually issued
+// (3 fp16 terms per product over the head dim, 6 bf16 terms per product over tokens), launches.  Host arrays of 7
+// (index 0 = all tags).  Call before ix_gemm_prof_read (which clears the records).
+extern "C" int ix_prof_flash(double* ms7, double* flops7, double* mfma_flops7, int64_t* launches7) {
+    double ms[7] = {0}, fl[7] = {0}, mf[7] = {0};
+    int64_t n[7] = {0};
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm != 2002 || r.K < 1 || r.K > 6) continue;
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        for (int k = 0; k < 2; ++k) {
+            const int j = k ? r.K : 0;
+            ms[j] += t; fl[j] += r.flops; mf[j] += r.mfma_flops; n[j] += 1;
+        }
+    }
+    for (int k = 0; k < 7; ++k) {
+        if (ms7) ms7[k] = ms[k];
+        if (flops7) flops7[k] = fl[k];
+        if (mfma_flops7) mfma_flops7[k] = mf[k];
+        if (launches7) launches7[k] = n[k];
+    }
+    return IX_OK;
+}
+
 // Executed algorithmic FLOPs and launch count of the flash attention kernels since the last reset (always on).
 extern "C" int ix_flash_stats(double* flops, int64_t* launches, int reset) {
     if (flops) *flops = g_flash_flops;
@@ -1536,11 +1563,12 @@ static inline void prof_mark(hipStream_t stream) {
 
 // The same per-launch event bracket for the flash attention kernels (csrc/flash.hip): kind 2, `flops` = algorithmic
 // (fp32-equivalent) FLOPs of the launch, products = [L, S] x hd products it evaluates (encoded in the record's K).
-void ix_prof_begin(hipStream_t stream, int kind, double flops, int tag) {
+void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops, int tag) {
     if (kind == 2) { g_flash_flops += flops; g_flash_launches += 1; }
     if (!g_prof_on) return;
     ProfRec r = {0, 0, tag, 0, 0, 0, 2000 + kind, 1};
     r.flops = flops;
+    r.mfma_flops = mfma_flops;
     g_rec.push_back(r);
     prof_mark(stream);
 }

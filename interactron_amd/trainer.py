@@ -113,10 +113,12 @@ class FlatOuterStep:
         self.sumsq = torch.zeros((), device=self.flat.params.device, dtype=torch.float32)
         self.max_norm, self.betas, self.eps, self.t = max_norm, betas, eps, 0
 
-    def step(self):
+    def step(self, all_reduce=True):
+        """``all_reduce=False``: the caller has already summed the gradients over the ranks (tests that inspect them)."""
         from . import hipops as ops
         f = self.flat
-        f.all_reduce_grads()
+        if all_reduce:
+            f.all_reduce_grads()
         self.t += 1
         self.sumsq.zero_()
         ops.sumsq_accum(f.grads, self.sumsq)

@@ -139,12 +139,13 @@ def fusion_state_shapes(cfg, style="gpt"):
     lin("prediction_embedding.", d, cfg["BOX_EMB_SIZE"] + c + 5)
     if style == "gpt":
         out["model.pos_emb"] = (1, 255, d)
-        out["model.seq_pos_embed"] = (1, 2060, d)
+        out["model.seq_pos_embed"] = (1, cfg["BLOCK_SIZE"], d)   # (2060 in the shipped configs, reference gpt.py:118-119)
         for i in range(cfg["NUM_LAYERS"]):
             b = "model.blocks.%d." % i
             ln(b + "ln1.")
             ln(b + "ln2.")
-            out[b + "attn.mask"] = (1, 1, cfg["BLOCK_SIZE"], cfg["BLOCK_SIZE"])
+            if cfg["BLOCK_SIZE"] <= 4096:   # all-ones buffer, never read (gpt.py:35-36); at 800x800 it would be 650 MB a layer
+                out[b + "attn.mask"] = (1, 1, cfg["BLOCK_SIZE"], cfg["BLOCK_SIZE"])
             for nm in ("key", "query", "value", "proj"):
                 lin("%sattn.%s." % (b, nm), d, d)
             lin(b + "mlp.0.", 4 * d, d)

@@ -44,13 +44,18 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
     assert err <= 20 * rel * scale + ref_noise + 1e-9, (what, err, scale)
     if "sample" in rec:
-        # element-wise over the strided sample: per element 20 x rel x the tensor's RMS (float32 summation-order noise is
-        # relative to the tensor's scale, not to each element), and the sample as a whole within 4 x rel in L2
+        # 256 values on an even stride over the whole tensor.  Float32 summation-order noise is relative to the tensor's
+        # RMS, not to each element, and in the second-order gradients single elements move discretely (an element of the
+        # clipped inner step or a ReLU on its kink flips -- run to run on the same binary, split-K atomics): so the
+        # sample must agree in L2 within 4 x rel, at most 2 % of its elements may be off by more than 20 x rel x RMS, and
+        # none by more than 100 x rel x RMS.  A slice routed to the wrong place is off by O(RMS) on EVERY element it covers.
         got = g.reshape(-1)[rec["idx"]].double()
         ref = rec["sample"].double()
-        diff = got - ref
-        worst = diff.abs().max().item()
-        assert worst <= 20 * rel * scale + ref_noise + 1e-9, (what, "strided sample", worst, scale)
+        diff = (got - ref).abs()
+        bound = 20 * rel * scale + ref_noise + 1e-9
+        outliers = int((diff > bound).sum())
+        assert outliers <= max(1, len(ref) // 50), (what, "strided sample: elements off", outliers, float(diff.max()), scale)
+        assert float(diff.max()) <= 5 * bound, (what, "strided sample: worst element", float(diff.max()), scale)
         rn = float(ref.norm())
         assert float(diff.norm()) <= 4 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9, \
             (what, "strided sample L2", float(diff.norm()), rn)

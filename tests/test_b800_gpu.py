@@ -1,0 +1,105 @@
+"""The north-star shape (BASELINE.json: 5 x 3x800x800 episodes -> 50x50 = 2500 tokens per frame, fusion T = 12 755): the HIP
+path against the CPU oracle at sizes the oracle finishes in seconds (one 800x800 frame through the detector; the fusion on
+two frames' worth of tokens, T = 5105), and size-independent properties of one FULL 5-frame 800x800 meta-train step.
+``pytest -m gpu``."""
+import random
+
+import pytest
+import torch
+
+from interactron_amd.synthetic import load_procedural, procedural_state_dict, synthetic_episodes
+from tests.test_parity_gpu import MODEL_CFG, to_gpu
+
+pytestmark = pytest.mark.gpu
+
+CFG800 = dict(MODEL_CFG, BLOCK_SIZE=5 * (2500 + 50) + 5)
+
+
+def _close(a, b, what):
+    tol = 1e-3 * float(b.abs().max()) + 1e-4    # the forward tolerance of tests/test_parity_gpu.py
+    torch.testing.assert_close(a.detach().cpu(), b, atol=tol, rtol=1e-3, msg=lambda m: what + ": " + m)
+
+
+def test_detector_800x800_frame_against_oracle():
+    from interactron_amd import Config, NestedTensor, build_model
+    from oracle import detector as od
+    m = build_model(Config(**dict(MODEL_CFG, TYPE="detr"))).cuda().eval()
+    data = synthetic_episodes(1, frames=1, height=800, width=800, tag="b800-det")
+    frames, masks = data["frames"][0], data["masks"][0]
+    with torch.no_grad():
+        out = m.model(NestedTensor(frames.cuda(), masks.cuda()))
+    assert out["embedded_memory_features"].shape == (1, 256, 50, 50) and out["pred_logits"].shape == (1, 50, 1236)
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+    with torch.no_grad():
+        ref = od.detr_forward(det, frames, masks)
+    for k, v in ref.items():
+        _close(out[k], v, "detector@800/" + k)
+
+
+def test_fusion_two_800x800_frames_against_oracle():
+    """GPT fusion with the 12 755-entry position table on the tokens of two 800x800 frames (T = 2 * 2550 + 5 = 5105)."""
+    from interactron_amd import Config, build_model
+    from interactron_amd.synthetic import hash_normal, hash_uniform
+    from oracle import fusion as of
+    import numpy as np
+    m = build_model(Config(**dict(CFG800, TYPE="interactron")))
+    assert m.fusion.model.seq_pos_embed.shape == (1, 12755, 512)
+    load_procedural(m.fusion, "fusion.")
+    fusion = m.fusion.cuda().eval()
+    t = lambda name, shape, scale=1.0: torch.from_numpy((hash_normal("b800/" + name, int(np.prod(shape))) * scale)
+                                                         .astype(np.float32)).reshape(shape)
+    x = {"embedded_memory_features": t("mem", (1, 2, 256, 50, 50)), "box_features": t("box", (1, 2, 50, 256)),
+         "pred_logits": t("logits", (1, 2, 50, 1236), 2.0),
+         "pred_boxes": torch.from_numpy(hash_uniform("b800/pb", 400, 0.1, 0.9).astype(np.float32)).reshape(1, 2, 50, 4)}
+    with torch.no_grad():
+        out = fusion({k: v.cuda() for k, v in x.items()})
+    sd = {k[len("fusion."):]: v for k, v in
+          procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(CFG800, "gpt").items()}).items()}
+    with torch.no_grad():
+        ref = of.fusion_gpt_forward(sd, x, CFG800)
+    for k in ("loss", "actions", "pred_boxes", "pred_logits"):
+        _close(out[k].reshape(ref[k].shape), ref[k], "fusion@T5105/" + k)
+
+
+def test_full_800x800_meta_train_step_properties(golden):
+    """One complete 5-frame 800x800 meta-train step (T = 12 755, encoder rows of 2500 tokens): everything finite, shapes
+    and None-pattern as at 300x300, and gradients ACCUMULATE -- a second identical pass doubles every .grad (the
+    reference sums over the tasks of a batch, models/interactron.py:123,134) -- the size-independent check that no part
+    of a gradient is dropped or written twice at this size."""
+    from interactron_amd import Config, build_model
+    m = build_model(Config(**dict(CFG800, TYPE="interactron", EPISODE_CHUNK=1)))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().eval()
+    assert m.fusion.model.block_size == 12755
+    data = to_gpu(synthetic_episodes(1, height=800, width=800, tag="b800-step"))
+    m.zero_grad()
+    random.seed(5)
+    preds, losses = m(data)
+    assert preds["pred_logits"].shape == (1, 1, 50, 1236) and preds["pred_boxes"].shape == (1, 1, 50, 4)
+    assert len(losses) >= 10 and all(bool(torch.isfinite(v).all()) for v in losses.values())
+    first = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    # None-pattern as at 300x300 (fixture G13): frozen tensors and the never-used fusion.model.pos_emb stay None
+    T = golden("golden_train.pt")["g13"]
+    ref_none = {"detector." + k: v is None for k, v in T["detector_grads"].items()}
+    ref_none.update({"fusion." + k: v is None for k, v in T["fusion_grads"].items()})
+    for k in first:
+        if k != "fusion.model.seq_pos_embed":   # (same tensor, longer table)
+            assert (first[k] is None) == ref_none[k], k
+    have = [k for k in trainable if first[k] is not None]
+    assert all(bool(torch.isfinite(first[k]).all()) for k in have)
+    assert sum(float(first[k].double().norm()) > 0 for k in have) > 0.9 * len(have)
+    random.seed(5)
+    m(data)
+    tot1 = tot2 = 0.0
+    for k in have:
+        n1 = float(first[k].double().norm())
+        n2 = float(m.get_parameter(k).grad.double().norm())
+        tot1, tot2 = tot1 + n1 * n1, tot2 + n2 * n2
+        if n1 < 1e-6:
+            continue
+        # per tensor: within float32 run-to-run noise of the second-order path (a few % on the smallest gradients: split-K
+        # atomics, elements on the clip / ReLU kinks); a part dropped or written twice is off by 50 % or more
+        assert abs(n2 - 2 * n1) <= 0.1 * 2 * n1, (k, n1, n2)
+    assert abs(tot2 ** 0.5 - 2 * tot1 ** 0.5) <= 1e-2 * 2 * tot1 ** 0.5, (tot1 ** 0.5, tot2 ** 0.5)
