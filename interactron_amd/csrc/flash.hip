@@ -32,7 +32,6 @@
 //   tr  layout  [3 planes][batch*head][hd][Rp]   bf16   rows permuted within 16-groups          (contraction over rows)
 //   Rp = R rounded up to 128 (zero rows); keys are walked in tiles of 32 up to ceil(S / 32) * 32.
 #include "common.h"
-#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -218,46 +217,42 @@ struct FlSeg {
     static __device__ __forceinline__ int tr_dst(int c) { return (c >> 2) * TROW + (c & 3) * 16; }
 };
 
-// Staging registers as a compile-time list (no arrays: an indexed array of in-flight loads is easily demoted to scratch
-// memory or to an LDS copy by the compiler), visited with compile-time indices.
-template <int N>
-struct FlRegs {
-    uint4 v;
-    FlRegs<N - 1> r;
-};
-template <>
-struct FlRegs<0> {};
-template <int I, int N, class F>
-__device__ __forceinline__ void fl_each(FlRegs<N>& s, F&& f) {
-    f(std::integral_constant<int, I>(), s.v);
-    if constexpr (N > 1) fl_each<I + 1>(s.r, f);
-}
+// Staging registers: twelve plain named variables per list (FL_DECL_REGS), visited by macro expansion with literal
+// indices.  (Neither an indexed array nor a struct of registers survives here: the compiler keeps either in scratch
+// memory as soon as a value is loaded before a barrier and stored to LDS after it, and a load whose destination is in
+// scratch is waited for on the spot -- every staging load then costs a full memory round trip.)
+#define FL_DECL_REGS(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8, P##9, P##10, P##11;
 // global -> staging registers (requested early) -> LDS (after the barrier that frees the destination) for the units
-// FIRST .. FIRST + COUNT - 1 of a tile whose first NROW segments are row segments (2 units each) followed by tr
-// segments (3 units each).  One chunk per thread and unit at HD 64, two units per pass at HD 32 (an odd unit out is
+// FIRST .. FIRST + COUNT - 1 (COUNT <= 12) of a tile whose first NROW segments are row segments (2 units each) followed
+// by tr segments (3 units each).  One chunk per thread and unit at HD 64, two units per pass at HD 32 (an odd unit out is
 // copied twice).  SRC / DST are expressions in seg_ (segment), pl_ (plane), c_ (chunk).
 #define FL_NREGS(COUNT) (HD == 64 ? (COUNT) : ((COUNT) + 1) / 2)
-#define FL_UNIT_DECODE(FIRST, COUNT, NROW)                                                                             \
-    constexpr int i_ = decltype(I_)::value;                                                                            \
-    const int u_ = (FIRST) + (HD == 64 ? i_ : min(2 * i_ + (tid >> 7), (COUNT) - 1));                                  \
+#define FL_UNIT_DECODE(I, FIRST, COUNT, NROW)                                                                          \
+    const int u_ = (FIRST) + (HD == 64 ? (I) : min(2 * (I) + (tid >> 7), (COUNT) - 1));                                \
     const int c_ = HD == 64 ? tid : (tid & 127);                                                                       \
     const bool isrow_ = u_ < 2 * (NROW);                                                                               \
     const int seg_ = isrow_ ? u_ / 2 : (NROW) + (u_ - 2 * (NROW)) / 3, pl_ = isrow_ ? u_ % 2 : (u_ - 2 * (NROW)) % 3;  \
     (void)isrow_;
-#define FL_STAGE_LOAD(REGS, FIRST, COUNT, NROW, SRC)                                                                   \
-    fl_each<0>(REGS, [&](auto I_, uint4& v_) {                                                                          \
-        if constexpr (decltype(I_)::value < FL_NREGS(COUNT)) {   /* (a register list may serve a shorter unit range) */  \
-            FL_UNIT_DECODE(FIRST, COUNT, NROW)                                                                         \
-            v_ = *reinterpret_cast<const uint4*>(SRC);                                                                 \
-        }                                                                                                              \
-    });
-#define FL_STAGE_STORE(REGS, FIRST, COUNT, NROW, DST)                                                                  \
-    fl_each<0>(REGS, [&](auto I_, uint4& v_) {                                                                          \
-        if constexpr (decltype(I_)::value < FL_NREGS(COUNT)) {                                                         \
-            FL_UNIT_DECODE(FIRST, COUNT, NROW)                                                                         \
-            *reinterpret_cast<uint4*>(DST) = v_;                                                                       \
-        }                                                                                                              \
-    });
+#define FL_LOAD1(P, I, FIRST, COUNT, NROW, SRC)                                                                        \
+    if ((I) < FL_NREGS(COUNT)) {                                                                                       \
+        FL_UNIT_DECODE(I, FIRST, COUNT, NROW)                                                                          \
+        P##I = *reinterpret_cast<const uint4*>(SRC);                                                                   \
+    }
+#define FL_STORE1(P, I, FIRST, COUNT, NROW, DST)                                                                       \
+    if ((I) < FL_NREGS(COUNT)) {                                                                                       \
+        FL_UNIT_DECODE(I, FIRST, COUNT, NROW)                                                                          \
+        *reinterpret_cast<uint4*>(DST) = P##I;                                                                         \
+    }
+#define FL_STAGE_LOAD(P, FIRST, COUNT, NROW, SRC)                                                                      \
+    FL_LOAD1(P, 0, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 1, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 2, FIRST, COUNT, NROW, SRC)   \
+    FL_LOAD1(P, 3, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 4, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 5, FIRST, COUNT, NROW, SRC)   \
+    FL_LOAD1(P, 6, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 7, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 8, FIRST, COUNT, NROW, SRC)   \
+    FL_LOAD1(P, 9, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 10, FIRST, COUNT, NROW, SRC) FL_LOAD1(P, 11, FIRST, COUNT, NROW, SRC)
+#define FL_STAGE_STORE(P, FIRST, COUNT, NROW, DST)                                                                     \
+    FL_STORE1(P, 0, FIRST, COUNT, NROW, DST) FL_STORE1(P, 1, FIRST, COUNT, NROW, DST) FL_STORE1(P, 2, FIRST, COUNT, NROW, DST) \
+    FL_STORE1(P, 3, FIRST, COUNT, NROW, DST) FL_STORE1(P, 4, FIRST, COUNT, NROW, DST) FL_STORE1(P, 5, FIRST, COUNT, NROW, DST) \
+    FL_STORE1(P, 6, FIRST, COUNT, NROW, DST) FL_STORE1(P, 7, FIRST, COUNT, NROW, DST) FL_STORE1(P, 8, FIRST, COUNT, NROW, DST) \
+    FL_STORE1(P, 9, FIRST, COUNT, NROW, DST) FL_STORE1(P, 10, FIRST, COUNT, NROW, DST) FL_STORE1(P, 11, FIRST, COUNT, NROW, DST)
 
 // three-term product of one k-slice on fp16 planes (h, l): acc += A . B, smallest terms first
 #define FL_MMA3(ACC, A, B) \
@@ -365,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     float m = -1e30f, l = 0.f;
     const unsigned rid = (unsigned)(bh * p.L + q0 + lq);
 
-    FlRegs<FL_NREGS(NU)> sv;
+    FL_DECL_REGS(sv)
 #define FLF_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.k_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
                : p.v_tr + kto + pl_ * p.k_plane + (T0) + G::tr_src(c_, p.Sp))
@@ -512,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) gq[db][r] = 0.f;
 
-    FlRegs<FL_NREGS(NU)> sv;
+    FL_DECL_REGS(sv)
 #define FLQ_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.k_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
    : seg_ == 1 ? p.v_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
@@ -597,7 +592,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gk[db][r] = 0.f; gv[db][r] = 0.f; }
 
-    FlRegs<FL_NREGS(NU)> sv;
+    FL_DECL_REGS(sv)
     float sst = 0.f;   // staged statistic: threads 0..31 carry lse, 32..63 delta of the next tile
 #define FLK_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.q_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
@@ -691,7 +686,10 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
     // row segments k, hk, v, hv; then (pass 2) tr segments hk, k, hv, v
     constexpr int OFF_K = 0, OFF_HK = G::RBYTES, OFF_V = 2 * G::RBYTES, OFF_HV = 3 * G::RBYTES;
     constexpr int OFF_HKT = 4 * G::RBYTES, OFF_KT = OFF_HKT + G::TBYTES, OFF_HVT = OFF_KT + G::TBYTES, OFF_VT = OFF_HVT + G::TBYTES;
-    constexpr int BYTES = STATS ? 4 * G::RBYTES : 4 * G::RBYTES + 4 * G::TBYTES;
+    // pass 2 also keeps the dO rows of each wave's 32 queries resident behind the tile (their B fragments are read from
+    // LDS per k-slice: 32 registers fewer, which is what keeps the staging loads out of scratch memory)
+    constexpr int OFF_RES = 4 * G::RBYTES + 4 * G::TBYTES;
+    constexpr int BYTES = STATS ? 4 * G::RBYTES : OFF_RES + 4 * G::RBYTES;
     constexpr int NBUF = STATS ? 2 : 1, NROW = 4, NUR = 8, NUT = 12;
     __shared__ __attribute__((aligned(16))) unsigned char ldsq[NBUF][BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -702,10 +700,19 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
     const int64_t kro = (int64_t)bh * p.Sp * HD, kto = (int64_t)bh * HD * p.Sp, kbo = (int64_t)bh * (p.Sp / 32);
     const float* bias = p.bias + (int64_t)b * p.Sp;
 
-    u32x4 qf[NKS][2], hqf[NKS][2], df[NKS][2];
+    u32x4 qf[NKS][2], hqf[NKS][2], df[STATS ? NKS : 1][2];
     FL_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a, p.q_plane)
     FL_BFRAGS(hqf, p.hq_row, ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a, p.q_plane)
-    FL_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a, p.q_plane)
+    const int res = OFF_RES + wave * G::RBYTES;
+    if (STATS) {
+        FL_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a, p.q_plane)
+    } else {
+        for (int c = lane; c < 2 * 4 * HD; c += 64) {   // 2 planes x (32 rows x HD fp16 = 4 HD chunks)
+            const int pl = c / (4 * HD), ch = c % (4 * HD);
+            const unsigned short* src = p.do_row + pl * p.q_plane + ((int64_t)bh * p.Lp + q0) * HD + G::row_src(ch);
+            *reinterpret_cast<uint4*>(ldsq[0] + res + pl * G::RPLANE + G::row_dst(ch)) = *reinterpret_cast<const uint4*>(src);
+        }
+    }
     const int64_t qb = (int64_t)bh * (p.Lp / 32) + q0 / 32;
     const float usq = p.q_us[qb], usd = p.do_us[qb], ushq = p.hq_us[qb];
     const int64_t so = (int64_t)bh * p.Lp + q0 + lq;
@@ -719,7 +726,8 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq[db][r] = 0.f; ddo[db][r] = 0.f; }
 
-    FlRegs<FL_NREGS(STATS ? NUR : NUT)> sv;
+    FL_DECL_REGS(sv)    // row units (phase 1)
+    FL_DECL_REGS(svt)   // tr units (phase 2)
 #define FLB_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.k_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
    : seg_ == 1 ? p.hk_row + kro + pl_ * p.k_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
@@ -735,8 +743,8 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
     FL_STAGE_LOAD(sv, 0, NUR, NROW, FLB_SRC(0))
     FL_STAGE_STORE(sv, 0, NUR, NROW, FLB_DST(ldsq[0]))
     if (!STATS) {
-        FL_STAGE_LOAD(sv, NUR, NUT, NROW, FLB_SRC(0))
-        FL_STAGE_STORE(sv, NUR, NUT, NROW, FLB_DST(ldsq[0]))
+        FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLB_SRC(0))
+        FL_STAGE_STORE(svt, NUR, NUT, NROW, FLB_DST(ldsq[0]))
     }
     __syncthreads();
 
@@ -755,15 +763,16 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; gd[r] = 0.f; g1[r] = 0.f; g2[r] = 0.f; hd_[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            u32x4 kf[2], hkf[2], vf[2], hvf[2];
+            u32x4 kf[2], hkf[2], vf[2], hvf[2], dfl[2];
             FL_ROWFRAG(kf, lds, OFF_K, lq, ks)
             FL_ROWFRAG(hkf, lds, OFF_HK, lq, ks)
             FL_ROWFRAG(vf, lds, OFF_V, lq, ks)
             FL_ROWFRAG(hvf, lds, OFF_HV, lq, ks)
+            if (STATS) { dfl[0] = df[STATS ? ks : 0][0]; dfl[1] = df[STATS ? ks : 0][1]; } else { FL_ROWFRAG(dfl, lds, res, lq, ks) }
             FL_MMA3(s, kf, qf[ks])
-            FL_MMA3(gd, vf, df[ks])
+            FL_MMA3(gd, vf, dfl)
             FL_MMA3(g1, kf, hqf[ks])
-            FL_MMA3(hd_, hvf, df[ks])
+            FL_MMA3(hd_, hvf, dfl)
             FL_MMA3(g2, hkf, qf[ks])
         }
         float pr[16], mk[16];
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
         } else {
             __syncthreads();   // (A) every wave has formed its tiles: the ROW region is free, the TR region is complete
             FL_STAGE_STORE(sv, 0, NUR, NROW, FLB_DST(lds))
-            FL_STAGE_LOAD(sv, NUR, NUT, NROW, FLB_SRC(tn))
+            FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLB_SRC(tn))
             float x[16];
             u32x4 pp[2][3];
             // gs = P (gy - t)                                   dq += hk^T gs
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
             FL_SPLIT16(pp, x)
             FL_STAGE2(ddo, lds, OFF_VT, lq, pp)
             __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
-            FL_STAGE_STORE(sv, NUR, NUT, NROW, FLB_DST(lds))
+            FL_STAGE_STORE(svt, NUR, NUT, NROW, FLB_DST(lds))
         }
     }
 #undef FLB_SRC
@@ -848,7 +857,9 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
     // row segments q, hq, dO; tr segments hq, q, dO; statistics lse, delta, u, w [32] each (part of the TR phase)
     constexpr int OFF_Q = 0, OFF_HQ = G::RBYTES, OFF_D = 2 * G::RBYTES;
     constexpr int OFF_HQT = 3 * G::RBYTES, OFF_QT = OFF_HQT + G::TBYTES, OFF_DT = OFF_QT + G::TBYTES, OFF_ST = OFF_DT + G::TBYTES;
-    constexpr int BYTES = OFF_ST + 512, NROW = 3, NUR = 6, NUT = 9;
+    // + resident: the hk and hv rows of each wave's 32 keys (their B fragments are read from here per k-slice instead of
+    // living in 64 registers: with them in registers the staging loads spill, and a spilled in-flight load is waited for)
+    constexpr int OFF_RES = OFF_ST + 512, BYTES = OFF_RES + 4 * 2 * G::RBYTES, NROW = 3, NUR = 6, NUT = 9;
     __shared__ __attribute__((aligned(16))) unsigned char lds[BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane & 31, a = lane >> 5;
@@ -857,11 +868,15 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
     const int ntiles = (p.L + 31) / 32;
     const int64_t qro = (int64_t)bh * p.Lp * HD, qto = (int64_t)bh * HD * p.Lp, sto = (int64_t)bh * p.Lp, qbo = (int64_t)bh * (p.Lp / 32);
 
-    u32x4 kf[NKS][2], hkf[NKS][2], vf[NKS][2], hvf[NKS][2];
+    u32x4 kf[NKS][2], vf[NKS][2];
     FL_BFRAGS(kf, p.k_row, ((int64_t)bh * p.Sp + k0 + lk) * HD + 8 * a, p.k_plane)
-    FL_BFRAGS(hkf, p.hk_row, ((int64_t)bh * p.Sp + k0 + lk) * HD + 8 * a, p.k_plane)
     FL_BFRAGS(vf, p.v_row, ((int64_t)bh * p.Sp + k0 + lk) * HD + 8 * a, p.k_plane)
-    FL_BFRAGS(hvf, p.hv_row, ((int64_t)bh * p.Sp + k0 + lk) * HD + 8 * a, p.k_plane)
+    const int res = OFF_RES + wave * 2 * G::RBYTES;   // this wave's resident rows: hk then hv, row-segment layout
+    for (int c = lane; c < 2 * 2 * 4 * HD; c += 64) {   // 2 tensors x 2 planes x (32 rows x HD fp16 = 4 HD chunks)
+        const int tsr = c / (2 * 4 * HD), pl = (c / (4 * HD)) & 1, ch = c % (4 * HD);
+        const unsigned short* src = (tsr ? p.hv_row : p.hk_row) + pl * p.k_plane + ((int64_t)bh * p.Sp + k0) * HD + G::row_src(ch);
+        *reinterpret_cast<uint4*>(lds + res + tsr * G::RBYTES + pl * G::RPLANE + G::row_dst(ch)) = *reinterpret_cast<const uint4*>(src);
+    }
     const int64_t kbk = (int64_t)bh * (p.Sp / 32) + k0 / 32;
     const float usk = p.k_us[kbk], ushk = p.hk_us[kbk], usv = p.v_us[kbk], ushv = p.hv_us[kbk];
     const float kbias = p.bias[(int64_t)b * p.Sp + k0 + lk];
@@ -872,7 +887,8 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
-    FlRegs<FL_NREGS(NUT)> sv;
+    FL_DECL_REGS(sv)    // row units (phase 1)
+    FL_DECL_REGS(svt)   // tr units (phase 2)
     float sst = 0.f;   // staged statistics: threads 0..127 carry lse | delta | u | w of the next tile
 #define FLC_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.q_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
@@ -891,9 +907,9 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
     }
     FL_STAGE_LOAD(sv, 0, NUR, NROW, FLC_SRC(0))
     FL_STAGE_STORE(sv, 0, NUR, NROW, FLC_DST)
-    FL_STAGE_LOAD(sv, NUR, NUT, NROW, FLC_SRC(0))
+    FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLC_SRC(0))
     FLC_STAT_LOAD(0)
-    FL_STAGE_STORE(sv, NUR, NUT, NROW, FLC_DST)
+    FL_STAGE_STORE(svt, NUR, NUT, NROW, FLC_DST)
     if (tid < 128) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
     __syncthreads();
 
@@ -907,19 +923,21 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; gd[r] = 0.f; g1[r] = 0.f; g2[r] = 0.f; hd_[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            u32x4 qa[2], hqa[2], da[2];
+            u32x4 qa[2], hqa[2], da[2], hkf[2], hvf[2];
             FL_ROWFRAG(qa, lds, OFF_Q, lk, ks)
             FL_ROWFRAG(hqa, lds, OFF_HQ, lk, ks)
             FL_ROWFRAG(da, lds, OFF_D, lk, ks)
+            FL_ROWFRAG(hkf, lds, res, lk, ks)
+            FL_ROWFRAG(hvf, lds, res + G::RBYTES, lk, ks)
             FL_MMA3(s, qa, kf[ks])
             FL_MMA3(gd, da, vf[ks])
             FL_MMA3(g1, hqa, kf[ks])
-            FL_MMA3(hd_, da, hvf[ks])
-            FL_MMA3(g2, qa, hkf[ks])
+            FL_MMA3(hd_, da, hvf)
+            FL_MMA3(g2, qa, hkf)
         }
         __syncthreads();   // (A) the ROW region is free, the TR region (and the statistics) are complete
         FL_STAGE_STORE(sv, 0, NUR, NROW, FLC_DST)
-        FL_STAGE_LOAD(sv, NUR, NUT, NROW, FLC_SRC(tn))
+        FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLC_SRC(tn))
         FLC_STAT_LOAD(tn)
         // statistics of this lane's 16 queries: register r <-> query t0 + (r & 3) + 8 (r >> 2) + 4 a; read per use
 #define FLC_ST(WHICH, R) (reinterpret_cast<const float*>(lds + OFF_ST + (WHICH) * 128)[((R) & 3) + 8 * ((R) >> 2) + 4 * a])
@@ -954,7 +972,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
         FL_STAGE2(dv, lds, OFF_DT, lk, pp)
 #undef FLC_ST
         __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
-        FL_STAGE_STORE(sv, NUR, NUT, NROW, FLC_DST)
+        FL_STAGE_STORE(svt, NUR, NUT, NROW, FLC_DST)
         if (tid < 128) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
     }
 #undef FLC_SRC
