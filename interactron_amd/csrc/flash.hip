@@ -315,20 +315,24 @@ struct FlashArgs {
     unsigned seed_lo, seed_hi;
 };
 
-// dropout factors (1/keep or 0) of the 16 accumulator registers of a tile whose lane holds ONE row id and whose
-// registers walk the OTHER index in accumulator order (PAIRS: registers 2i, 2i+1 are the two keys of one hash)
+// dropout keep flags of the 16 accumulator registers of a tile whose lane holds ONE row id and whose registers walk the
+// OTHER index in accumulator order (PAIRS: registers 2i, 2i+1 are the two keys of one hash).  bool, not float: the
+// sixteen flags live as lane masks in scalar register pairs instead of sixteen vector registers.
+// FL_M(r, x) = M_r x (the mask with its 1/keep);  FL_K(r, x) = x where kept, 0 where dropped (1/keep applied elsewhere)
+#define FL_M(R, X) (DROP ? (kp[R] ? (X) * p.inv_keep : 0.f) : (X))
+#define FL_K(R, X) (DROP ? (kp[R] ? (X) : 0.f) : (X))
 #define FL_MASK_KEYS_IN_REGS(MK, RID, T0)                                                                              \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                 \
         const int key_ = (T0) + ((2 * i_) & 3) + 8 * ((2 * i_) >> 2) + 4 * a;                                          \
         const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (RID), (unsigned)key_ >> 1);                               \
-        MK[2 * i_] = (hsh_ & 0xffffu) >= p.thr16 ? p.inv_keep : 0.f;                                                   \
-        MK[2 * i_ + 1] = (hsh_ >> 16) >= p.thr16 ? p.inv_keep : 0.f;                                                   \
+        MK[2 * i_] = (hsh_ & 0xffffu) >= p.thr16;                                                                      \
+        MK[2 * i_ + 1] = (hsh_ >> 16) >= p.thr16;                                                                      \
     }
 #define FL_MASK_QUERIES_IN_REGS(MK, KEY, T0)                                                                           \
     _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                                                \
         const int q_ = (T0) + (r_ & 3) + 8 * (r_ >> 2) + 4 * a;                                                        \
         const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q_), (unsigned)(KEY) >> 1);          \
-        MK[r_] = (((KEY) & 1) ? (hsh_ >> 16) : (hsh_ & 0xffffu)) >= p.thr16 ? p.inv_keep : 0.f;                        \
+        MK[r_] = (((KEY) & 1) ? (hsh_ >> 16) : (hsh_ & 0xffffu)) >= p.thr16;                                           \
     }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -416,10 +420,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
         if (DROP) {
-            float mk[16];
-            FL_MASK_KEYS_IN_REGS(mk, rid, t0)
+            bool kp[16];
+            FL_MASK_KEYS_IN_REGS(kp, rid, t0)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = mk[r] != 0.f ? x[r] : 0.f;   // (1 / keep is applied once, to O)
+            for (int r = 0; r < 16; ++r) x[r] = kp[r] ? x[r] : 0.f;   // (1 / keep is applied once, to O)
         }
         // ---- O^T[d, query] += V^T[d, key] . P^T[key, query] ----
         u32x4 pp[2][3];
@@ -539,13 +543,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
             FL_MMA3(gd, vf, df[ks])
         }
         // ---- gs = P o (M o gd - t) ----
-        float x[16], mk[16];
+        float x[16];
+        bool kp[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = 1.f;
-        if (DROP) { FL_MASK_KEYS_IN_REGS(mk, rid, t0) }
+        for (int r = 0; r < 16; ++r) kp[r] = true;
+        if (DROP) { FL_MASK_KEYS_IN_REGS(kp, rid, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            x[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2) * (gd[r] * cg * mk[r] - dl);
+            x[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2) * (FL_M(r, gd[r] * cg) - dl);
         u32x4 pp[2][3];
         FL_SPLIT16(pp, x)
         // ---- gQ^T[d, query] += K^T[d, key] gs^T[key, query] ----
@@ -563,13 +568,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
 }
 
 // ---- key-owning workgroup: gK (o2), gV (o3); tiles oriented [query, key]: lane = key, registers = queries ------------
+// One LDS buffer, two phases per tile (as the second-order passes below): the ROW region (q, dO rows) feeds the two
+// [query, key] tiles while the next tile's rows are in flight, the TR region (q, dO transposed + lse, delta) feeds the two
+// output products while the next tile's tr operands are in flight.  49 KB of LDS and <= 256 registers: two workgroups per CU.
 template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     constexpr int OFF_Q = 0, OFF_D = G::RBYTES, OFF_QT = 2 * G::RBYTES, OFF_DT = 2 * G::RBYTES + G::TBYTES;
-    constexpr int OFF_ST = 2 * G::RBYTES + 2 * G::TBYTES, BYTES = OFF_ST + 256, NU = 10, NROW = 2;   // + lse[32], delta[32]
-    __shared__ __attribute__((aligned(16))) unsigned char ldsb[2][BYTES];
+    constexpr int OFF_ST = 2 * G::RBYTES + 2 * G::TBYTES, BYTES = OFF_ST + 256, NROW = 2, NUR = 4, NUT = 6;   // + lse[32], delta[32]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane & 31, a = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
@@ -592,29 +600,30 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gk[db][r] = 0.f; gv[db][r] = 0.f; }
 
-    FL_DECL_REGS(sv)
-    float sst = 0.f;   // staged statistic: threads 0..31 carry lse, 32..63 delta of the next tile
+    FL_DECL_REGS(sv)    // row units (phase 1)
+    FL_DECL_REGS(svt)   // tr units (phase 2)
+    float sst = 0.f;    // staged statistic: threads 0..31 carry lse, 32..63 delta of the next tile
 #define FLK_SRC(T0)                                                                                                    \
     (seg_ == 0 ? p.q_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                                \
    : seg_ == 1 ? p.do_row + qro + pl_ * p.q_plane + (int64_t)(T0) * HD + G::row_src(c_)                               \
    : seg_ == 2 ? p.q_tr + qto + pl_ * p.q_plane + (T0) + G::tr_src(c_, p.Lp)                                           \
                : p.do_tr + qto + pl_ * p.q_plane + (T0) + G::tr_src(c_, p.Lp))
-#define FLK_DST(BUF)                                                                                                   \
-    (seg_ < 2 ? (BUF) + seg_ * G::RBYTES + pl_ * G::RPLANE + G::row_dst(c_)                                            \
-              : (BUF) + 2 * G::RBYTES + (seg_ - 2) * G::TBYTES + pl_ * G::TPLANE + G::tr_dst(c_))
+#define FLK_DST                                                                                                        \
+    (seg_ < 2 ? lds + seg_ * G::RBYTES + pl_ * G::RPLANE + G::row_dst(c_)                                              \
+              : lds + 2 * G::RBYTES + (seg_ - 2) * G::TBYTES + pl_ * G::TPLANE + G::tr_dst(c_))
 #define FLK_STAT_LOAD(T0) if (tid < 64) sst = tid < 32 ? p.lse[sto + (T0) + tid] : p.delta[sto + (T0) + tid - 32];
-    FL_STAGE_LOAD(sv, 0, NU, NROW, FLK_SRC(0))
+    FL_STAGE_LOAD(sv, 0, NUR, NROW, FLK_SRC(0))
+    FL_STAGE_STORE(sv, 0, NUR, NROW, FLK_DST)
+    FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLK_SRC(0))
     FLK_STAT_LOAD(0)
-    FL_STAGE_STORE(sv, 0, NU, NROW, FLK_DST(ldsb[0]))
-    if (tid < 64) reinterpret_cast<float*>(ldsb[0] + OFF_ST)[tid] = sst;
+    FL_STAGE_STORE(svt, NUR, NUT, NROW, FLK_DST)
+    if (tid < 64) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        unsigned char* lds = ldsb[t & 1];
         const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
         const float cs = c2 * qus[t], cg = usv * dus[t];
-        FL_STAGE_LOAD(sv, 0, NU, NROW, FLK_SRC(tn))
-        FLK_STAT_LOAD(tn)
+        FL_STAGE_LOAD(sv, 0, NUR, NROW, FLK_SRC(tn))
         // ---- S[query, key] = Q K^T and gd = dO V^T ----
         f32x16 s, gd;
 #pragma unroll
@@ -627,17 +636,22 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
             FL_MMA3(s, qa, kf[ks])
             FL_MMA3(gd, da, vf[ks])
         }
+        __syncthreads();   // (A) the ROW region is free, the TR region (and the statistics) are complete
+        FL_STAGE_STORE(sv, 0, NUR, NROW, FLK_DST)
+        FL_STAGE_LOAD(svt, NUR, NUT, NROW, FLK_SRC(tn))
+        FLK_STAT_LOAD(tn)
         // statistics of this lane's 16 queries: register r <-> query t0 + (r & 3) + 8 (r >> 2) + 4 a
 #define FLK_ST(WHICH, R) (reinterpret_cast<const float*>(lds + OFF_ST + (WHICH) * 128)[((R) & 3) + 8 * ((R) >> 2) + 4 * a])
-        float pd[16], gs[16], mk[16];
+        float pd[16], gs[16];
+        bool kp[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mk[r] = 1.f;
-        if (DROP) { FL_MASK_QUERIES_IN_REGS(mk, key, t0) }
+        for (int r = 0; r < 16; ++r) kp[r] = true;
+        if (DROP) { FL_MASK_QUERIES_IN_REGS(kp, key, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float pr = fl_exp2(s[r] * cs + kbias - FLK_ST(0, r) * FL_LOG2E);
-            pd[r] = mk[r] != 0.f ? pr : 0.f;                              // (x 1/keep at the end, on gV)
-            gs[r] = pr * (gd[r] * cg * mk[r] - FLK_ST(1, r));
+            pd[r] = FL_K(r, pr);                                          // (x 1/keep at the end, on gV)
+            gs[r] = pr * (FL_M(r, gd[r] * cg) - FLK_ST(1, r));
         }
 #undef FLK_ST
         // ---- gV^T[d, key] += dO^T[d, query] Pd[query, key];  gK^T[d, key] += Q^T[d, query] gs[query, key] ----
@@ -646,9 +660,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kv_kernel(FlashArgs p) {
         FL_STAGE2(gv, lds, OFF_DT, lk, pp)
         FL_SPLIT16(pp, gs)
         FL_STAGE2(gk, lds, OFF_QT, lk, pp)
-        FL_STAGE_STORE(sv, 0, NU, NROW, FLK_DST(ldsb[(t + 1) & 1]))
-        if (tid < 64) reinterpret_cast<float*>(ldsb[(t + 1) & 1] + OFF_ST)[tid] = sst;
-        __syncthreads();
+        __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
+        FL_STAGE_STORE(svt, NUR, NUT, NROW, FLK_DST)
+        if (tid < 64) reinterpret_cast<float*>(lds + OFF_ST)[tid] = sst;
     }
 #undef FLK_SRC
 #undef FLK_DST
@@ -775,23 +789,25 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
             FL_MMA3(hd_, hvf, dfl)
             FL_MMA3(g2, hkf, qf[ks])
         }
-        float pr[16], mk[16];
+        float pr[16];
+        bool kp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kp[r] = true;
+        if (DROP) { FL_MASK_KEYS_IN_REGS(kp, rid, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             pr[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2);
-            mk[r] = 1.f;
             g1[r] = g1[r] * c1 + g2[r] * c3;   // G
-            gd[r] *= cg;
-            hd_[r] *= ch;
+            gd[r] = FL_M(r, gd[r] * cg);       // gy = M o gd
+            hd_[r] = FL_M(r, hd_[r] * ch);     // M o HD
         }
-        if (DROP) { FL_MASK_KEYS_IN_REGS(mk, rid, t0) }
         if (STATS) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float gy = mk[r] * gd[r], pg = pr[r] * g1[r];
+                const float pg = pr[r] * g1[r];
                 uu += pg;
-                aa += pg * gy;
-                bq += pr[r] * mk[r] * hd_[r];
+                aa += pg * gd[r];
+                bq += pr[r] * hd_[r];
             }
             FL_STAGE_STORE(sv, 0, NUR, NROW, FLB_DST(ldsq[(t + 1) & 1]))
             __syncthreads();
@@ -803,25 +819,22 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
             u32x4 pp[2][3];
             // gs = P (gy - t)                                   dq += hk^T gs
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = pr[r] * (mk[r] * gd[r] - dl);
+            for (int r = 0; r < 16; ++r) x[r] = pr[r] * (gd[r] - dl);
             FL_SPLIT16(pp, x)
             FL_STAGE2(dq, lds, OFF_HKT, lq, pp)
             // HS = P (G (gy - t) - gy u + M HD - w)             dq += k^T HS
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float gy = mk[r] * gd[r];
-                x[r] = pr[r] * (g1[r] * (gy - dl) - gy * uu + mk[r] * hd_[r] - ww);
-            }
+            for (int r = 0; r < 16; ++r) x[r] = pr[r] * (g1[r] * (gd[r] - dl) - gd[r] * uu + hd_[r] - ww);
             FL_SPLIT16(pp, x)
             FL_STAGE2(dq, lds, OFF_KT, lq, pp)
             // Pd = M P                                          ddO += hv^T Pd
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r];
+            for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r]);
             FL_SPLIT16(pp, x)
             FL_STAGE2(ddo, lds, OFF_HVT, lq, pp)
             // HgD = M P (G - u)                                 ddO += v^T HgD
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r] * (g1[r] - uu);
+            for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r] * (g1[r] - uu));
             FL_SPLIT16(pp, x)
             FL_STAGE2(ddo, lds, OFF_VT, lq, pp)
             __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
@@ -941,33 +954,33 @@ __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
         FLC_STAT_LOAD(tn)
         // statistics of this lane's 16 queries: register r <-> query t0 + (r & 3) + 8 (r >> 2) + 4 a; read per use
 #define FLC_ST(WHICH, R) (reinterpret_cast<const float*>(lds + OFF_ST + (WHICH) * 128)[((R) & 3) + 8 * ((R) >> 2) + 4 * a])
-        float pr[16], mk[16], x[16];
+        float pr[16], x[16];
+        bool kp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kp[r] = true;
+        if (DROP) { FL_MASK_QUERIES_IN_REGS(kp, key, t0) }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             pr[r] = fl_exp2(s[r] * cs + kbias - FLC_ST(0, r) * FL_LOG2E);
-            mk[r] = 1.f;
             g1[r] = g1[r] * c1 + g2[r] * c3;   // G
-            gd[r] *= cg;
-            hd_[r] *= ch;
+            gd[r] = FL_M(r, gd[r] * cg);       // gy = M o gd
+            hd_[r] = FL_M(r, hd_[r] * ch);     // M o HD
         }
-        if (DROP) { FL_MASK_QUERIES_IN_REGS(mk, key, t0) }
         u32x4 pp[2][3];
         // gs                                                     dk += hq^T gs
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = pr[r] * (mk[r] * gd[r] - FLC_ST(1, r));
+        for (int r = 0; r < 16; ++r) x[r] = pr[r] * (gd[r] - FLC_ST(1, r));
         FL_SPLIT16(pp, x)
         FL_STAGE2(dk, lds, OFF_HQT, lk, pp)
         // HS                                                     dk += q^T HS
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float gy = mk[r] * gd[r];
-            x[r] = pr[r] * (g1[r] * (gy - FLC_ST(1, r)) - gy * FLC_ST(2, r) + mk[r] * hd_[r] - FLC_ST(3, r));
-        }
+        for (int r = 0; r < 16; ++r)
+            x[r] = pr[r] * (g1[r] * (gd[r] - FLC_ST(1, r)) - gd[r] * FLC_ST(2, r) + hd_[r] - FLC_ST(3, r));
         FL_SPLIT16(pp, x)
         FL_STAGE2(dk, lds, OFF_QT, lk, pp)
         // HgD                                                    dv += dO^T HgD
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = mk[r] * pr[r] * (g1[r] - FLC_ST(2, r));
+        for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r] * (g1[r] - FLC_ST(2, r)));
         FL_SPLIT16(pp, x)
         FL_STAGE2(dv, lds, OFF_DT, lk, pp)
 #undef FLC_ST
