@@ -249,7 +249,7 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res = {"seconds": dt, "steps": steps, "episodes": episodes, "frames_per_s": 5.0 * episodes * world * steps / dt,
+    res = {"peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9, "seconds": dt, "steps": steps, "episodes": episodes, "frames_per_s": 5.0 * episodes * world * steps / dt,
            "ms_per_step": dt * 1e3 / steps, "block_size": cfg["BLOCK_SIZE"], "cfg": cfg,
            "gemm_gflop_per_step": flops.value / 1e9 / steps, "gemm_launches_per_step": launches.value / steps,
            "attention_gflop_per_step": fflops.value / 1e9 / steps, "attention_launches_per_step": flaunches.value / steps,
@@ -347,6 +347,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
     ap.add_argument("--n800-episodes", type=int, default=4,
                     help="episodes per GPU per step of the north-star sub-measurement (5 x 3x800x800 frames each; 0 = skip it)")
+    ap.add_argument("--attention-dtype", default="fp32", choices=["fp32", "fp8"],
+                    help="fp8: the forward attention products on OCP e4m3 MFMA (BASELINE.json configs[4], the 1600 / 200-query "
+                         "stress configuration: --size 1600 --queries 200 --attention-dtype fp8); fp32 = the parity path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -371,6 +374,8 @@ def main():
     if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
         lib.ix_gemm_set_mode(int(os.environ["IX_GEMM_MODE"]))
     ctx = {"lib": lib, "dev": dev, "rank": rank, "world": world, "local": local}
+    from interactron_amd import hipops as _ops
+    _ops.ATTENTION_DTYPE = args.attention_dtype
 
     head = run_workload(args, args.size, args.episodes, args.chunk, args.steps, args.warmup, ctx, not args.no_roofline, "bench")
     # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755),
@@ -402,7 +407,8 @@ def main():
                                                                  "interactive": "interactive episode (4 x get_next_action + predict)"}
                                        [args.mode], args.episodes, args.size, args.size)),
                        "mode": args.mode, "episodes_per_gpu": args.episodes, "frame_size": args.size,
-                       "attention": hipops.ATTENTION_IMPL, "parallelism": "dp%d" % world},
+                       "attention": hipops.ATTENTION_IMPL, "attention_dtype": hipops.ATTENTION_DTYPE,
+                       "peak_memory_GB": head.get("peak_memory_GB"), "parallelism": "dp%d" % world},
             "gemm_gflop_per_step": head["gemm_gflop_per_step"], "gemm_launches_per_step": head["gemm_launches_per_step"],
             "attention_gflop_per_step": head["attention_gflop_per_step"],
             "roofline": head["roofline"],
@@ -411,7 +417,7 @@ def main():
             "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,
             "allreduce": head["allreduce"],
         }
-        if not args.no_cpu_baseline and world == 1 and args.mode == "train":
+        if not args.no_cpu_baseline and world == 1 and args.mode == "train" and args.size <= 800 and args.attention_dtype == "fp32":
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -188,6 +188,19 @@ int ix_flash_bwd_bwd_f32(const struct ix_attn_planes* q, const struct ix_attn_pl
 int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out_host);
 int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
 
+/* fp8 forward (opt-in, BASELINE.json configs[4] "fp8 MFMA attention"): q k^T and P v of the forward pass on
+ * v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, fp32 accumulate, fp32 softmax / output / lse).
+ * ix_attn_split_fp8_f32: x -> one e4m3 plane in row layout [n*H][Rp][hd] and / or tr layout [n*H][hd][Rp] (either may be
+ *   null) + unscale [n*H][Rp/32] (block maximum scaled into [128, 256)).
+ * ix_flash_fwd_fp8_f32: as ix_flash_fwd_f32 on those planes (q row, k row, v tr).  The derivative entry points are not
+ *   affected: they recompute the probabilities from the fp16 planes. */
+int ix_attn_split_fp8_f32(const float* x, void* row_plane, void* tr_plane, float* unscale, int n, int R, int Rp, int64_t ld,
+                          int off, int H, int hd, ix_stream_t stream);
+int ix_flash_fwd_fp8_f32(const void* q_row8, const float* q_unscale, const void* k_row8, const float* k_unscale,
+                         const void* v_tr8, const float* v_unscale, const float* bias, float* out, float* lse, int n, int H,
+                         int L, int Lp, int S, int Sp, int hd, int64_t ld_out, int off_out, float scale, float p_drop,
+                         uint64_t seed, ix_stream_t stream);
+
 /* ---- set criterion ---------------------------------------------------------------------------------------
  * ix_match_cost_f32: HungarianMatcher cost matrix (matcher.py:54-73); ix_lsap_f32 (HOST pointers): the
  * scipy.optimize.linear_sum_assignment call of matcher.py:76; weighted CE: detr.py:111-132; box losses:

@@ -1170,3 +1170,251 @@ extern "C" int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_dro
     IX_CHECK_LAUNCH("ix_flash_dropmask_f32");
     return IX_OK;
 }
+
+// ============================================================================================================
+// fp8 forward (opt-in; BASELINE.json configs[4]: 1600 long edge, 200 queries, "fp8 MFMA attention"): the two products of
+// the forward pass -- q k^T and P v (reference models/gpt.py:48-53) -- on v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands,
+// fp32 accumulate), ONE matrix instruction per 16 contracted elements instead of three / six.  Operands are quantised
+// once by ix_attn_split_fp8_f32 (one plane, per-32-row block scale so that the block maximum lands in [128, 256)), the
+// probabilities in registers (x 256).  Softmax statistics, the output and lse stay fp32; the derivative kernels above are
+// unchanged (they recompute P from the fp16 planes), so this is an approximation of the FORWARD values only, with a
+// stated tolerance (tests/test_ops_gpu.py::test_flash_forward_fp8).
+// ============================================================================================================
+__device__ __forceinline__ unsigned fl_pack_fp8x4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_split_fp8_kernel(const float* __restrict__ X, unsigned char* __restrict__ rowp,
+                                                             float* __restrict__ unscale, unsigned char* __restrict__ trp, int R,
+                                                             int Rp, int64_t ld, int off, int H) {
+    constexpr int EPT = 32 * HD / 256, TPR = HD / EPT;
+    __shared__ __attribute__((aligned(16))) unsigned char lt[HD][32 + 8];   // [d][permuted row]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, r0 = blockIdx.x * 32, bh = blockIdx.y;
+    const int b = bh / H, h = bh % H;
+    const int row = tid / TPR, c0 = (tid % TPR) * EPT;
+    float v[EPT];
+    const bool in = r0 + row < R;
+    const float* src = X + ((int64_t)b * R + r0 + row) * ld + off + h * HD + c0;
+#pragma unroll
+    for (int i = 0; i < EPT; i += 4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) t = *reinterpret_cast<const float4*>(src + i);
+        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) mx = fmaxf(mx, fabsf(v[i]));
+    mx = ix_block_max_256(mx, red);
+    const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;
+    const bool tiny = e < 16u || e > 250u;
+    const float sc = tiny ? 1.f : __uint_as_float((261u - e) << 23);   // 2^(7 - E): block maximum in [128, 256) (e4m3 max 448)
+    const float us = tiny ? 1.f : __uint_as_float((e - 7u) << 23);
+    if (tid == 0) unscale[(int64_t)bh * (Rp / 32) + blockIdx.x] = us;
+    unsigned w[EPT / 4];
+#pragma unroll
+    for (int i = 0; i < EPT / 4; ++i) w[i] = fl_pack_fp8x4(v[4 * i] * sc, v[4 * i + 1] * sc, v[4 * i + 2] * sc, v[4 * i + 3] * sc);
+    if (rowp) {
+        unsigned* dst = reinterpret_cast<unsigned*>(rowp + ((int64_t)bh * Rp + r0 + row) * HD + c0);
+#pragma unroll
+        for (int i = 0; i < EPT / 4; ++i) dst[i] = w[i];
+    }
+    if (!trp) return;
+    const int prow = (row & 16) | fl_perm16(row & 15);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) lt[c0 + i][prow] = (unsigned char)(w[i / 4] >> (8 * (i & 3)));
+    __syncthreads();
+    for (int c = tid; c < HD * 4; c += 256) {   // HD rows of 32 bytes = four 8-byte chunks
+        const int d = c / 4, ch = c % 4;
+        *reinterpret_cast<uint2*>(trp + ((int64_t)bh * HD + d) * Rp + r0 + ch * 8) = *reinterpret_cast<const uint2*>(&lt[d][ch * 8]);
+    }
+}
+
+extern "C" int ix_attn_split_fp8_f32(const float* x, void* row_plane, void* tr_plane, float* unscale, int n, int R, int Rp,
+                                     int64_t ld, int off, int H, int hd, hipStream_t stream) {
+    if (n <= 0 || R <= 0) return IX_OK;
+    IX_CHECK_ARG(x && unscale && (row_plane || tr_plane), "ix_attn_split_fp8_f32: null pointer");
+    IX_CHECK_ARG(hd == 32 || hd == 64, "ix_attn_split_fp8_f32: head dim %d (32 or 64)", hd);
+    IX_CHECK_ARG(Rp % 128 == 0 && Rp >= R, "ix_attn_split_fp8_f32: Rp=%d must be R=%d rounded up to 128", Rp, R);
+    IX_CHECK_ARG(ld % 4 == 0 && off % 4 == 0 && ((uintptr_t)x & 15) == 0, "ix_attn_split_fp8_f32: rows must be 16-byte aligned");
+    dim3 grid(Rp / 32, n * H);
+    if (hd == 64)
+        hipLaunchKernelGGL(attn_split_fp8_kernel<64>, grid, dim3(256), 0, stream, x, (unsigned char*)row_plane, unscale,
+                           (unsigned char*)tr_plane, R, Rp, ld, off, H);
+    else
+        hipLaunchKernelGGL(attn_split_fp8_kernel<32>, grid, dim3(256), 0, stream, x, (unsigned char*)row_plane, unscale,
+                           (unsigned char*)tr_plane, R, Rp, ld, off, H);
+    IX_CHECK_LAUNCH("ix_attn_split_fp8_f32");
+    return IX_OK;
+}
+
+struct FlashFp8Args {
+    const unsigned char *q_row, *k_row, *v_tr;   // [BH][Lp][hd], [BH][Sp][hd], [BH][hd][Sp] (e4m3)
+    const float *q_us, *k_us, *v_us, *bias;
+    float *out, *lse;
+    int H, L, Lp, S, Sp;
+    int64_t ld_out;
+    int off_out;
+    float scale_log2e;
+    unsigned thr16;
+    float inv_keep;
+    unsigned seed_lo, seed_hi;
+};
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256, 2) void flash_fwd_fp8_kernel(FlashFp8Args p) {
+    constexpr int NKS = HD / 16, NDB = HD / 32;
+    constexpr int KROW = HD + 8, VROW = 32 + 8, OFF_VT = 32 * KROW, BYTES = OFF_VT + HD * VROW;   // 8-byte padded rows
+    constexpr int NCH = 32 * HD / 8;   // 8-byte chunks of the K tile (= of the V tile): 256 at hd 64, 128 at hd 32
+    __shared__ __attribute__((aligned(16))) unsigned char ldsb[2][BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, a = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int ntiles = (p.S + 31) / 32;
+    const unsigned char* krow = p.k_row + (int64_t)bh * p.Sp * HD;
+    const unsigned char* vtr = p.v_tr + (int64_t)bh * HD * p.Sp;
+    const float* bias = p.bias + (int64_t)b * p.Sp;
+    const float* kus = p.k_us + (int64_t)bh * (p.Sp / 32);
+    const float* vus = p.v_us + (int64_t)bh * (p.Sp / 32);
+
+    long qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        qf[ks] = *reinterpret_cast<const long*>(p.q_row + ((int64_t)bh * p.Lp + q0 + lq) * HD + ks * 16 + 8 * a);
+    const float c2 = p.scale_log2e * p.q_us[(int64_t)bh * (p.Lp / 32) + q0 / 32];
+    f32x16 o[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -1e30f, l = 0.f;
+    const unsigned rid = (unsigned)(bh * p.L + q0 + lq);
+
+    // staging: one 8-byte chunk of the K tile and one of the V tile per thread (hd 64); hd 32: threads 0..127 K, 128..255 V
+    uint2 s0, s1;
+    const int c = HD == 64 ? tid : (tid & 127);
+    const bool doK = HD == 64 || tid < 128, doV = HD == 64 || tid >= 128;
+#define FL8_LOAD(T0)                                                                                                   \
+    if (doK) s0 = *reinterpret_cast<const uint2*>(krow + (int64_t)(T0) * HD + c * 8);                                  \
+    if (doV) s1 = *reinterpret_cast<const uint2*>(vtr + (int64_t)(c >> 2) * p.Sp + (T0) + (c & 3) * 8);
+#define FL8_STORE(BUF)                                                                                                 \
+    if (doK) *reinterpret_cast<uint2*>((BUF) + (c / (HD / 8)) * KROW + (c % (HD / 8)) * 8) = s0;                       \
+    if (doV) *reinterpret_cast<uint2*>((BUF) + OFF_VT + (c >> 2) * VROW + (c & 3) * 8) = s1;
+    (void)NCH;
+    s0 = make_uint2(0, 0); s1 = make_uint2(0, 0);
+    FL8_LOAD(0)
+    FL8_STORE(ldsb[0])
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* lds = ldsb[t & 1];
+        const int t0 = t * 32;
+        f32x4 kb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) kb[g] = *reinterpret_cast<const f32x4*>(bias + t0 + 8 * g + 4 * a);
+        const float cs = c2 * kus[t], cv = vus[t] * (1.f / 256.f);
+        FL8_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const long kf = *reinterpret_cast<const long*>(lds + lq * KROW + ks * 16 + 8 * a);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf, qf[ks], s, 0, 0, 0);
+        }
+        float x[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[r] = s[r] * cs + kb[r >> 2][r & 3];
+            tmax = fmaxf(tmax, x[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = fl_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[r] = fl_exp2(x[r] - mn);
+            ps += x[r];
+        }
+        l = l * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        if (DROP) {
+            bool kp[16];
+            FL_MASK_KEYS_IN_REGS(kp, rid, t0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = kp[r] ? x[r] : 0.f;
+        }
+        // P^T x 256 -> e4m3: accumulator registers 8 s2 + j are the B fragment of key slice s2
+        long pf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned lo = fl_pack_fp8x4(x[8 * s2] * 256.f, x[8 * s2 + 1] * 256.f, x[8 * s2 + 2] * 256.f, x[8 * s2 + 3] * 256.f);
+            const unsigned hi = fl_pack_fp8x4(x[8 * s2 + 4] * 256.f, x[8 * s2 + 5] * 256.f, x[8 * s2 + 6] * 256.f, x[8 * s2 + 7] * 256.f);
+            pf[s2] = (long)(((unsigned long)hi << 32) | lo);
+        }
+        // O^T += (V^T . P^T) x (V block unscale / 256): the V tile carries its own block scale, so it goes through a
+        // zero-initialised accumulator and one multiply-add per output register
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            f32x16 tmp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmp[r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const long vf = *reinterpret_cast<const long*>(lds + OFF_VT + (db * 32 + lq) * VROW + s2 * 16 + 8 * a);
+                tmp = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf[s2], tmp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] += tmp[r] * cv;
+        }
+        FL8_STORE(ldsb[(t + 1) & 1])
+        __syncthreads();
+    }
+#undef FL8_LOAD
+#undef FL8_STORE
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + lq;
+    if (q < p.L) {
+        const float inv = p.inv_keep / l;
+        float* dst = p.out + ((int64_t)b * p.L + q) * p.ld_out + p.off_out + h * HD + 4 * a;
+        FL_STORE_ROWS(o, dst, inv)
+        if (a == 0) p.lse[(int64_t)bh * p.Lp + q] = (m + log2f(l)) * FL_LN2;
+    }
+}
+
+extern "C" int ix_flash_fwd_fp8_f32(const void* q_row8, const float* q_unscale, const void* k_row8, const float* k_unscale,
+                                    const void* v_tr8, const float* v_unscale, const float* bias, float* out, float* lse, int n,
+                                    int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_out, int off_out, float scale,
+                                    float p_drop, uint64_t seed, hipStream_t stream) {
+    if (n <= 0 || L <= 0) return IX_OK;
+    IX_CHECK_ARG(q_row8 && q_unscale && k_row8 && k_unscale && v_tr8 && v_unscale && bias && out && lse, "ix_flash_fwd_fp8_f32: null pointer");
+    IX_CHECK_ARG(hd == 32 || hd == 64, "ix_flash_fwd_fp8_f32: head dim %d (32 or 64)", hd);
+    IX_CHECK_ARG(S > 0 && Lp % 128 == 0 && Sp % 128 == 0 && Lp >= L && Sp >= S, "ix_flash_fwd_fp8_f32: bad padded sizes");
+    IX_CHECK_ARG(FL_OUT_OK(ld_out, off_out) && ((uintptr_t)out & 15) == 0, "ix_flash_fwd_fp8_f32: output rows must be 16-byte aligned");
+    IX_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "ix_flash_fwd_fp8_f32: p=%f outside [0,1)", p_drop);
+    IX_CHECK_ARG((int64_t)n * H * L < ((int64_t)1 << 32) && n * H <= 65535, "ix_flash_fwd_fp8_f32: too many rows");
+    FlashFp8Args a;
+    a.q_row = (const unsigned char*)q_row8; a.k_row = (const unsigned char*)k_row8; a.v_tr = (const unsigned char*)v_tr8;
+    a.q_us = q_unscale; a.k_us = k_unscale; a.v_us = v_unscale; a.bias = bias; a.out = out; a.lse = lse;
+    a.H = H; a.L = L; a.Lp = Lp; a.S = S; a.Sp = Sp; a.ld_out = ld_out; a.off_out = off_out;
+    a.scale_log2e = scale * FL_LOG2E;
+    a.thr16 = (unsigned)((double)p_drop * 65536.0 + 0.5);
+    a.inv_keep = a.thr16 ? 65536.f / (float)(65536u - a.thr16) : 1.f;
+    a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    dim3 grid((L + 127) / 128, n * H);
+    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, 2.0 * FL_PRODUCT_FLOPS, 1);
+    FL_DISPATCH(flash_fwd_fp8_kernel, grid)
+    ix_prof_end(stream);
+    IX_CHECK_LAUNCH("ix_flash_fwd_fp8_f32");
+    return IX_OK;
+}

@@ -415,6 +415,9 @@ class AttentionCoreBwd(Function):
 # and probabilities as [n, H, L, S] tensors).  IX_ATTENTION in the environment overrides the default (A/B runs).
 import os as _os
 ATTENTION_IMPL = _os.environ.get("IX_ATTENTION", "flash")
+# "fp32" (default, the parity path): fp32-grade arithmetic everywhere.  "fp8": the two products of the flash FORWARD kernel
+# on OCP e4m3 operands (BASELINE.json configs[4], the 1600 / 200-query stress configuration); derivatives stay fp32-grade.
+ATTENTION_DTYPE = _os.environ.get("IX_ATTENTION_DTYPE", "fp32")
 
 
 def _pad128(R):
@@ -465,16 +468,41 @@ def flash_dropmask(BH, L, S, p, seed, device="cuda"):
     return m
 
 
-def flash_forward(q, k, v, g, mask, p, seed, need_backward=True):
-    """-> (out [n, L, H*hd], lse [n*H, Lp] (+inf beyond L), operand planes) for geometry g (AttnGeom)."""
+def attn_split_fp8(x, n, R, ld, off, H, hd, row=True, tr=False):
+    """fp32 activations -> one OCP e4m3 plane in row and / or tr layout + block unscale factors (csrc/flash.hip, fp8 forward)."""
+    x = _req(x, "attention operand")
+    Rp = _pad128(R)
+    rowp = torch.empty(n * H * Rp * hd, dtype=torch.uint8, device=x.device) if row else None
+    trp = torch.empty(n * H * Rp * hd, dtype=torch.uint8, device=x.device) if tr else None
+    us = torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=x.device)
+    _chk(_L().ix_attn_split_fp8_f32(x.data_ptr(), rowp.data_ptr() if row else None, trp.data_ptr() if tr else None,
+                                    us.data_ptr(), n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_fp8_f32")
+    return rowp, trp, us
+
+
+def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
+    """-> (out [n, L, H*hd], lse [n*H, Lp] (+inf beyond L), operand planes) for geometry g (AttnGeom).
+    dtype "fp8": the two forward products on e4m3 operands (ATTENTION_DTYPE); the planes for the derivative kernels are
+    the fp16 / bf16 ones either way."""
     dev = q.device
-    pl = {"q": attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr=need_backward),
-          "k": attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr=need_backward),
-          "v": attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=need_backward),
-          "bias": attn_bias(mask, g.n, g.S, dev)}
+    dtype = dtype or ATTENTION_DTYPE
+    fp8 = dtype == "fp8"
+    pl = {"bias": attn_bias(mask, g.n, g.S, dev)}
+    if need_backward or not fp8:
+        pl["q"] = attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr=need_backward)
+        pl["k"] = attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr=need_backward)
+        pl["v"] = attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=need_backward)
     Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
     out = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
     lse = torch.full((g.n * g.heads, Lp), float("inf"), dtype=torch.float32, device=dev)   # +inf: P = 0 for padded queries
+    if fp8:
+        q8, _, qus = attn_split_fp8(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
+        k8, _, kus = attn_split_fp8(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
+        _, v8, vus = attn_split_fp8(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=False, tr=True)
+        _chk(_L().ix_flash_fwd_fp8_f32(q8.data_ptr(), qus.data_ptr(), k8.data_ptr(), kus.data_ptr(), v8.data_ptr(), vus.data_ptr(),
+                                       pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
+                                       g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_fp8_f32")
+        return out, lse, pl
     _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(),
                                g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_f32")
     return out, lse, pl

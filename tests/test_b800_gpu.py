@@ -103,3 +103,57 @@ def test_full_800x800_meta_train_step_properties(golden):
         # atomics, elements on the clip / ReLU kinks); a part dropped or written twice is off by 50 % or more
         assert abs(n2 - 2 * n1) <= 0.1 * 2 * n1, (k, n1, n2)
     assert abs(tot2 ** 0.5 - 2 * tot1 ** 0.5) <= 1e-2 * 2 * tot1 ** 0.5, (tot1 ** 0.5, tot2 ** 0.5)
+
+
+FP8_LOGIT_MAX, FP8_LOGIT_L2, FP8_BOX_ABS = 0.08, 0.05, 0.03   # measured: 0.038, 0.030, 0.012
+
+
+def test_stress_config_200_queries_fp32_and_fp8_attention():
+    """BASELINE.json configs[4] at reduced frames: NUM_QUERIES = 200 (reference hard-codes 50, detr.py:331) on 2 frames of
+    320x256 through detector + GPT fusion, HIP vs CPU oracle -- once on the parity path (fp32-grade attention, the usual
+    forward tolerance) and once with the opt-in fp8 forward attention (IX_ATTENTION_DTYPE=fp8 / hipops.ATTENTION_DTYPE).
+    Stated fp8 tolerance on this model (FP8_* below): logits within 8 % of max|logit| element-wise and 5 % relative L2,
+    boxes (sigmoid outputs in [0, 1]) within 0.03 absolute."""
+    from interactron_amd import Config, NestedTensor, build_model, hipops
+    from oracle import detector as od, fusion as of
+    Q, s, h, w = 200, 2, 320, 256
+    tokens = (h // 16) * (w // 16)
+    cfg = dict(MODEL_CFG, TYPE="interactron", NUM_QUERIES=Q, BLOCK_SIZE=5 * (tokens + Q) + 5)
+    m = build_model(Config(**cfg))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().eval()
+    data = synthetic_episodes(1, frames=s, height=h, width=w, tag="stress-q200")
+    frames, masks = data["frames"][0], data["masks"][0]
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes(num_queries=Q).items()}).items()}
+    fus = {k[len("fusion."):]: v for k, v in
+           procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, "gpt").items()}).items()}
+    with torch.no_grad():
+        rd = od.detr_forward(det, frames, masks)
+        rf = of.fusion_gpt_forward(fus, {k: v.unsqueeze(0) for k, v in rd.items() if k != "image_features"}, cfg)
+
+    def run():
+        with torch.no_grad():
+            d = m.detector(NestedTensor(frames.cuda(), masks.cuda()))
+            f = m.fusion({k: v.unsqueeze(0) for k, v in d.items() if k != "image_features"})
+        return d, f
+
+    assert hipops.ATTENTION_DTYPE == "fp32"
+    d, f = run()
+    assert d["pred_logits"].shape == (s, Q, 1236) and f["pred_logits"].shape[-2:] == (Q, 1236)
+    for k in ("pred_logits", "pred_boxes", "box_features"):
+        _close(d[k], rd[k], "q200/detector/" + k)
+    for k in ("pred_logits", "pred_boxes", "loss", "actions"):
+        _close(f[k].reshape(rf[k].shape), rf[k], "q200/fusion/" + k)
+    hipops.ATTENTION_DTYPE = "fp8"
+    try:
+        d8, f8 = run()
+    finally:
+        hipops.ATTENTION_DTYPE = "fp32"
+    for name, got, ref in (("detector", d8, rd), ("fusion", f8, rf)):
+        lg, rl = got["pred_logits"].cpu().reshape(ref["pred_logits"].shape), ref["pred_logits"]
+        bx, rb = got["pred_boxes"].cpu().reshape(ref["pred_boxes"].shape), ref["pred_boxes"]
+        worst, l2, box = float((lg - rl).abs().max() / rl.abs().max()), float((lg - rl).norm() / rl.norm()), float((bx - rb).abs().max())
+        print("fp8 attention, %s: logits max err / max|logit| = %.4f, relative L2 = %.4f; boxes max abs err = %.4f" % (name, worst, l2, box))
+        assert worst <= FP8_LOGIT_MAX and l2 <= FP8_LOGIT_L2 and box <= FP8_BOX_ABS, (name, worst, l2, box)
+    assert float((d8["pred_logits"] - d["pred_logits"]).abs().max()) > 0   # (the fp8 path really ran)
