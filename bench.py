@@ -293,6 +293,47 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     return res
 
 
+def hbm_kernels(torch, hipops, dev):
+    """The HBM-bound kernels of the path, timed alone on step-sized buffers (HIP events on the current stream, 5 launches
+    after a warm-up): achieved GB/s = ALGORITHMIC bytes per launch / average launch time, against the 8 TB/s HBM3E peak
+    (/opt/skills/guides/MI355X_MICROARCH.md; a float4 copy reaches 6.3).  Sizes: the 58.4 M-element flat parameter buffer
+    (Adam, clip norm), theta's 38.0 M elements (clipped SGD), a [32960, 512] fusion activation (LayerNorm) and a
+    [16, 2060, 512] projection (operand split)."""
+    import math
+    def timed(fn, it=5):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / it * 1e-3
+    out = {}
+    n = 58_400_000
+    pbuf, g, m, v = (torch.randn(n, device=dev) * 1e-3 for _ in range(4))
+    v.abs_()
+    sq = torch.zeros((), device=dev)
+    t = timed(lambda: hipops.adam_step(pbuf, g, m, v, 1e-5, 0.9, 0.999, 1e-8, 1, sq, 1.0, zero_grad=False))
+    out["adam_kernel"] = {"bytes": 28 * n, "GBps": 28 * n / t / 1e9}
+    t = timed(lambda: hipops.sumsq_accum(g, sq))
+    out["sumsq_accum_kernel"] = {"bytes": 4 * n, "GBps": 4 * n / t / 1e9}
+    n2 = 38_030_808
+    ps, gs = [torch.randn(n2, device=dev)], [torch.randn(n2, device=dev) * 10]
+    t = timed(lambda: hipops.ClippedSGD.forward(hipops._NullCtx(), 1e-3, 0.01, 1, *(ps + gs)))
+    out["multi_map2_kernel<sgd_clip>"] = {"bytes": 12 * n2, "GBps": 12 * n2 / t / 1e9}
+    x = torch.randn(32960, 512, device=dev)
+    w, b = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+    t = timed(lambda: hipops.LayerNorm.forward(hipops._NullCtx(), x, w, b, 1e-5))
+    out["ln_fwd_kernel"] = {"bytes": 8 * x.numel(), "GBps": 8 * x.numel() / t / 1e9}
+    y = torch.randn(16, 2060, 512, device=dev)
+    t = timed(lambda: hipops.attn_split(y, 16, 2060, 512, 0, 8, 64))
+    out["attn_split_kernel"] = {"bytes": 14 * y.numel(), "GBps": 14 * y.numel() / t / 1e9}   # 4 B read, 4 B fp16 + 6 B bf16 planes written
+    for k in out:
+        out[k]["frac_of_8TBps"] = out[k]["GBps"] / 8000.0
+    return out
+
+
 FLASH_KERNELS = ["all", "flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_kernel", "flash_bb_q_kernel<stats>",
                  "flash_bb_q_kernel", "flash_bb_kv_kernel"]
 
@@ -371,8 +412,6 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (torchrun --nproc-per-node must match)" % (args.gpus, world)
     dev = torch.device("cuda", local)
     lib = _lib.load()
-    if os.environ.get("IX_GEMM_MODE"):   # A/B of contraction-kernel variants (tools/mode_ab.sh); default = library default
-        lib.ix_gemm_set_mode(int(os.environ["IX_GEMM_MODE"]))
     ctx = {"lib": lib, "dev": dev, "rank": rank, "world": world, "local": local}
     from interactron_amd import hipops as _ops
     _ops.ATTENTION_DTYPE = args.attention_dtype
@@ -414,6 +453,7 @@ def main():
             "roofline": head["roofline"],
             "cpu_baseline": None,
             "n800": n800,
+            "hbm_kernels": hbm_kernels(torch, hipops, dev) if not args.no_roofline else None,
             "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,
             "allreduce": head["allreduce"],
         }

@@ -10,7 +10,8 @@
  *     (or int64 / uint8 where stated) owned by the caller; the library never allocates or frees device memory;
  *   - all work is enqueued on `stream` (pass torch.cuda.current_stream().cuda_stream); no internal syncs;
  *   - return 0 on success, negative on error; ix_last_error() returns a thread-local message;
- *   - compute entry points are re-entrant; the only global mutable state is the ix_gemm_stats/prof counters.
+ *   - compute entry points are re-entrant; the only global mutable state is the ix_gemm_stats / ix_flash_stats / prof
+ *     counters and the test hook ix_gemm_set_mode (kernel choice for cross-checks; never called by the product).
  */
 #ifndef INTERACTRON_HIP_H
 #define INTERACTRON_HIP_H
@@ -44,10 +45,9 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
  * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */
-int ix_gemm_set_mode(int mode); /* 0: fp32 MFMA only; 1: bf16x6 (3-way bf16 split) kernel, one tile per workgroup;
-                                   2: persistent bf16x6 kernel, 8 waves; 3 (default): persistent, 12 waves (two
-                                   producer waves per SIMD); 4: as 3 with the compact LDS image and deferred C
-                                   stores (experiment, neutral); 5: eight consumer waves (experiment, slower).  Returns the previous mode. */
+int ix_gemm_set_mode(int mode); /* TEST HOOK (process-global, not part of the re-entrant compute surface; the product never
+                                   calls it): 0 = every contraction on the exact-fp32 MFMA kernel, 3 (default) = eligible
+                                   contractions on the persistent 12-wave bf16x6 kernel.  Returns the previous mode. */
 int ix_gemm_stats(double* flops, int64_t* launches, int reset);
 int ix_gemm_prof_enable(int on);
 int ix_gemm_prof_kinds(double* ms2, double* flops2, int64_t* launches2); /* [0] fp32-MFMA kernel, [1] bf16x6 kernel */
@@ -153,6 +153,8 @@ int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, 
  * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; the
  *   caller pre-fills +inf so that padded query rows count as P = 0 in the derivative kernels).
  *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key).
+ *   out == null: only lse is produced (q k^T + softmax statistics) -- used after the fp8 forward, whose own normalisers
+ *   belong to fp8 scores and not to the fp16 scores the derivative kernels recompute.
  * ix_attn_rowdot_f32: t[bh][q] = sum_d a[q, h, d] b[q, h, d] over heads of two [n][L][ld] activations (delta = dO . O).
  * ix_flash_bwd_f32: (gq, gk, gv) from the planes of (q, k, v, dO) + lse + delta; probabilities are recomputed tile by
  *   tile.  gq (may be null) is written by query-owning workgroups, gk + gv (both or neither) by key-owning ones; outputs

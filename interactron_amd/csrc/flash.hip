@@ -338,11 +338,14 @@ struct FlashArgs {
 // ------------------------------------------------------------------------------------------------------------
 // forward: query-owning workgroups (4 waves x 32 queries), key tiles of 32, double-buffered LDS, one barrier per tile
 // ------------------------------------------------------------------------------------------------------------
-template <int HD, bool DROP>
+// LSE_ONLY: only the row normalisers are produced (q k^T + online softmax statistics, no P v): what the derivative kernels
+// need when the forward OUTPUT came from the fp8 kernel, whose normalisers belong to fp8 scores, not to the fp16 scores
+// the derivative kernels recompute.
+template <int HD, bool DROP, bool LSE_ONLY = false>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
-    constexpr int OFF_K = 0, OFF_VT = G::RBYTES, BYTES = G::RBYTES + G::TBYTES, NU = 5, NROW = 1;
+    constexpr int OFF_K = 0, OFF_VT = G::RBYTES, BYTES = LSE_ONLY ? G::RBYTES : G::RBYTES + G::TBYTES, NU = LSE_ONLY ? 2 : 5, NROW = 1;
     __shared__ __attribute__((aligned(16))) unsigned char ldsb[2][BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, a = lane >> 5;
@@ -413,22 +416,24 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
             ps += x[r];
         }
         l = l * alpha + ps;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // (a row maximum moved somewhere in this wave: rare after the first tiles)
+        if (!LSE_ONLY && __builtin_amdgcn_ballot_w64(alpha != 1.f)) {   // (a row maximum moved somewhere in this wave: rare after the first tiles)
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
-        if (DROP) {
-            bool kp[16];
-            FL_MASK_KEYS_IN_REGS(kp, rid, t0)
+        if (!LSE_ONLY) {
+            if (DROP) {
+                bool kp[16];
+                FL_MASK_KEYS_IN_REGS(kp, rid, t0)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = kp[r] ? x[r] : 0.f;   // (1 / keep is applied once, to O)
+                for (int r = 0; r < 16; ++r) x[r] = kp[r] ? x[r] : 0.f;   // (1 / keep is applied once, to O)
+            }
+            // ---- O^T[d, query] += V^T[d, key] . P^T[key, query] ----
+            u32x4 pp[2][3];
+            FL_SPLIT16(pp, x)
+            FL_STAGE2(o, lds, OFF_VT, lq, pp)
         }
-        // ---- O^T[d, query] += V^T[d, key] . P^T[key, query] ----
-        u32x4 pp[2][3];
-        FL_SPLIT16(pp, x)
-        FL_STAGE2(o, lds, OFF_VT, lq, pp)
         FL_STAGE_STORE(sv, 0, NU, NROW, FLF_DST(ldsb[(t + 1) & 1]))
         __syncthreads();
     }
@@ -437,9 +442,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     l += __shfl_xor(l, 32, 64);
     const int q = q0 + lq;
     if (q < p.L) {
-        const float inv = p.inv_keep / l;
-        float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * HD + 4 * a;
-        FL_STORE_ROWS(o, dst, inv)
+        if (!LSE_ONLY) {
+            const float inv = p.inv_keep / l;
+            float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * HD + 4 * a;
+            FL_STORE_ROWS(o, dst, inv)
+        }
         if (a == 0) p.lse[(int64_t)bh * p.Lp + q] = (m + log2f(l)) * FL_LN2;
     }
 }
@@ -1042,16 +1049,25 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
                                 float* out, float* lse, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_out,
                                 int off_out, float scale, float p_drop, uint64_t seed, hipStream_t stream) {
     if (n <= 0 || L <= 0) return IX_OK;
-    IX_CHECK_ARG(q && k && v && q->row && q->unscale && k->row && k->unscale && v->tr && out && lse, "ix_flash_fwd_f32: null pointer");
+    IX_CHECK_ARG(q && k && q->row && q->unscale && k->row && k->unscale && lse, "ix_flash_fwd_f32: null pointer");
+    IX_CHECK_ARG(!out || (v && v->tr), "ix_flash_fwd_f32: v tr planes missing");
     IX_CHECK_ARG(FL_OUT_OK(ld_out, off_out) && ((uintptr_t)out & 15) == 0, "ix_flash_fwd_f32: output rows must be 16-byte aligned");
     FlashArgs a;
     const int rc = fl_common(a, "ix_flash_fwd_f32", bias, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
     if (rc) return rc;
     a.q_row = (const unsigned short*)q->row; a.q_us = q->unscale;
     a.k_row = (const unsigned short*)k->row; a.k_us = k->unscale;
-    a.v_tr = (const unsigned short*)v->tr;
+    a.v_tr = out ? (const unsigned short*)v->tr : nullptr;
     a.o1 = out; a.ld1 = ld_out; a.off1 = off_out; a.lse = lse;
     dim3 grid((L + 127) / 128, n * H);
+    if (!out) {   // row normalisers only
+        ix_prof_begin(stream, 2, 1.0 * FL_PRODUCT_FLOPS, 3 * FL_PRODUCT_FLOPS, 1);
+        if (hd == 64) hipLaunchKernelGGL((flash_fwd_kernel<64, false, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((flash_fwd_kernel<32, false, true>), grid, dim3(256), 0, stream, a);
+        ix_prof_end(stream);
+        IX_CHECK_LAUNCH("ix_flash_fwd_f32");
+        return IX_OK;
+    }
     ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 1);
     FL_DISPATCH(flash_fwd_kernel, grid)
     ix_prof_end(stream);

@@ -1312,6 +1312,7 @@ static void launch_x6q_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipS
         hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, DEFER>), grid, dim3(768), 0, stream, a, items);
 }
 
+#ifdef X6_DIAG_MODES   // experiment: eight consumer waves (mode 5)
 template <int BN>
 static void launch_x6q8_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
     int g = (items + 7) / 8 * 8;
@@ -1327,6 +1328,8 @@ static void launch_x6q8_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hip
         hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, false, 8>), grid, dim3(1024), 0, stream, a, items);
 }
 
+#endif
+
 template <bool DEFER>
 static void launch_x6q(const GemmArgs& a, int bn, int a_kc, int b_kc, int items, hipStream_t stream) {
     if (bn == 128)
@@ -1337,6 +1340,7 @@ static void launch_x6q(const GemmArgs& a, int bn, int a_kc, int b_kc, int items,
         launch_x6q_bn<32, DEFER>(a, a_kc, b_kc, items, stream);
 }
 
+#ifdef X6_DIAG_MODES   // superseded forms: 8-wave persistent kernel (mode 2), one tile per workgroup (mode 1)
 template <int BN>
 static void launch_x6p_bn(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
     int g = (items + 7) / 8 * 8;
@@ -1382,6 +1386,8 @@ static void launch_x6(const GemmArgs& a, int bn, int a_kc, int b_kc, dim3 grid, 
         launch_x6_bn<32>(a, a_kc, b_kc, grid, stream);
 }
 
+
+#endif
 
 __global__ void zero_strided_kernel(float* C, int M, int N, int64_t ldc, int64_t sCo, int64_t sCi, int batch_inner) {
     const int zb = blockIdx.y;
@@ -1429,11 +1435,17 @@ extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
     return IX_OK;
 }
 
-// mode 0: every contraction on v_mfma_f32_32x32x2_f32; mode 1: 128x128 tiles on the bf16x6 kernel (fp32-grade accuracy
-// from three-way bf16 splits, 6 bf16 MFMAs per k-slice).  Returns the previous mode.
+// Test hook: 0 = every contraction on the exact-fp32 kernel (v_mfma_f32_32x32x2_f32), 3 (default) = eligible contractions
+// on the 12-wave persistent bf16x6 kernel.  Process-global and NOT part of the re-entrant compute surface: the product
+// never calls it; tests use it to cross-check the two kernels.  (The superseded kernel forms 1 / 2 / 4 / 5 exist only in
+// the diagnostic build, `make diag`, -DX6_DIAG_MODES.)  Returns the previous mode.
 extern "C" int ix_gemm_set_mode(int mode) {
     const int old = g_x6;
-    g_x6 = mode < 0 ? 0 : (mode > 5 ? 5 : mode);   // 2: persistent bf16x6 kernel (8 waves); 3: 12-wave form
+#ifdef X6_DIAG_MODES
+    g_x6 = mode < 0 ? 0 : (mode > 5 ? 5 : mode);
+#else
+    g_x6 = mode == 0 ? 0 : 3;
+#endif
     return old;
 }
 
@@ -1604,7 +1616,8 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
     // bf16x6 kernel: 32-bit buffer offsets + 16-byte loads; its 3-stage ring and one-workgroup-per-CU residency only pay
     // off once there are enough K steps to stream (attention's K = 32 / 64 products stay on the fp32 kernel, where a
     // second resident workgroup hides the prologue)
-    const bool x6_ok = sa && sb && K >= 32 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31;
+    const bool x6_ok = sa && sb && K >= 32 && a.extA * 4 < (int64_t)1 << 31 && a.extB * 4 < (int64_t)1 << 31 &&
+                       (int64_t)ix_div_up(M, 128) * ix_div_up(N, 32) * nbatch * 64 < ((int64_t)1 << 30);   // (item index fits an int)
     const bool want_x6 = x6_ok && (tile_hint == 1128 || (g_x6 && tile_hint != 128));
 
     // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
@@ -1671,21 +1684,22 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
         g_rec.push_back(r);
     }
     prof_mark(stream);
-    if (use_x6 && g_x6 == 5 && bn >= 64 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30)) {
-        if (bn == 128)
-            launch_x6q8_bn<128>(a, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-        else
-            launch_x6q8_bn<64>(a, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-    } else if (use_x6 && g_x6 == 5 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
-        launch_x6q<false>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-    else if (use_x6 && g_x6 == 4 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
-        launch_x6q<true>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-    else if (use_x6 && g_x6 == 3 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
-        launch_x6q<false>(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-    else if (use_x6 && g_x6 == 2 && (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30))
-        launch_x6p(a, bn, a_kcontig, b_kcontig, a.tiles_m * a.tiles_n * nbatch * split, stream);
-    else if (use_x6)
+    const bool persistent_ok = (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30);
+    const int items = a.tiles_m * a.tiles_n * nbatch * split;
+#ifdef X6_DIAG_MODES
+    if (use_x6 && g_x6 == 5 && bn >= 64 && persistent_ok) {
+        if (bn == 128) launch_x6q8_bn<128>(a, a_kcontig, b_kcontig, items, stream);
+        else launch_x6q8_bn<64>(a, a_kcontig, b_kcontig, items, stream);
+    } else if (use_x6 && g_x6 == 4 && persistent_ok)
+        launch_x6q<true>(a, bn, a_kcontig, b_kcontig, items, stream);
+    else if (use_x6 && g_x6 == 2 && persistent_ok)
+        launch_x6p(a, bn, a_kcontig, b_kcontig, items, stream);
+    else if (use_x6 && (g_x6 == 1 || !persistent_ok))
         launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);
+    else
+#endif
+    if (use_x6)
+        launch_x6q<false>(a, bn, a_kcontig, b_kcontig, items, stream);
     else if (bm == 128)
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else

@@ -502,6 +502,9 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
         _chk(_L().ix_flash_fwd_fp8_f32(q8.data_ptr(), qus.data_ptr(), k8.data_ptr(), kus.data_ptr(), v8.data_ptr(), vus.data_ptr(),
                                        pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
                                        g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_fp8_f32")
+        if need_backward:   # the derivative kernels recompute the scores from the fp16 planes: give them THEIR normalisers
+            _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, None, pl["bias"].data_ptr(), None, lse.data_ptr(), g.n, g.heads,
+                                       g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, 0.0, 0, _stream()), "ix_flash_fwd_f32")
         return out, lse, pl
     _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(),
                                g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_f32")
