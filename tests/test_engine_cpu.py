@@ -139,3 +139,58 @@ def test_logger_and_factories(tmp_path):
         build_trainer(None, cfg)
     with pytest.raises(AssertionError):
         build_evaluator(None, cfg)
+
+
+# ---- N3: the data path against fixture G17 (the reference's own datasets / transforms on tests/golden/data) ---------------
+def _check_summary(rec, t, what):
+    assert tuple(t.shape) == tuple(rec["shape"]) and str(t.dtype) == rec["dtype"], (what, tuple(t.shape), rec["shape"])
+    flat = t.reshape(-1)
+    torch.testing.assert_close(flat[rec["idx"]], rec["sample"], atol=1e-6, rtol=1e-6, msg=lambda m: what + ": " + m)
+    assert abs(float(flat.double().norm()) - rec["norm"]) <= 1e-6 * max(rec["norm"], 1.0), what
+
+
+def _check_sample(rec, s, root, what):
+    for i, (f, r) in enumerate(zip(s["frames"], rec["frames"])):
+        _check_summary(r, f, "%s/frame%d" % (what, i))
+    assert [tuple(m.shape) for m in s["masks"]] == rec["masks"] and all(m.dtype == torch.long for m in s["masks"])
+    assert list(s["actions"]) == rec["actions"] and [len(o) for o in s["object_ids"]] == rec["n_objects"]
+    for a, b in zip(s["category_ids"], rec["category_ids"]):
+        assert a.dtype == b.dtype and torch.equal(a, b), what
+    for a, b in zip(s["boxes"], rec["boxes"]):
+        torch.testing.assert_close(a, b, atol=1e-7, rtol=1e-6, msg=lambda m: what + " boxes: " + m)
+    assert s["episode_ids"] == rec["episode_ids"] and os.path.relpath(s["initial_image_path"], root) == rec["initial_image_path"]
+
+
+def test_g17_sequence_dataset_collate_and_interactive_match_reference(golden):
+    """SequenceDataset (test mode + an explicit action script), collate_fn and InteractiveDataset reset / step on the
+    committed tiny dataset == what the imported reference returned (tests/golden/make_golden_data.py): decoded and
+    normalised pixels, label offset, cxcywh boxes (incl. a 400x300 scene that is really resized and a state without
+    detections), mask shapes, action indices, episode ids and paths."""
+    G = golden("golden_data.pt")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    imgs, ann = os.path.join(root, "imgs"), os.path.join(root, "annotations.json")
+    ds = SequenceDataset(imgs + "/", ann, "test", transform=transform)
+    assert len(ds) == G["len"]
+    for i, rec in enumerate(G["samples"]):
+        _check_sample(rec, ds[i], root, "episode%d" % i)
+    _check_sample(G["scripted"], ds.__getitem__(1, actions=["MoveBack", "MoveBack", "RotateRight", "MoveAhead", "RotateLeft"]),
+                  root, "scripted")
+    batch = collate_fn([ds[0], ds[1]])
+    c = G["collate"]
+    _check_summary(c["frames"], batch["frames"], "collate/frames")
+    assert tuple(batch["masks"].shape) == c["masks"] and torch.equal(batch["actions"], c["actions"])
+    assert torch.equal(batch["episode_ids"], c["episode_ids"])
+    assert [os.path.relpath(p, root) for p in batch["initial_image_path"]] == c["initial_image_path"]
+    for ep, rep in zip(batch["category_ids"], c["category_ids"]):
+        assert all(torch.equal(a, b) for a, b in zip(ep, rep))
+    env = InteractiveDataset(imgs, ann, "test", transform=transform)
+    for trace in G["interactive"]:
+        obs = [env.reset()] + [env.step(a) for a in trace["script"]]
+        for k, (d, rec) in enumerate(zip(obs, trace["steps"])):
+            what = "interactive/%s/%d" % (trace["script"], k)
+            _check_summary(rec["frames"], d["frames"], what)
+            assert torch.equal(d["actions"], rec["actions"]) and int(d["episode_ids"]) == rec["episode_ids"], what
+            assert [os.path.relpath(p, root) for p in d["initial_image_path"]] == rec["initial_image_path"]
+            for a, b in zip(d["boxes"][0], rec["boxes"]):
+                torch.testing.assert_close(a, b, atol=1e-7, rtol=1e-6)
+            assert all(torch.equal(a, b) for a, b in zip(d["category_ids"][0], rec["category_ids"]))
