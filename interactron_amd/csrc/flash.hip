@@ -190,14 +190,13 @@ extern "C" int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, 
 // whichever way their tiles are oriented.  keep <=> draw >= thr16, thr16 = round(p * 65536).
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned fl_hash(unsigned seed_lo, unsigned seed_hi, unsigned rid, unsigned kpair) {
-    unsigned x = seed_lo ^ (rid * 0x9E3779B1u) ^ (kpair * 0x85EBCA77u);
-    x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= seed_hi;
-    x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    x ^= x >> 16;
-    return x;
+    // one multiply-fold round on (row term) ^ (key-pair term): in the kernels one of the two terms is invariant per lane
+    // and the other advances by a wave-uniform amount per tile, so a draw costs an add, an xor, the 32 x 32 -> 64-bit
+    // product and a fold (the earlier two-multiply xorshift mix was a third of the forward kernel's vector instructions)
+    const unsigned a = (rid * 0x9E3779B1u) ^ seed_lo;
+    const unsigned b = kpair * 0x85EBCA77u + seed_hi;
+    const unsigned long long m = (unsigned long long)(a ^ b) * 0xD6E8FEB9ull;
+    return (unsigned)m ^ (unsigned)(m >> 32);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """Fold two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) into
-profiles/<tag>_pmc_hbm_traffic.json: HBM bytes per launch of every contraction kernel.
+profiles/<tag>_pmc_hbm_traffic.json: HBM bytes per launch of every contraction and flash attention kernel.
 usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import collections, csv, json, re, sys
 
@@ -8,7 +8,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(gemm_f32_\w+?kernel)", r["Kernel_Name"])
+        m = re.search(r"(gemm_f32_\w+?kernel|flash_\w+?_kernel)", r["Kernel_Name"])
         if not m:
             continue
         tot[m.group(1)] += float(r["Counter_Value"]) * 1024.0   # both counters are in KiB

@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "load":
     import torch
     from interactron_amd import _lib
     lib = _lib.load()
-    lib.ix_gemm_set_mode(int(sys.argv[2]))
+    lib.ix_gemm_set_mode(int(sys.argv[2]))   # test hook: 3 = bf16x6 kernel, 0 = exact-fp32 kernel
     th = int(sys.argv[3])
     M = N = K = 4096
     A = torch.randn(M * K, device="cuda"); B = torch.randn(K * N, device="cuda"); C = torch.empty(M, N, device="cuda")

@@ -1,0 +1,26 @@
+#!/bin/sh
+# One round's measurement artefacts (run on the GPU box through gpurun; results land in gpurun_out/$1/ and are copied into
+# profiles/ by hand): driver-style bench line, rocprofv3 kernel stats of the same command, the two PMC HBM-traffic passes,
+# SQ counters, the other reference configs / evaluation modes, the stress configuration, the 2-rank launcher smoke, power probe.
+TAG=${1:-r2a}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_p300_e16_profiled.json 2> $OUT/prof.err
+cp $OUT/prof/p_kernel_stats.csv $OUT/${TAG}_bench_p300_e16_kernel_stats.csv; rm -rf $OUT/prof
+rocprofv3 --kernel-trace --stats -d $OUT/prof8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 4 --chunk 4 --steps 2 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_800_e4_profiled.json 2> $OUT/prof8.err
+cp $OUT/prof8/p_kernel_stats.csv $OUT/${TAG}_bench_800_e4_kernel_stats.csv; rm -rf $OUT/prof8
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+python tools/pmc_summary.py $OUT/pf/p_counter_collection.csv $OUT/pw/p_counter_collection.csv $OUT/${TAG}_pmc_hbm_traffic.json > /dev/null; rm -rf $OUT/pf $OUT/pw
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/ps -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+python tools/pmc_sq_summary.py $OUT/ps/p_counter_collection.csv $OUT/${TAG}_pmc_sq_counters.json > /dev/null
+python tools/pmc_flash_summary.py $OUT/ps/p_counter_collection.csv $OUT/${TAG}_pmc_sq_counters_flash.json > /dev/null; rm -rf $OUT/ps
+for c in interactron_random multi_frame_baseline single_frame_baseline; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_$c.json 2>/dev/null; done
+for m in predict predict-batched interactive; do python bench.py --mode $m --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > $OUT/${TAG}_bench_mode_$m.json 2>/dev/null; done
+python bench.py --size 1600 --queries 200 --attention-dtype fp8 --episodes 1 --chunk 1 --steps 2 --warmup 1 --n800-episodes 0 > $OUT/${TAG}_bench_stress_1600_q200_fp8.json 2>/dev/null
+python bench.py --size 1600 --queries 200 --attention-dtype fp8 --mode predict --episodes 1 --steps 2 --warmup 1 --n800-episodes 0 --no-roofline > $OUT/${TAG}_bench_stress_1600_q200_fp8_predict.json 2>/dev/null
+IX_DIST_BACKEND=gloo python bench.py --gpus 2 --episodes 4 --chunk 4 --steps 2 --warmup 1 --n800-episodes 0 --no-roofline > $OUT/${TAG}_bench_2ranks_gloo_one_gpu.json 2>/dev/null
+python tools/power_probe.py > $OUT/${TAG}_power_probe.txt 2>&1
+ls -la $OUT
