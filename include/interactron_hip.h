@@ -150,8 +150,8 @@ int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, 
  *   point does not read may be null: forward reads q.row, k.row, v.tr).
  * ix_attn_bias_f32: key_padding_mask uint8 [n][mask_ld] (nonzero = ignore; null = none) -> additive bias [n][Sb],
  *   Sb >= S (the kernels want S rounded up to 128): 0 for valid keys, -inf for masked keys and the tail.
- * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; the
- *   caller pre-fills +inf so that padded query rows count as P = 0 in the derivative kernels).
+ * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; rows
+ *   L..Lp are written as +inf so that padded query rows count as P = 0 in the derivative kernels).
  *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key).
  *   out == null: only lse is produced (q k^T + softmax statistics) -- used after the fp8 forward, whose own normalisers
  *   belong to fp8 scores and not to the fp16 scores the derivative kernels recompute.

@@ -447,6 +447,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
             FL_STORE_ROWS(o, dst, inv)
         }
         if (a == 0) p.lse[(int64_t)bh * p.Lp + q] = (m + log2f(l)) * FL_LN2;
+    } else if (a == 0) {
+        p.lse[(int64_t)bh * p.Lp + q] = INFINITY;   // padded query rows: the derivative kernels then see P = 0 there
     }
 }
 
@@ -1404,6 +1406,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_fp8_kernel(FlashFp8Args p) {
         float* dst = p.out + ((int64_t)b * p.L + q) * p.ld_out + p.off_out + h * HD + 4 * a;
         FL_STORE_ROWS(o, dst, inv)
         if (a == 0) p.lse[(int64_t)bh * p.Lp + q] = (m + log2f(l)) * FL_LN2;
+    } else if (a == 0) {
+        p.lse[(int64_t)bh * p.Lp + q] = INFINITY;
     }
 }
 

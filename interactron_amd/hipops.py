@@ -452,12 +452,26 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True):
     return AttnPlanes(rowp, us, trp)
 
 
+_bias_cache = {}
+
+
 def attn_bias(mask, n, S, device):
-    """additive key bias [n, Sp]: 0 valid / -inf masked or tail (Sp = S rounded up to 128); mask uint8 [n, S] or None."""
+    """additive key bias [n, Sp]: 0 valid / -inf masked or tail (Sp = S rounded up to 128); mask uint8 [n, S] or None.
+    Without a mask the bias depends on (n, S) only and is kept (the GPT fusion asks for the same one in every layer of
+    every step); with a mask it is kept for as long as the SAME mask tensor (address, version) is presented -- the six
+    encoder and six decoder layers of one detector pass share one key_padding_mask."""
     Sb = _pad128(S)
+    key = (device.index, n, S) if mask is None else (device.index, n, S, mask.data_ptr(), mask._version)
+    hit = _bias_cache.get(key)
+    if hit is not None and (mask is None or hit[1] is mask):
+        return hit[0]
     bias = torch.empty(n, Sb, dtype=torch.float32, device=device)
     _chk(_L().ix_attn_bias_f32(mask.data_ptr() if mask is not None else None, bias.data_ptr(), n, S, Sb,
                                mask.shape[-1] if mask is not None else 0, _stream()), "ix_attn_bias_f32")
+    if mask is not None:   # one masked entry at a time (masks change with every batch)
+        for k in [k for k in _bias_cache if len(k) == 5]:
+            del _bias_cache[k]
+    _bias_cache[key] = (bias, mask)
     return bias
 
 
@@ -494,7 +508,7 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
         pl["v"] = attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=need_backward)
     Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
     out = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
-    lse = torch.full((g.n * g.heads, Lp), float("inf"), dtype=torch.float32, device=dev)   # +inf: P = 0 for padded queries
+    lse = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)   # (rows L..Lp come back as +inf: P = 0 there)
     if fp8:
         q8, _, qus = attn_split_fp8(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
         k8, _, kus = attn_split_fp8(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
