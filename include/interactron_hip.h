@@ -42,6 +42,21 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
                 int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride_outer, float alpha,
                 int tile_hint, int split_k_hint, ix_stream_t stream);
 
+/* ix_gemm_f32_ws: the same contraction with caller-provided scratch memory.  With `workspace` (device, at least
+ * ix_workspace_bytes_gemm_f32(...) bytes; that function returns 0 for calls that do not need any) eligible contractions run
+ * on the pre-split fp16x3 kernel (csrc/gemm_x3.hip): each operand is converted ONCE into two fp16 planes with a power-of-two
+ * scale per block of 32 rows (taken over the whole contracted extent), the GEMM kernel streams those planes and issues three
+ * v_mfma_f32_32x32x16_f16 terms per 16 contracted elements -- fp32-grade accuracy at half the matrix instructions of the
+ * bf16x6 kernel and without its per-tile conversion work.  Without a workspace the call is ix_gemm_f32. */
+int ix_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int a_kcontig,
+                   int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo,
+                   int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride_outer, float alpha,
+                   int tile_hint, int split_k_hint, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int batch_outer,
+                                int batch_inner, int64_t sAo, int64_t sBo, const float* A, const float* B, int tile_hint,
+                                int split_k_hint, size_t* out_host);
+int ix_prof_x3(double* ms, double* flops, int64_t* calls); /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
+
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
  * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */

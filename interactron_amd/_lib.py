@@ -8,7 +8,7 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libinteractron_hip.so")
+LIB_PATH = os.environ.get("IX_LIB_PATH") or os.path.join(_PKG, "lib", "libinteractron_hip.so")   # (IX_LIB_PATH: diagnostic builds)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "interactron_hip.h")
 
 _SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "float": ctypes.c_float,

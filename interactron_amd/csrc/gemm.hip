@@ -25,6 +25,7 @@
 // Split-K (atomic f32 accumulation into a zeroed C) fills the chip for the weight-gradient shapes
 // (small M x N, K = tokens).
 #include "common.h"
+#include "gemm_x3.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1496,6 +1497,7 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
         float t = 0.f;
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
         const ProfRec& r = g_rec[i / 2];
+        if (r.bm == 3128) continue;   // pre-split fp16x3 kernel: reported by ix_prof_x3
         const int k = r.bm == 2002 ? 2 : (r.bm == 1128 ? 1 : 0);
         ms[k] += t;
         fl[k] += r.flops;
@@ -1533,6 +1535,25 @@ extern "C" int ix_prof_flash(double* ms7, double* flops7, double* mfma_flops7, i
         if (mfma_flops7) mfma_flops7[k] = mf[k];
         if (launches7) launches7[k] = n[k];
     }
+    return IX_OK;
+}
+
+// Profiled launches of the pre-split fp16x3 contraction path (two operand-split kernels + the GEMM kernel per call, one
+// event bracket around all three): summed time (ms), algorithmic FLOPs, calls.  Call before ix_gemm_prof_read.
+extern "C" int ix_prof_x3(double* ms, double* flops, int64_t* calls) {
+    double m = 0, f = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm != 3128) continue;
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        m += t; f += r.flops; n += 1;
+    }
+    if (ms) *ms = m;
+    if (flops) *flops = f;
+    if (calls) *calls = n;
     return IX_OK;
 }
 
@@ -1586,16 +1607,85 @@ void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops
 }
 void ix_prof_end(hipStream_t stream) { prof_mark(stream); }
 
+// Which contractions ix_gemm_f32_ws can run on the pre-split fp16x3 kernel (gemm_x3.hip): 16-byte-aligned operands, one
+// batch level, no tile or split hint, enough work that two conversion launches pay (>= 0.25 GFLOP), K and N large enough
+// for its 128 x {128, 64} tiles.  The caller opts in per call by passing a workspace (hipops: IX_GEMM_X3=1).
+static bool x3_eligible(int M, int N, int K, int batch_outer, int batch_inner, int64_t lda, int64_t ldb, int64_t sAo,
+                        int64_t sBo, const float* A, const float* B, int tile_hint, int split_k_hint) {
+    if (g_x6 == 0 || tile_hint != 0 || split_k_hint != 0 || batch_inner != 1) return false;
+    if (K < 64 || N < 48 || M < 64) return false;
+    if ((lda % 4) || (ldb % 4) || (sAo % 4) || (sBo % 4) || !aligned16(A) || !aligned16(B)) return false;
+    return 2.0 * (double)M * (double)N * (double)K * (double)batch_outer >= 0.25e9;
+}
+
+extern "C" int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb,
+                                           int batch_outer, int batch_inner, int64_t sAo, int64_t sBo, const float* A,
+                                           const float* B, int tile_hint, int split_k_hint, size_t* out) {
+    IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_gemm_f32: null out");
+    (void)a_kcontig; (void)b_kcontig;
+    *out = x3_eligible(M, N, K, batch_outer, batch_inner, lda, ldb, sAo, sBo, A, B, tile_hint, split_k_hint)
+               ? ix_x3_workspace_bytes(M, N, K, sAo ? batch_outer : 1, sBo ? batch_outer : 1) : 0;
+    return IX_OK;
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                     int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
+                     int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
+                     int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
                            int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
                            int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
                            hipStream_t stream) {
+    return gemm_impl(A, B, C, bias, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, batch_inner, sAo, sAi, sBo, sBi,
+                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, nullptr, 0, stream);
+}
+
+extern "C" int ix_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                              int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
+                              int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
+                              int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
+                              void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return gemm_impl(A, B, C, bias, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, batch_inner, sAo, sAi, sBo, sBi,
+                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, workspace, workspace_bytes, stream);
+}
+
+static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                     int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
+                     int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
+                     int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
+                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
     IX_CHECK_ARG(A && B && C, "ix_gemm_f32: null operand");
     IX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 1, "ix_gemm_f32: bad dims");
     const int nbatch = batch_outer * batch_inner;
     if (M == 0 || N == 0 || nbatch == 0) return IX_OK;
     IX_CHECK_ARG(nbatch <= 65535, "ix_gemm_f32: batch %d > 65535", nbatch);
+    if (workspace && x3_eligible(M, N, K, batch_outer, batch_inner, lda, ldb, sAo, sBo, A, B, tile_hint, split_k_hint)) {
+        const size_t need = ix_x3_workspace_bytes(M, N, K, sAo ? batch_outer : 1, sBo ? batch_outer : 1);
+        if (workspace_bytes < need) {
+            ix_set_error("ix_gemm_f32_ws: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+            return IX_ERR_WORKSPACE;
+        }
+        X3Call c;
+        c.A = A; c.B = B; c.C = C; c.bias = bias; c.M = M; c.N = N; c.K = K; c.a_kc = a_kcontig; c.b_kc = b_kcontig;
+        c.nbatch = batch_outer; c.lda = lda; c.ldb = ldb; c.ldc = ldc; c.sA = sAo; c.sB = sBo; c.sC = sCo;
+        c.sBias = bias_stride_outer; c.alpha = alpha;
+        const double fl = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+        g_flops += fl;
+        g_launches += 1;
+        if (g_prof_on) {
+            ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, 3128, 1};
+            r.flops = fl;
+            g_rec.push_back(r);
+        }
+        prof_mark(stream);
+        ix_x3_gemm(c, workspace, stream);
+        prof_mark(stream);
+        IX_CHECK_LAUNCH("ix_gemm_f32_ws");
+        return IX_OK;
+    }
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias;
     a.M = M; a.N = N; a.K = K;

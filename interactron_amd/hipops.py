@@ -9,6 +9,7 @@ meta-gradient of reference models/interactron.py:99-123 -- runs entirely on thes
 No CPU fallback exists: calling any op without the built library or with CPU tensors raises.
 """
 import ctypes
+import os
 from collections import namedtuple
 
 import torch
@@ -122,6 +123,28 @@ def _numel(shape):
     return n
 
 
+# Pre-split fp16x3 contraction route (csrc/gemm_x3.hip), opt-in: IX_GEMM_X3=1.  Measured on the step's shapes
+# (tools/x3_bench.py, profiles/r2b_x3_bench.json): 1.2-1.4x the bf16x6 kernel where both operands are stored with the
+# contracted index contiguous and N >= 1024 (the operand-split passes amortise over N), slower elsewhere -- so only those
+# shapes are routed, and the default stays bf16x6 for every contraction.
+GEMM_X3 = os.environ.get("IX_GEMM_X3", "0") == "1"
+_ws_bytes = {}   # contraction signature -> scratch bytes of its fp16x3 route (0: bf16x6 / fp32 kernels)
+
+
+def _gemm_workspace_bytes(pa, pb, sp):
+    if not GEMM_X3 or sp.A.trans or not sp.B.trans or sp.N < 1024 or sp.M < 1024:
+        return 0
+    key = (sp.M, sp.N, sp.K, sp.bo, sp.bi, sp.A.ld, sp.B.ld, sp.A.so, sp.B.so, pa & 15, pb & 15)
+    n = _ws_bytes.get(key)
+    if n is None:
+        out = ctypes.c_size_t(0)
+        _chk(_L().ix_workspace_bytes_gemm_f32(sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0, sp.A.ld,
+                                              sp.B.ld, sp.bo, sp.bi, sp.A.so, sp.B.so, pa, pb, 0, 0, ctypes.byref(out)),
+             "ix_workspace_bytes_gemm_f32")
+        n = _ws_bytes[key] = out.value
+    return n
+
+
 def _run_gemm(a, b, bias, sp, fill=True):
     """fill=False: the caller guarantees nobody reads the elements of `out` the product does not write (the pad columns
     of attention tensors: every consumer stops at the row length) -- saves a memset of the whole tensor."""
@@ -129,12 +152,16 @@ def _run_gemm(a, b, bias, sp, fill=True):
     out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
     assert not sp.C.trans
     esz = 4
-    rc = _L().ix_gemm_f32(a.data_ptr() + sp.A.offset * esz, b.data_ptr() + sp.B.offset * esz,
-                          out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
-                          sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
-                          sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
-                          sp.N if (bias is not None and bias.dim() == 2) else 0, sp.alpha, 0, 0, _stream())
-    _chk(rc, "ix_gemm_f32")
+    pa, pb = a.data_ptr() + sp.A.offset * esz, b.data_ptr() + sp.B.offset * esz
+    nws = _gemm_workspace_bytes(pa, pb, sp)
+    ws = torch.empty(nws, dtype=torch.uint8, device=a.device) if nws else None
+    rc = _L().ix_gemm_f32_ws(pa, pb,
+                             out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
+                             sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
+                             sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
+                             sp.N if (bias is not None and bias.dim() == 2) else 0, sp.alpha, 0, 0,
+                             ws.data_ptr() if nws else None, nws, _stream())
+    _chk(rc, "ix_gemm_f32_ws")
     return out
 
 

@@ -463,6 +463,55 @@ def test_bf16x6_contraction_is_fp32_grade(ops, akc, bkc):
         assert errs[1128] <= 2.0 * errs[128] + 1e-7, (M, N, K, errs)
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
+    """The pre-split fp16x3 route of ix_gemm_f32_ws (two fp16 planes + one power-of-two scale per 32 rows, three fp16 MFMA
+    terms) against float64: every operand layout, ragged M/N/K, batches, shared operands (stride 0), bias, alpha, the
+    split-K tail, rows whose magnitudes differ by e^+-8 between 32-row blocks, and a 2^18 spread INSIDE rows (the low
+    plane then leaves fp16's normal range; its error must stay below the fp32 rounding of the dominant terms)."""
+    from interactron_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, b, shareB, spread) in [(132, 76, 2048, 8, False, 0), (300, 260, 1808, 2, True, 0), (1804, 512, 260, 1, False, 0),
+                                         (5000, 64, 520, 1, False, 0), (364, 48, 4000, 3, False, 0), (256, 256, 16640, 1, False, 0),
+                                         (516, 132, 1024, 2, False, 18)]:
+        a = rnd(b, M, K, seed=1) * (2.0 * rnd(b, M, 1, seed=2)).exp()
+        if spread:
+            a = a * torch.exp2(-spread * torch.rand(b, M, K, generator=torch.Generator().manual_seed(5)))
+        a = a.cuda()
+        w = rnd(1 if shareB else b, K, N, seed=3).cuda()
+        bias = rnd(N, seed=4).cuda()
+        ref = 0.37 * (a.double() @ w.double()) + bias.double()
+        scale = 0.37 * (a.double().abs() @ w.double().abs()) + bias.double().abs() + 1e-30
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        lda, ldb = (K if akc else M), (K if bkc else N)
+        sB = 0 if shareB else K * N
+        nws = ctypes.c_size_t(0)
+        rc = lib.ix_workspace_bytes_gemm_f32(M, N, K, akc, bkc, lda, ldb, b, 1, M * K, sB, A.data_ptr(), B.data_ptr(), 0, 0,
+                                             ctypes.byref(nws))
+        assert rc == 0 and nws.value > 0, (M, N, K, "expected the fp16x3 route")
+        ws = torch.empty(nws.value, dtype=torch.uint8, device="cuda")
+        errs = {}
+        for name in ("x3", "fp32"):
+            C = torch.full((b, M, N), float("nan"), device="cuda")
+            if name == "x3":
+                rc = lib.ix_gemm_f32_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc, lda, ldb,
+                                        N, b, 1, M * K, 0, sB, 0, M * N, 0, 0, 0.37, 0, 0, ws.data_ptr(), nws.value, stream)
+            else:
+                rc = lib.ix_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc, lda, ldb,
+                                     N, b, 1, M * K, 0, sB, 0, M * N, 0, 0, 0.37, 128, 1, stream)
+            assert rc == 0, lib.ix_last_error()
+            errs[name] = float(((C.double() - ref).abs() / scale).max())
+        assert errs["x3"] <= 6e-7, (M, N, K, errs)
+        assert errs["x3"] <= 2.0 * errs["fp32"] + 1e-7, (M, N, K, errs)
+    # too small a workspace is refused, not overrun
+    rc = lib.ix_gemm_f32_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, akc, bkc, lda, ldb, N, b, 1, M * K, 0, sB, 0,
+                            M * N, 0, 0, 1.0, 0, 0, ws.data_ptr(), 64, stream)
+    assert rc != 0
+
+
 def test_episode_batched_linear_layernorm_rowvec(ops):
     """Grouped forms used by the episode-batched fast weights: weight [E,N,K] + bias [E,N], LayerNorm affine [E,D],
     per-episode row vector -- forward, first and second order against per-episode float64 references."""
