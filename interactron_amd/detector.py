@@ -85,7 +85,7 @@ class ResNet50Body(nn.Module):
         with torch.no_grad():
             g = ops.conv_geom(n, H, W, c, 7, 7, 2, 3, 1)
             cols = ops.im2col_any_layout(frames_nchw, g, channels_last=False)
-            w = self.conv1.weight.permute(0, 2, 3, 1).reshape(64, -1)
+            w = self.conv1.weight.reshape(64, -1)   # stored [out, kh, kw, in]
             if g.Kp != w.shape[1]:
                 w = torch.nn.functional.pad(w, (0, g.Kp - w.shape[1]))
             x = ops.linear(cols, w).reshape(n, g.OH, g.OW, 64)

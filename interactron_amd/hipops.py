@@ -1156,26 +1156,25 @@ def maxpool_nhwc(x, k, stride, pad):
 
 
 def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
-    """x [n,H,W,Cin] NHWC, weight [Cout,Cin,KH,KW] (reference layout) -> [n,OH,OW,Cout]."""
+    """x [n,H,W,Cin] NHWC, weight [Cout,KH,KW,Cin] (nn.Conv2dNHWC's storage layout: the patch-matrix column order
+    (kh, kw, cin), so it is the contraction's k-contiguous operand as stored) -> [n,OH,OW,Cout]."""
     n, H, W, C = x.shape
-    if weight.dim() == 5:   # episode-batched fast weights [E, Cout, Cin, KH, KW]; frames of episode e are x[e*n/E:(e+1)*n/E]
-        E, Cout, Cin, KH, KW = weight.shape
+    if weight.dim() == 5:   # episode-batched fast weights [E, Cout, KH, KW, Cin]; frames of episode e are x[e*n/E:(e+1)*n/E]
+        E, Cout, KH, KW, Cin = weight.shape
         assert Cin == C and n % E == 0
         if KH == 1 and KW == 1 and stride == 1 and pad == 0:
             return linear(x, weight.reshape(E, Cout, Cin))
         g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
         cols = Im2Col.call(x, g)
-        w2 = weight.permute(0, 1, 3, 4, 2).reshape(E, Cout, KH * KW * Cin)
         assert g.Kp == KH * KW * Cin, "episode-batched convs need KH*KW*Cin % 4 == 0"
-        return linear(cols.reshape(E, -1, g.Kp), w2).reshape(n, g.OH, g.OW, Cout)
-    Cout, Cin, KH, KW = weight.shape
+        return linear(cols.reshape(E, -1, g.Kp), weight.reshape(E, Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
+    Cout, KH, KW, Cin = weight.shape
     assert Cin == C
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
         return linear(x, weight.reshape(Cout, Cin))
     g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
     cols = Im2Col.call(x, g)
-    w2 = weight.permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin)   # (kh, kw, cin) fastest = patch-matrix column order
-    return linear(cols, w2).reshape(n, g.OH, g.OW, Cout)
+    return linear(cols, weight.reshape(Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -135,12 +135,33 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 class Conv2dNHWC(nn.Module):
-    """Bias-free convolution, weight stored [out, in, kh, kw] like the reference; activations NHWC."""
+    """Bias-free convolution on NHWC activations.
+
+    The parameter lives in HBM as [out, kh, kw, in] -- the column order of the patch matrix, so the contraction reads it
+    (and every per-episode fast weight derived from it) as a plain k-contiguous operand with no per-call permute copy.
+    ``state_dict`` / ``load_state_dict`` speak the reference's [out, in, kh, kw] layout (checkpoint compatibility)."""
 
     def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1):
         super().__init__()
         self.stride, self.padding, self.dilation = stride, padding, dilation
-        self.weight = _uniform((cout, cin, k, k), math.sqrt(6.0 / (cin * k * k)))
+        w = _uniform((cout, cin, k, k), math.sqrt(6.0 / (cin * k * k)))   # drawn in the reference's element order
+        self.weight = nn.Parameter(w.data.permute(0, 2, 3, 1).contiguous())
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        w = destination[prefix + "weight"]
+        destination[prefix + "weight"] = w.permute(0, 3, 1, 2)   # [out, in, kh, kw] view of the same storage
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "weight"
+        w = state_dict.get(key)
+        if w is not None and w.dim() == 4:
+            state_dict[key] = w.permute(0, 2, 3, 1)
+        try:
+            super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        finally:
+            if w is not None:
+                state_dict[key] = w
 
     def forward(self, x):
         return ops.conv2d_nhwc(x, self.weight, self.stride, self.padding, self.dilation)

@@ -27,6 +27,8 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
         return
     assert g is not None, what + ": reference has a gradient here"
     g = g.detach().cpu()
+    if g.dim() == 4 and tuple(g.shape) != tuple(rec["shape"]):
+        g = g.permute(0, 3, 1, 2).contiguous()   # conv weights are stored [out, kh, kw, in]; the fixtures are [out, in, kh, kw]
     assert tuple(g.shape) == tuple(rec["shape"]), what
     n = float(g.double().norm())
     if max(n, rec["norm"]) < noise:

@@ -206,7 +206,8 @@ def test_conv2d_nhwc(ops, cin, cout, k, stride, pad, dil, hw):
     def ref(x, w):
         return F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil).permute(0, 2, 3, 1)
 
-    check_op(lambda x, w: ops.conv2d_nhwc(x, w, stride, pad, dil), ref,
+    # the op takes the weight in its storage layout [out, kh, kw, in]; gradients are compared on the [out, in, kh, kw] leaf
+    check_op(lambda x, w: ops.conv2d_nhwc(x, w.permute(0, 2, 3, 1).contiguous(), stride, pad, dil), ref,
              [rnd(2, hw, hw + 1, cin), rnd(cout, cin, k, k, scale=(cin * k * k) ** -0.5)], name="conv")
 
 
@@ -540,7 +541,8 @@ def test_episode_batched_conv(ops):
             per = n // E
             out = [F.conv2d(x[e * per:(e + 1) * per].permute(0, 3, 1, 2), w[e], None, stride, pad, dil) for e in range(E)]
             return torch.cat(out).permute(0, 2, 3, 1)
-        check_op(lambda x, w: ops.conv2d_nhwc(x, w, stride, pad, dil), ref, [x, w], name="batched conv k%d s%d d%d" % (k, stride, dil))
+        check_op(lambda x, w: ops.conv2d_nhwc(x, w.permute(0, 1, 3, 4, 2).contiguous(), stride, pad, dil), ref, [x, w],
+                 name="batched conv k%d s%d d%d" % (k, stride, dil))
 
 
 # ---- flash-style attention (csrc/flash.hip) ---------------------------------------------------------------------------
