@@ -76,6 +76,20 @@ int ix_gemm_prof_read(double* total_ms, int64_t* pairs);
 int ix_gemm_prof_dump(const char* path_host); /* per-launch CSV (shape, tile, split, ms); call before ix_gemm_prof_read */
 
 /* ---- convolution gather / scatter (NHWC) -- torchvision resnet50 convs, backbone.py:88-90 ------------------- */
+/* Implicit-GEMM convolution on the bf16x6 contraction kernel -- no patch matrix in HBM: the kernel's producer waves gather
+ * the NHWC taps themselves.  Bias-free convolution with weights stored [out][kh][kw][in] (nn.Conv2dNHWC's layout):
+ *   kind 0: src = x [groups*imgs, H, W, Cin],   other = w [groups, Cout, KH, KW, Cin] -> out = y  [groups*imgs, OH, OW, Cout]
+ *   kind 1: src = dy [groups*imgs, OH, OW, Cout], other = w                           -> out = dx [groups*imgs, H, W, Cin]
+ *   kind 2: src = dy,                            other = x                            -> out = dw [groups, Cout, KH, KW, Cin]
+ * groups = episodes with their own fast weights (shared weights: groups = 1, imgs = every image).  The three kinds are each
+ * other's derivatives (reference: torch.nn.functional.conv2d under autograd, models/detr_models/backbone.py:88-90 layer2-4
+ * 3x3 convolutions, incl. the dilated stage).  ix_conv_gemm_supported: Cin, Cout multiples of 64, stride 1 / 2 / 4, each
+ * group's tensors below 2 GiB; otherwise callers use ix_im2col_f32 + ix_gemm_f32 (+ ix_col2im_f32). */
+int ix_conv_gemm_supported(int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                           int pad, int dil);
+int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W, int Cin,
+                     int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, ix_stream_t stream);
+
 int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,
                   int64_t sxc, int KH, int KW, int stride, int pad, int dil, int Kp, ix_stream_t stream);
 int ix_col2im_f32(const float* cols, float* dx, int n, int H, int W, int C, int KH, int KW, int stride, int pad,

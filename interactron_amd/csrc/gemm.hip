@@ -29,6 +29,39 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Division by an invariant positive integer d:  n / d = (mulhi(n, m) + n) >> s  for 0 <= n < 2^31 (host: make_fastdiv).
+struct FastDiv {
+    unsigned m;
+    int s;
+};
+__device__ __forceinline__ int fd_div(int n, FastDiv f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.s); }
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    f.s = 0;
+    while ((1ull << f.s) < d) ++f.s;
+    f.m = (unsigned)((((1ull << 32) * ((1ull << f.s) - d)) / d) + 1);
+    return f;
+}
+
+// Implicit-GEMM convolution on the bf16x6 kernel: instead of a patch matrix in HBM (im2col) the producer waves compute,
+// per 16-byte load, where the element lives in the NHWC tensor.  A "pixel row" index decomposes over a grid
+//     row = (img * gH + gy) * gW + gx
+// and tap (ky, kx) of that pixel reads the source tensor [img][sH][sW][sC] at
+//     sy = (gy * a + b + ky * d) >> qs,  sx = (gx * a + b + kx * d) >> qs      (valid iff both divisible by 1 << qs and inside)
+// -- forward / weight gradient: grid = output pixels, a = stride, b = -pad, d = dilation, qs = 0;  data gradient: grid =
+// input pixels, source = dY, a = 1, b = pad, d = -dilation, qs = log2(stride).  Invalid taps are requested out of range
+// (the buffer load returns zeros without touching memory).
+//   mode_a 1: A rows are pixels, k = (tap, c) -- a K tile of 32 lies inside one tap (sC % 32 == 0)
+//   mode_b 2: B rows k are pixels, n = (tap, c) -- an N tile lies inside one tap (sC % BN == 0)        (weight gradient)
+//   mode_b 3: B rows k = (tap, co) live at W[co][tap][c]: offset (k % bmod) * ldb + (k / bmod) * btap     (data gradient)
+struct ConvGather {
+    int mode_a, mode_b;
+    int gH, gW, sH, sW, sC;
+    int a, b, d, qs, KW;
+    int bmod, btap;
+    FastDiv dW, dHW, dC, dKW, dBmod;   // divisions by gW, gH * gW, sC, KW, bmod
+};
+
 struct GemmArgs {
     const float* A;
     const float* B;
@@ -45,6 +78,7 @@ struct GemmArgs {
     float alpha;
     int a_vec, b_vec, c_vec;
     int tiles_m, tiles_n;
+    struct ConvGather cg;   // implicit-GEMM convolution operands (ix_conv_gemm_f32); mode 0 for plain contractions
 };
 
 // XCD-aware, bijective remap: consecutive logical tiles land on the same XCD (same L2).
@@ -367,6 +401,74 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
                 off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
             off = valid ? off * 4 : 0x7ffffff0;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
+
+    // ---- implicit-GEMM gathers (ConvGather) ----
+    // mode 1 (KC): this thread's NI pixel rows, decomposed once per item: image base (pixels), tap-0 source coordinates
+    struct PixRows {
+        int base[NI], ys[NI], xs[NI];
+        __device__ __forceinline__ void setup(const ConvGather& g, int t0, int tmax, int tid) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = min(t0 + kc_row(tid) + 32 * i, tmax - 1);
+                const int img = fd_div(r, g.dHW), rem = r - img * (g.gH * g.gW);
+                const int gy = fd_div(rem, g.dW), gx = rem - gy * g.gW;
+                base[i] = img * (g.sH * g.sW);
+                ys[i] = gy * g.a + g.b;
+                xs[i] = gx * g.a + g.b;
+            }
+        }
+    };
+    __device__ __forceinline__ void load_pixrows(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, const PixRows& pr, int k0,
+                                                 int tid, bool valid) {
+        static_assert(KC || NI == 4, "");
+        const int tap = fd_div(k0, g.dC), c0 = k0 - tap * g.sC;
+        const int ky = fd_div(tap, g.dKW), kx = tap - ky * g.KW;
+        const int ty = ky * g.d, tx = kx * g.d, qm = (1 << g.qs) - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int sy = pr.ys[i] + ty, sx = pr.xs[i] + tx;
+            bool ok = valid && ((sy | sx) & qm) == 0;
+            sy >>= g.qs;
+            sx >>= g.qs;
+            ok = ok && (unsigned)sy < (unsigned)g.sH && (unsigned)sx < (unsigned)g.sW;
+            int off = ((pr.base[i] + sy * g.sW + sx) * g.sC + c0 + (tid & 7) * 4) * 4;
+            off = ok ? off : 0x7ffffff0;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
+    // mode 2 (!KC): this thread's four k rows are pixels (decomposed per tile), the tile's n range lies inside tap (ty, tx)
+    __device__ __forceinline__ void load_pixk(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int t0, int k0, int kmax, int tid,
+                                              bool valid) {
+        const int tap = fd_div(t0, g.dC), c0 = t0 - tap * g.sC;
+        const int ky = fd_div(tap, g.dKW), kx = tap - ky * g.KW;
+        const int ty = ky * g.d + g.b, tx = kx * g.d + g.b, qm = (1 << g.qs) - 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int k = min(k0 + (tid & 7) * 4 + i, kmax - 1);
+            const int img = fd_div(k, g.dHW), rem = k - img * (g.gH * g.gW);
+            const int gy = fd_div(rem, g.dW), gx = rem - gy * g.gW;
+            int sy = gy * g.a + ty, sx = gx * g.a + tx;
+            bool ok = valid && ((sy | sx) & qm) == 0;
+            sy >>= g.qs;
+            sx >>= g.qs;
+            ok = ok && (unsigned)sy < (unsigned)g.sH && (unsigned)sx < (unsigned)g.sW;
+            int off = (((img * g.sH + sy) * g.sW + sx) * g.sC + c0 + (tid >> 3) * 4) * 4;
+            off = ok ? off : 0x7ffffff0;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
+    // mode 3 (!KC): k rows (tap, co) of the data gradient's weight operand, stored [co][tap][c]
+    __device__ __forceinline__ void load_kremap(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, int t0, int k0, int kmax,
+                                                int tid, bool valid) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int k = min(k0 + (tid & 7) * 4 + i, kmax - 1);
+            const int tap = fd_div(k, g.dBmod);
+            int off = ((k - tap * g.bmod) * ld + tap * g.btap + t0 + (tid >> 3) * 4) * 4;
+            off = valid ? off : 0x7ffffff0;
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
@@ -994,22 +1096,32 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 
 // One operand's producer waves (256 threads): flat stream of K tiles over the workgroup's items, as in the 8-wave
 // kernel, for the A operand (IS_B false: BT = 128 rows of M) or the B operand (BT = BN rows of N).
-template <int BN, int BT, bool KC, bool IS_B, bool SWZ>
+template <int BN, int BT, bool KC, bool IS_B, bool SWZ, int G = 0>
 __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int buf_bytes,
                                             int plane_off, int pt) {
     constexpr int BK = X6_BK;
     constexpr int NI_ = SplitLoader<BT, KC, SWZ>::NI;
     static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
+    static_assert(G == 0 || (G == 1 && KC && !IS_B) || ((G == 2 || G == 3) && !KC && IS_B), "gather mode vs operand layout");
     SplitLoader<BT, KC, SWZ> s0, s1, s2;
+    typename SplitLoader<BT, KC, SWZ>::PixRows pr;   // (mode 1 only; dead otherwise)
     const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
     const int ext = (int)((IS_B ? p.extB : p.extA) * 4);
     X6Item itL = x6_item<BN>(p, w), itS = itL;
     int wL = w, tL = 0, wS = w, tS = 0, buf = 0;
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
+    if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);
 #define X6Q_LD(S)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    S.load(rs, ld, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, tmax, itL.kend, pt, moreL);                  \
+    if (G == 1)                                                                                             \
+        S.load_pixrows(rs, p.cg, pr, itL.kbeg + tL * BK, pt, moreL);                                        \
+    else if (G == 2)                                                                                        \
+        S.load_pixk(rs, p.cg, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                             \
+    else if (G == 3)                                                                                        \
+        S.load_kremap(rs, p.cg, ld, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                       \
+    else                                                                                                    \
+        S.load(rs, ld, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, tmax, itL.kend, pt, moreL);              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (++tL >= itL.nk) {                                                                                   \
         tL = 0;                                                                                             \
@@ -1017,6 +1129,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         moreL = wL < last;                                                                                  \
         itL = x6_item<BN>(p, moreL ? wL : last - 1);                                                        \
         rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);          \
+        if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);                                                       \
     }
 #define X6Q_STEP(S)                                                                                         \
     X6Q_WAIT_STAGE(S)                                                                                       \
@@ -1055,7 +1168,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 // sub-tile stall a consumer ~4600 clocks per item (a whole K = 64 item is ~8000 clocks of MFMA).
 // NC = 8 (mode 5, experiment): eight consumer waves of (64 x 32) / (32 x 32) sub-tiles beside the eight producers
 // (four waves per SIMD, 128 registers each): two MFMA-issuing waves per SIMD.
-template <int BN, bool A_KC, bool B_KC, bool DEFER, int NC = 4>
+template <int BN, bool A_KC, bool B_KC, bool DEFER, int NC = 4, int GA = 0, int GB = 0>
 __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
     static_assert(NC == 4 || (NC == 8 && !DEFER && BN >= 64), "consumer wave count");
     constexpr int BM = X6_BT;
@@ -1077,11 +1190,11 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
     const bool staged = p.split_k == 1 && p.c_vec;
 
     if (wave >= NC + 4) {
-        x6q_produce<BN, BN, B_KC, true, DEFER>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - (NC + 4) * 64);
+        x6q_produce<BN, BN, B_KC, true, DEFER, GB>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - (NC + 4) * 64);
         return;
     }
     if (wave >= NC) {
-        x6q_produce<BN, BM, A_KC, false, DEFER>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64);
+        x6q_produce<BN, BM, A_KC, false, DEFER, GA>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64);
         return;
     }
 
@@ -1687,6 +1800,8 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         return IX_OK;
     }
     GemmArgs a;
+    a.cg = ConvGather();
+    a.cg.mode_a = a.cg.mode_b = 0;
     a.A = A; a.B = B; a.C = C; a.bias = bias;
     a.M = M; a.N = N; a.K = K;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -1796,5 +1911,154 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         launch_cfg<64, 64, 64>(a, a_kcontig, b_kcontig, grid, stream);
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_gemm_f32");
+    return IX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution (no patch matrix in HBM): forward, data gradient and weight gradient of a bias-free NHWC
+// convolution with [out][kh][kw][in] weights, as three gather modes of the bf16x6 kernel's producer waves (ConvGather).
+// The three are closed under differentiation (hipops.ConvFwd / ConvBwdData / ConvBwdWeight), so the MAML double
+// backward through the adapted backbone stages runs on them as well.
+//   kind 0  y[g][img][oy][ox][co]  = sum_{ky,kx,c} x[g][img][oy*s-p+ky*d][ox*s-p+kx*d][c] * w[g][co][ky][kx][c]
+//   kind 1  dx[g][img][y][x][c]    = sum_{ky,kx,co} dy[g][img][(y+p-ky*d)/s][(x+p-kx*d)/s][co] * w[g][co][ky][kx][c]
+//   kind 2  dw[g][co][ky][kx][c]   = sum_{img,oy,ox} dy[g][img][oy][ox][co] * x[g][img][oy*s-p+ky*d][ox*s-p+kx*d][c]
+// `groups` = episodes with their own (fast) weights; shared weights: groups = 1 and imgs = all images.
+// ------------------------------------------------------------------------------------------------------------
+static int x6_pick_split(int M, int N, int K, int nbatch) {
+    double best = 1e300;
+    int bs = 1;
+    const int cand[14] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
+    const int64_t tl = (int64_t)ix_div_up(M, 128) * ix_div_up(N, 128) * nbatch;
+    for (int si = 0; si < 14; ++si) {
+        const int sp = cand[si];
+        if (sp > 1 && K < 2 * 32 * sp) break;
+        const int kps = ix_div_up(ix_div_up(K, sp), 32) * 32;
+        const int real = ix_div_up(K, kps), ksteps = kps / 32;
+        const int64_t per_cu = (tl * real + 255) / 256;
+        double cost = (double)per_cu * ksteps * 1900.0 + (double)((per_cu + 1) / 2) * 7000.0;
+        if (real > 1) {
+            const double cbytes = 4.0 * (double)M * (double)N * (double)nbatch;
+            cost += 6000.0 + cbytes / 2048.0 + cbytes * real / 1024.0;
+        }
+        if (cost < best) { best = cost; bs = real; }
+    }
+    return bs;
+}
+
+template <int BN>
+static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    if (kind == 0)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true, false, 4, 1, 0>), grid, dim3(768), 0, stream, a, items);
+    else if (kind == 1)
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, false, false, 4, 1, 3>), grid, dim3(768), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, false, false, false, 4, 0, 2>), grid, dim3(768), 0, stream, a, items);
+}
+
+// 1 if ix_conv_gemm_f32 takes this convolution (else the caller keeps the patch-matrix path: ix_im2col_f32 + ix_gemm_f32)
+extern "C" int ix_conv_gemm_supported(int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                                      int stride, int pad, int dil) {
+    if (g_x6 == 0) return 0;
+    if (groups < 1 || imgs < 1 || (Cin % 64) || (Cout % 64) || (stride != 1 && stride != 2 && stride != 4)) return 0;
+    if (KH < 1 || KW < 1 || pad < 0 || dil < 1) return 0;
+    const int64_t lim = ((int64_t)1 << 31) / 4 - 64;
+    if ((int64_t)imgs * H * W * Cin >= lim || (int64_t)imgs * OH * OW * Cout >= lim || (int64_t)Cout * KH * KW * Cin >= lim) return 0;
+    if ((int64_t)imgs * H * W >= ((int64_t)1 << 30) || (int64_t)groups > 65535) return 0;
+    return 1;
+}
+
+extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W,
+                                int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                hipStream_t stream) {
+    IX_CHECK_ARG(src && other && out, "ix_conv_gemm_f32: null operand");
+    IX_CHECK_ARG(kind >= 0 && kind <= 2, "ix_conv_gemm_f32: kind %d", kind);
+    IX_CHECK_ARG(ix_conv_gemm_supported(groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil),
+                 "ix_conv_gemm_f32: unsupported geometry (Cin %d, Cout %d must be multiples of 64; stride %d in {1, 2, 4}; a group's "
+                 "tensors below 2 GiB) -- use ix_im2col_f32 + ix_gemm_f32",
+                 Cin, Cout, stride);
+    IX_CHECK_ARG(aligned16(src) && aligned16(other) && aligned16(out), "ix_conv_gemm_f32: operands must be 16-byte aligned");
+    const int T = KH * KW;
+    const int qs = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
+    GemmArgs a;
+    a.cg = ConvGather();
+    ConvGather& g = a.cg;
+    g.mode_a = g.mode_b = 0;
+    g.KW = KW;
+    g.dKW = make_fastdiv(KW);
+    g.bmod = 1; g.btap = 0;
+    g.dBmod = make_fastdiv(1);
+    a.bias = nullptr;
+    a.sBias = 0;
+    a.alpha = 1.f;
+    a.batch_inner = 1;
+    a.sAi = a.sBi = a.sCi = 0;
+    a.a_vec = a.b_vec = a.c_vec = 1;
+    const int64_t x_slice = (int64_t)imgs * H * W * Cin, y_slice = (int64_t)imgs * OH * OW * Cout, w_slice = (int64_t)Cout * T * Cin;
+    int a_kc, b_kc;
+    if (kind == 0) {          // y = conv(x, w):  A = x gathered over output pixels, B = w [co][(tap, c)]
+        a.A = src; a.B = other; a.C = out;
+        a.M = imgs * OH * OW; a.N = Cout; a.K = T * Cin;
+        a.lda = Cin; a.ldb = (int64_t)T * Cin; a.ldc = Cout;
+        a.sAo = x_slice; a.sBo = w_slice; a.sCo = y_slice;
+        a.extA = x_slice; a.extB = w_slice;
+        g.mode_a = 1;
+        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        a_kc = 1; b_kc = 1;
+    } else if (kind == 1) {   // dx = conv^T(dy, w):  A = dy gathered over input pixels, B rows (tap, co) remapped into w
+        a.A = src; a.B = other; a.C = out;
+        a.M = imgs * H * W; a.N = Cin; a.K = T * Cout;
+        a.lda = Cout; a.ldb = (int64_t)T * Cin; a.ldc = Cin;
+        a.sAo = y_slice; a.sBo = w_slice; a.sCo = x_slice;
+        a.extA = y_slice; a.extB = w_slice;
+        g.mode_a = 1; g.mode_b = 3;
+        g.gH = H; g.gW = W; g.sH = OH; g.sW = OW; g.sC = Cout; g.a = 1; g.b = pad; g.d = -dil; g.qs = qs;
+        g.bmod = Cout; g.btap = Cin; g.dBmod = make_fastdiv(Cout);
+        a_kc = 1; b_kc = 0;
+    } else {                  // dw = dy^T (x) x:  A = dy^T (co x pixels), B rows = pixels, columns (tap, c) gathered from x
+        a.A = src; a.B = other; a.C = out;
+        a.M = Cout; a.N = T * Cin; a.K = imgs * OH * OW;
+        a.lda = Cout; a.ldb = Cin; a.ldc = (int64_t)T * Cin;
+        a.sAo = y_slice; a.sBo = x_slice; a.sCo = w_slice;
+        a.extA = y_slice; a.extB = x_slice;
+        g.mode_b = 2;
+        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        a_kc = 0; b_kc = 0;
+    }
+    (void)a_kc; (void)b_kc;
+    g.dW = make_fastdiv(g.gW);
+    g.dHW = make_fastdiv(g.gH * g.gW);
+    g.dC = make_fastdiv(g.sC);
+    // N tiles: 128 wide when the tile stays inside one tap (weight gradient: sC % BN == 0), else 64
+    const int bn = (kind == 2 ? (Cin % 128 == 0) : (a.N > 64)) ? 128 : 64;
+    a.tiles_m = ix_div_up(a.M, 128);
+    a.tiles_n = ix_div_up(a.N, bn);
+    int split = x6_pick_split(a.M, a.N, a.K, groups);
+    int kps = ix_div_up(ix_div_up(a.K, split), 32) * 32;
+    split = ix_div_up(a.K, kps);
+    a.split_k = split;
+    a.k_per_split = kps;
+    if (split > 1) {
+        dim3 zg(ix_grid_1d((int64_t)a.M * a.N, 256), groups);
+        hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, a.C, a.M, a.N, a.ldc, a.sCo, (int64_t)0, 1);
+    }
+    const int64_t items64 = (int64_t)a.tiles_m * a.tiles_n * groups * split;
+    IX_CHECK_ARG(items64 < (1 << 30), "ix_conv_gemm_f32: too many tiles");
+    const int items = (int)items64;
+    const double fl = 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)groups;
+    g_flops += fl;
+    g_launches += 1;
+    if (g_prof_on) {
+        ProfRec r = {a.M, a.N, a.K, groups, a_kc, b_kc, 1128, split};
+        r.flops = fl;
+        g_rec.push_back(r);
+    }
+    prof_mark(stream);
+    if (bn == 128) launch_conv_bn<128>(a, kind, items, stream);
+    else launch_conv_bn<64>(a, kind, items, stream);
+    prof_mark(stream);
+    IX_CHECK_LAUNCH("ix_conv_gemm_f32");
     return IX_OK;
 }

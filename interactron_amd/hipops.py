@@ -1155,6 +1155,81 @@ def maxpool_nhwc(x, k, stride, pad):
     return y
 
 
+# ---- implicit-GEMM convolution (csrc/gemm.hip ix_conv_gemm_f32): no patch matrix in HBM ----------------------------------
+ConvGemmGeom = namedtuple("ConvGemmGeom", "E imgs H W Cin OH OW Cout KH KW stride pad dil")
+CONV_IMPL = os.environ.get("IX_CONV", "implicit")   # "im2col": keep every convolution on the patch-matrix path (A/B runs)
+_conv_ok = {}
+
+
+def conv_gemm_supported(cg):
+    ok = _conv_ok.get(cg)
+    if ok is None:
+        ok = _conv_ok[cg] = CONV_IMPL == "implicit" and bool(_L().ix_conv_gemm_supported(
+            cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil))
+    return ok
+
+
+def _conv_gemm(kind, src, other, out_shape, cg):
+    out = torch.empty(out_shape, device=src.device, dtype=torch.float32)
+    _chk(_L().ix_conv_gemm_f32(kind, src.data_ptr(), other.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin,
+                               cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil, _stream()), "ix_conv_gemm_f32")
+    return out
+
+
+class ConvFwd(Function):
+    """y = conv(x, w): x [E*imgs, H, W, Cin], w [(E,) Cout, KH, KW, Cin] -> [E*imgs, OH, OW, Cout].  With ConvBwdData and
+    ConvBwdWeight the three implicit-GEMM kinds are closed under differentiation (each one's backward is the other two)."""
+
+    @staticmethod
+    def forward(ctx, x, w, cg):
+        x, w = _req(x, "conv x"), _req(w, "conv weight")
+        ctx.cg = cg
+        ctx.save_for_backward(x, w)
+        return _conv_gemm(0, x, w, (cg.E * cg.imgs, cg.OH, cg.OW, cg.Cout), cg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ConvBwdData.call(dy, w, ctx.cg) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeight.call(dy, x, ctx.cg, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class ConvBwdData(Function):
+    @staticmethod
+    def forward(ctx, dy, w, cg):
+        dy, w = _req(dy, "conv dy"), _req(w, "conv weight")
+        ctx.cg = cg
+        ctx.save_for_backward(dy, w)
+        return _conv_gemm(1, dy, w, (cg.E * cg.imgs, cg.H, cg.W, cg.Cin), cg)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        g = g.contiguous()
+        ddy = ConvFwd.call(g, w, ctx.cg) if ctx.needs_input_grad[0] else None
+        dw = ConvBwdWeight.call(dy, g, ctx.cg, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        return ddy, dw, None
+
+
+class ConvBwdWeight(Function):
+    @staticmethod
+    def forward(ctx, dy, x, cg, w_shape):
+        dy, x = _req(dy, "conv dy"), _req(x, "conv x")
+        ctx.cg = cg
+        ctx.save_for_backward(dy, x)
+        return _conv_gemm(2, dy, x, w_shape, cg)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, x = ctx.saved_tensors
+        g = g.contiguous()
+        ddy = ConvFwd.call(x, g, ctx.cg) if ctx.needs_input_grad[0] else None
+        dx = ConvBwdData.call(dy, g, ctx.cg) if ctx.needs_input_grad[1] else None
+        return ddy, dx, None, None
+
+
 def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
     """x [n,H,W,Cin] NHWC, weight [Cout,KH,KW,Cin] (nn.Conv2dNHWC's storage layout: the patch-matrix column order
     (kh, kw, cin), so it is the contraction's k-contiguous operand as stored) -> [n,OH,OW,Cout]."""
@@ -1165,6 +1240,9 @@ def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
         if KH == 1 and KW == 1 and stride == 1 and pad == 0:
             return linear(x, weight.reshape(E, Cout, Cin))
         g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
+        cg = ConvGemmGeom(E, n // E, H, W, Cin, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
+        if conv_gemm_supported(cg):
+            return ConvFwd.call(x, weight, cg)
         cols = Im2Col.call(x, g)
         assert g.Kp == KH * KW * Cin, "episode-batched convs need KH*KW*Cin % 4 == 0"
         return linear(cols.reshape(E, -1, g.Kp), weight.reshape(E, Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
@@ -1173,6 +1251,9 @@ def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
         return linear(x, weight.reshape(Cout, Cin))
     g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
+    cg = ConvGemmGeom(1, n, H, W, Cin, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
+    if conv_gemm_supported(cg):
+        return ConvFwd.call(x, weight, cg)
     cols = Im2Col.call(x, g)
     return linear(cols, weight.reshape(Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
 

@@ -211,6 +211,34 @@ def test_conv2d_nhwc(ops, cin, cout, k, stride, pad, dil, hw):
              [rnd(2, hw, hw + 1, cin), rnd(cout, cin, k, k, scale=(cin * k * k) ** -0.5)], name="conv")
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw,n", [(64, 128, 3, 1, 1, 1, 19, 2), (128, 64, 3, 2, 1, 1, 20, 3),
+                                                             (64, 64, 3, 1, 2, 2, 13, 2), (128, 256, 1, 2, 0, 1, 15, 2),
+                                                             (256, 128, 3, 2, 1, 1, 9, 1), (64, 64, 3, 1, 1, 1, 38, 5)])
+def test_implicit_gemm_conv(ops, cin, cout, k, stride, pad, dil, hw, n):
+    """ix_conv_gemm_f32 (the bf16x6 producers gather the taps; no patch matrix): forward, both gradients and the gradients
+    of those (MAML's double backward) against F.conv2d in float64 -- 3x3 stride 1 / 2, the dilated stage, the 1x1 stride-2
+    downsample, image sizes that leave ragged pixel tiles, shared and per-episode weights."""
+    g = ops.conv_geom(n, hw, hw + 1, cin, k, k, stride, pad, dil)
+    cg = ops.ConvGemmGeom(1, n, hw, hw + 1, cin, g.OH, g.OW, cout, k, k, stride, pad, dil)
+    assert ops.conv_gemm_supported(cg), "this geometry must take the implicit-GEMM path"
+
+    def ref(x, w):
+        return F.conv2d(x.permute(0, 3, 1, 2), w, None, stride, pad, dil).permute(0, 2, 3, 1)
+
+    check_op(lambda x, w: ops.conv2d_nhwc(x, w.permute(0, 2, 3, 1).contiguous(), stride, pad, dil), ref,
+             [rnd(n, hw, hw + 1, cin), rnd(cout, cin, k, k, scale=(cin * k * k) ** -0.5)], name="implicit conv")
+    if n % 2 == 0 or n == 3:   # per-episode fast weights: E groups of n / E images
+        E = 2 if n % 2 == 0 else 3
+        w5 = rnd(E, cout, cin, k, k, seed=5, scale=(cin * k * k) ** -0.5)
+
+        def ref5(x, w):
+            per = n // E
+            out = [F.conv2d(x[e * per:(e + 1) * per].permute(0, 3, 1, 2), w[e], None, stride, pad, dil) for e in range(E)]
+            return torch.cat(out).permute(0, 2, 3, 1)
+        check_op(lambda x, w: ops.conv2d_nhwc(x, w.permute(0, 1, 3, 4, 2).contiguous(), stride, pad, dil), ref5,
+                 [rnd(n, hw, hw + 1, cin, seed=6), w5], name="implicit conv, episode-batched")
+
+
 def test_stem_conv_and_maxpool(ops):
     x = rnd(2, 3, 37, 41)
     w = rnd(64, 3, 7, 7, scale=0.1)
