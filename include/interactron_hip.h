@@ -57,6 +57,15 @@ int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kconti
                                 int split_k_hint, size_t* out_host);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls); /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
 
+/* ix_gemm_rowsum_f32: C = alpha A B and, from the same launch, rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  With A
+ * stored m-contiguous (a_kcontig = 0) the bf16x6 kernel's A-producer waves accumulate the sums from the tiles they stream
+ * anyway: the bias gradient colsum(dy) of a Linear rides on its weight-gradient contraction dW = dy^T x (reference:
+ * F.linear under autograd -- models/gpt.py:27-32,79-84, detr_models/transformer.py FFN / projections).  Shapes the bf16x6
+ * kernel does not take fall back to ix_gemm_f32 + ix_colsum_f32 inside the call (A must then be contiguous). */
+int ix_gemm_rowsum_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
+                       int64_t ldb, int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, float alpha,
+                       float* rowsum, int64_t rowsum_stride, ix_stream_t stream);
+
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
  * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */

@@ -79,6 +79,8 @@ struct GemmArgs {
     int a_vec, b_vec, c_vec;
     int tiles_m, tiles_n;
     struct ConvGather cg;   // implicit-GEMM convolution operands (ix_conv_gemm_f32); mode 0 for plain contractions
+    float* rowsum;          // optional side output (bf16x6 kernel, A stored m-contiguous): rowsum[bo][m] = sum_k A(m, k)
+    int64_t sRowsum;
 };
 
 // XCD-aware, bijective remap: consecutive logical tiles land on the same XCD (same L2).
@@ -746,6 +748,7 @@ struct X6Item {
     const float* B;
     float* C;
     const float* bias;
+    float* rowsum;   // non-null for the items of the first tile column when GemmArgs.rowsum is set
     int m0, n0, kbeg, kend, nk, ks;
 };
 
@@ -766,6 +769,7 @@ __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     it.B = p.B + bo * p.sBo + bi * p.sBi;
     it.C = p.C + bo * p.sCo + bi * p.sCi;
     it.bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+    it.rowsum = (p.rowsum && it.n0 == 0) ? p.rowsum + bo * p.sRowsum : nullptr;
     it.ks = ks;
     it.kbeg = ks * p.k_per_split;
     it.kend = min(p.K, it.kbeg + p.k_per_split);
@@ -1112,6 +1116,39 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
     if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);
+    // Row sums of an m-contiguous A operand (the bias gradient riding on the weight-gradient contraction): this thread
+    // holds the same four rows (pt >> 3) * 4 .. + 3 in every K tile, so it keeps four running sums over its k lines; at
+    // the end of an item the eight threads of a row group are combined and one of them adds the result to rowsum[m].
+    constexpr bool RSUM = !KC && !IS_B && G == 0;
+    x6_f32x4 rsum = {0.f, 0.f, 0.f, 0.f};
+#define X6Q_RSUM_ACC(S)                                                                                     \
+    if (RSUM && itS.rowsum) {                                                                               \
+        const int gk = itS.kbeg + tS * BK + (pt & 7) * 4;                                                   \
+        _Pragma("unroll") for (int i = 0; i < NI_; ++i) if (gk + i < itS.kend) rsum += S.v[i];              \
+    }
+#define X6Q_RSUM_FLUSH                                                                                      \
+    if (RSUM && itS.rowsum) {                                                                               \
+        _Pragma("unroll") for (int o = 1; o < 8; o <<= 1) {                                                 \
+            rsum.x += __shfl_xor(rsum.x, o); rsum.y += __shfl_xor(rsum.y, o);                               \
+            rsum.z += __shfl_xor(rsum.z, o); rsum.w += __shfl_xor(rsum.w, o);                               \
+        }                                                                                                   \
+        if ((pt & 7) == 0) {                                                                                \
+            const int m = itS.m0 + (pt >> 3) * 4;                                                           \
+            float* dst = itS.rowsum + m;                                                                    \
+            if (p.split_k > 1) {                                                                            \
+                if (m + 0 < p.M) unsafeAtomicAdd(dst + 0, rsum.x);                                          \
+                if (m + 1 < p.M) unsafeAtomicAdd(dst + 1, rsum.y);                                          \
+                if (m + 2 < p.M) unsafeAtomicAdd(dst + 2, rsum.z);                                          \
+                if (m + 3 < p.M) unsafeAtomicAdd(dst + 3, rsum.w);                                          \
+            } else {                                                                                        \
+                if (m + 0 < p.M) dst[0] = rsum.x;                                                           \
+                if (m + 1 < p.M) dst[1] = rsum.y;                                                           \
+                if (m + 2 < p.M) dst[2] = rsum.z;                                                           \
+                if (m + 3 < p.M) dst[3] = rsum.w;                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+        rsum = x6_f32x4{0.f, 0.f, 0.f, 0.f};                                                                \
+    }
 #define X6Q_LD(S)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (G == 1)                                                                                             \
@@ -1135,9 +1172,11 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     X6Q_WAIT_STAGE(S)                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     S.store(lds0 + buf * buf_bytes + plane_off, pt, itS.kbeg + tS * BK, itS.kend);                          \
+    X6Q_RSUM_ACC(S)                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     buf ^= 1;                                                                                               \
     if (++tS >= itS.nk) {                                                                                   \
+        X6Q_RSUM_FLUSH                                                                                      \
         tS = 0;                                                                                             \
         wS += stride;                                                                                       \
         moreS = wS < last;                                                                                  \
@@ -1158,6 +1197,8 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     }
 #undef X6Q_LD
 #undef X6Q_STEP
+#undef X6Q_RSUM_ACC
+#undef X6Q_RSUM_FLUSH
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
 }
 
@@ -1523,6 +1564,7 @@ static void launch_cfg(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStre
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, false>), grid, dim3(256), 0, stream, a);
 }
 
+extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, hipStream_t stream);
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- launch statistics (bench.py's roofline object) ----------------------------------------------------------
@@ -1745,7 +1787,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
                      int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
                      int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
                      int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream);
+                     void* workspace, size_t workspace_bytes, float* rowsum, int64_t rowsum_stride, hipStream_t stream);
 
 extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
@@ -1753,7 +1795,7 @@ extern "C" int ix_gemm_f32(const float* A, const float* B, float* C, const float
                            int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
                            hipStream_t stream) {
     return gemm_impl(A, B, C, bias, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, batch_inner, sAo, sAi, sBo, sBi,
-                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, nullptr, 0, stream);
+                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, nullptr, 0, nullptr, 0, stream);
 }
 
 extern "C" int ix_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
@@ -1762,14 +1804,27 @@ extern "C" int ix_gemm_f32_ws(const float* A, const float* B, float* C, const fl
                               int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
                               void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return gemm_impl(A, B, C, bias, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, batch_inner, sAo, sAi, sBo, sBi,
-                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, workspace, workspace_bytes, stream);
+                     sCo, sCi, bias_stride_outer, alpha, tile_hint, split_k_hint, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// The contraction plus, in the same launch, the row sums of A:  rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  For A
+// stored m-contiguous (a_kcontig = 0) on the bf16x6 kernel the A-producer waves accumulate them from the operand tiles
+// they stream anyway -- the bias gradient colsum(dy) rides on the weight-gradient contraction dW = dy^T x for free
+// (reference: torch.nn.functional.linear under autograd, every Linear of models/gpt.py and detr_models/transformer.py).
+// Other layouts / kernels: a separate column-sum launch (needs A contiguous: lda = M, sAo = K * M, rowsum_stride = M).
+extern "C" int ix_gemm_rowsum_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig,
+                                  int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo,
+                                  float alpha, float* rowsum, int64_t rowsum_stride, hipStream_t stream) {
+    IX_CHECK_ARG(rowsum != nullptr, "ix_gemm_rowsum_f32: null rowsum");
+    return gemm_impl(A, B, C, nullptr, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, 1, sAo, 0, sBo, 0, sCo, 0, 0, alpha,
+                     0, 0, nullptr, 0, rowsum, rowsum_stride, stream);
 }
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                      int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer,
                      int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo,
                      int64_t sCi, int64_t bias_stride_outer, float alpha, int tile_hint, int split_k_hint,
-                     void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                     void* workspace, size_t workspace_bytes, float* rowsum, int64_t rowsum_stride, hipStream_t stream) {
     IX_CHECK_ARG(A && B && C, "ix_gemm_f32: null operand");
     IX_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch_outer >= 0 && batch_inner >= 1, "ix_gemm_f32: bad dims");
     const int nbatch = batch_outer * batch_inner;
@@ -1802,6 +1857,8 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     GemmArgs a;
     a.cg = ConvGather();
     a.cg.mode_a = a.cg.mode_b = 0;
+    a.rowsum = nullptr;
+    a.sRowsum = 0;
     a.A = A; a.B = B; a.C = C; a.bias = bias;
     a.M = M; a.N = N; a.K = K;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -1879,6 +1936,23 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     if (split > 1) {
         dim3 zg(ix_grid_1d((int64_t)M * N, 256), nbatch);
         hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, C, M, N, ldc, sCo, sCi, batch_inner);
+    }
+    if (rowsum) {
+        if (use_x6 && !a_kcontig && batch_inner == 1 && g_x6 == 3) {
+            a.rowsum = rowsum;
+            a.sRowsum = rowsum_stride;
+            if (split > 1) {   // split-K items add their partial sums
+                if (rowsum_stride == M || batch_outer == 1)
+                    hipMemsetAsync(rowsum, 0, sizeof(float) * ((size_t)(batch_outer - 1) * rowsum_stride + M), stream);
+                else
+                    for (int b = 0; b < batch_outer; ++b) hipMemsetAsync(rowsum + b * rowsum_stride, 0, sizeof(float) * M, stream);
+            }
+        } else {
+            IX_CHECK_ARG(!a_kcontig && lda == M && batch_inner == 1 && (batch_outer == 1 || (sAo == (int64_t)K * M && rowsum_stride == M)),
+                         "ix_gemm_rowsum_f32: the separate column-sum path needs a contiguous m-fastest A");
+            const int rc = ix_colsum_f32(A, rowsum, K, M, batch_outer, stream);
+            if (rc != IX_OK) return rc;
+        }
     }
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
@@ -1986,6 +2060,8 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     a.cg = ConvGather();
     ConvGather& g = a.cg;
     g.mode_a = g.mode_b = 0;
+    a.rowsum = nullptr;
+    a.sRowsum = 0;
     g.KW = KW;
     g.dKW = make_fastdiv(KW);
     g.bmod = 1; g.btap = 0;

@@ -186,28 +186,83 @@ class Gemm(Function):
         a, b = ctx.saved_tensors
         sp = ctx.sp
         dc = dc.contiguous()
-        da = db = dbias = None
-        if ctx.needs_input_grad[0]:
-            if not sp.A.trans:   # dA (MxK) = alpha * dC (MxN) * B^T (NxK)
-                s = GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B),
-                             View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), ctx.a_shape, sp.alpha)
-                da = Gemm.call(dc, b, None, s)
-            else:                # storage holds A^T (KxM): dA^T = alpha * B (KxN) * dC^T (NxM)
-                s = GemmSpec(sp.K, sp.M, sp.N, sp.bo, sp.bi, sp.B, _flip(sp.C),
-                             View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), ctx.a_shape, sp.alpha)
-                da = Gemm.call(b, dc, None, s)
-        if ctx.needs_input_grad[1]:
-            if not sp.B.trans:   # dB (KxN) = alpha * A^T (KxM) * dC (MxN)
-                s = GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C,
-                             View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
-                db = Gemm.call(a, dc, None, s)
-            else:                # storage holds B^T (NxK): dB^T = alpha * dC^T (NxM) * A (MxK)
-                s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
-                             View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
-                db = Gemm.call(dc, a, None, s)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        need_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
+        # A-producer waves of that launch sum the dC tiles they stream anyway) whenever dC is its plain m-contiguous A operand
+        fuse = (GEMM_ROWSUM and need_bias and ctx.needs_input_grad[1] and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
+                and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
+                and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
+        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, ctx.needs_input_grad[0],
+                                ctx.needs_input_grad[1] and not fuse)
+        dbias = None
+        if fuse:
+            s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
+                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
+            db, dbias = GemmRowsum.call(dc, a, s, ctx.bias_groups)
+        elif need_bias:
             dbias = ColSum.call(dc.reshape(ctx.bias_groups, -1, sp.N) if ctx.bias_groups else dc.reshape(-1, sp.N))
         return da, db, dbias, None
+
+
+def _gemm_backward(sp, a, b, a_shape, b_shape, dc, need_a, need_b):
+    """Gradients of C = alpha A B w.r.t. the storage of A and of B (each again one strided contraction)."""
+    da = db = None
+    if need_a:
+        if not sp.A.trans:   # dA (MxK) = alpha * dC (MxN) * B^T (NxK)
+            s = GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B),
+                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
+            da = Gemm.call(dc, b, None, s)
+        else:                # storage holds A^T (KxM): dA^T = alpha * B (KxN) * dC^T (NxM)
+            s = GemmSpec(sp.K, sp.M, sp.N, sp.bo, sp.bi, sp.B, _flip(sp.C),
+                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
+            da = Gemm.call(b, dc, None, s)
+    if need_b:
+        if not sp.B.trans:   # dB (KxN) = alpha * A^T (KxM) * dC (MxN)
+            s = GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C,
+                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha)
+            db = Gemm.call(a, dc, None, s)
+        else:                # storage holds B^T (NxK): dB^T = alpha * dC^T (NxM) * A (MxK)
+            s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
+                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha)
+            db = Gemm.call(dc, a, None, s)
+    return da, db
+
+
+GEMM_ROWSUM = os.environ.get("IX_GEMM_ROWSUM", "1") == "1"   # "0": bias gradients by a separate ix_colsum_f32 launch (A/B runs)
+
+
+class GemmRowsum(Function):
+    """(alpha A B, rowsum(A)) for a contiguous m-fastest A view of `a` (spec A.trans, offset 0): one launch of
+    ix_gemm_rowsum_f32.  rowsum: [M], or [groups, M] for per-episode operands."""
+
+    @staticmethod
+    def forward(ctx, a, b, sp, groups):
+        a, b = _req(a, "gemm A"), _req(b, "gemm B")
+        assert sp.A.trans and sp.A.offset == 0 and sp.A.ld == sp.M and sp.bi == 1 and not sp.C.trans
+        ctx.sp, ctx.groups = sp, groups
+        ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
+        ctx.save_for_backward(a, b)
+        covered = sp.bo * sp.M * sp.N == _numel(sp.out_shape)
+        out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
+        rs = torch.empty((groups, sp.M) if groups else (sp.M,), device=a.device, dtype=torch.float32)
+        _chk(_L().ix_gemm_rowsum_f32(a.data_ptr(), b.data_ptr() + sp.B.offset * 4, out.data_ptr() + sp.C.offset * 4,
+                                     sp.M, sp.N, sp.K, 0, 1 if sp.B.trans else 0, sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.A.so,
+                                     sp.B.so, sp.C.so, sp.alpha, rs.data_ptr(), sp.M, _stream()), "ix_gemm_rowsum_f32")
+        return out, rs
+
+    @staticmethod
+    def backward(ctx, gc, gr):
+        a, b = ctx.saved_tensors
+        sp = ctx.sp
+        da = db = None
+        if gc is not None:
+            da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, gc.contiguous(), ctx.needs_input_grad[0],
+                                    ctx.needs_input_grad[1])
+        if gr is not None and ctx.needs_input_grad[0]:   # rowsum[m] = sum_k A(m, k): every k line of A's storage gets gr
+            if da is None:
+                da = torch.zeros(ctx.a_shape, device=a.device, dtype=torch.float32)
+            da = AddRowVec.call(da, gr.contiguous(), max(ctx.groups, 1))
+        return da, db, None, None
 
 
 def linear(x, weight, bias=None):

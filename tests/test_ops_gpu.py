@@ -541,6 +541,34 @@ def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     assert rc != 0
 
 
+@pytest.mark.parametrize("bkc", [0, 1])
+def test_gemm_with_fused_rowsum(ops, bkc):
+    """ix_gemm_rowsum_f32: the weight-gradient contraction dW = dy^T x with the bias gradient colsum(dy) produced by the
+    same launch (A-producer waves of the bf16x6 kernel), against float64 -- one split-K launch (atomic partial sums), a
+    per-episode batch, a ragged M (last row tile partly outside), and a small shape that falls back to the separate
+    column-sum kernel."""
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, b) in [(512, 512, 32960, 1), (2048, 256, 1805, 16), (1236, 256, 1250, 2), (24, 40, 37, 3)]:
+        dy = (rnd(b, K, M, seed=1) + 0.25).cuda()                 # A(m, k) = dy[k, m]: m-contiguous
+        x = rnd(b, K, N, seed=2).cuda()
+        B = x.transpose(1, 2).contiguous() if bkc else x
+        C, C0 = torch.empty(b, M, N, device="cuda"), torch.empty(b, M, N, device="cuda")
+        rs = torch.full((b, M), float("nan"), device="cuda")
+        rc = lib.ix_gemm_rowsum_f32(dy.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, 0, bkc, M, K if bkc else N, N, b,
+                                    K * M, K * N, M * N, 1.0, rs.data_ptr(), M, stream)
+        assert rc == 0, lib.ix_last_error()
+        rc = lib.ix_gemm_f32(dy.data_ptr(), B.data_ptr(), C0.data_ptr(), None, M, N, K, 0, bkc, M, K if bkc else N, N, b, 1,
+                             K * M, 0, K * N, 0, M * N, 0, 0, 1.0, 0, 0, stream)
+        assert rc == 0, lib.ix_last_error()
+        ref = dy.double().sum(1)
+        scale = dy.double().abs().sum(1)
+        assert float(((rs.double() - ref).abs() / scale).max()) < 2e-6, (M, N, K, b)
+        close(C, dy.double().transpose(1, 2) @ x.double(), 2e-5, "rowsum gemm product")
+        close(C, C0, 1e-6, "rowsum gemm product vs ix_gemm_f32")   # (same kernel; split-K partial sums arrive in any order)
+
+
 def test_episode_batched_linear_layernorm_rowvec(ops):
     """Grouped forms used by the episode-batched fast weights: weight [E,N,K] + bias [E,N], LayerNorm affine [E,D],
     per-episode row vector -- forward, first and second order against per-episode float64 references."""
