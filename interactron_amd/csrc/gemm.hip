@@ -494,11 +494,13 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                 e2 = i == 0 ? v[2].x : i == 1 ? v[2].y : i == 2 ? v[2].z : v[2].w;
                 e3 = i == 0 ? v[3].x : i == 1 ? v[3].y : i == 2 ? v[3].z : v[3].w;
             }
-            const int gk = k0 + (tid & 7) * 4;
-            e0 = gk + 0 < kmax ? e0 : 0.f;
-            e1 = gk + 1 < kmax ? e1 : 0.f;
-            e2 = gk + 2 < kmax ? e2 : 0.f;
-            e3 = gk + 3 < kmax ? e3 : 0.f;
+            if (k0 + X6_BK > kmax) {   // (wave-uniform) only the last K tile of an item can reach past the K range
+                const int gk = k0 + (tid & 7) * 4;
+                e0 = gk + 0 < kmax ? e0 : 0.f;
+                e1 = gk + 1 < kmax ? e1 : 0.f;
+                e2 = gk + 2 < kmax ? e2 : 0.f;
+                e3 = gk + 3 < kmax ? e3 : 0.f;
+            }
             unsigned h0, m0, l0, h1, m1, l1;
             split3(e0, e1, h0, m0, l0);
             split3(e2, e3, h1, m1, l1);
@@ -1281,6 +1283,16 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
     }
 #define X6Q_HOOK3 if (TN == 2) X6Q_HOOK
 #define X6Q_NOHOOK
+#ifdef X6_DIAG_HALFMMA   // diagnostic build (wrong numbers): three of the six products, everything else unchanged
+#define X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, H3, H1)                                                              \
+    X6Q_LDA(A0N, 0, NBASE, NS) X6Q_LDB(B0N, 0, NBASE, NS) X6Q_SB                                                      \
+    X6Q_MM(a2, B0C) X6Q_SB X6Q_LDA(a2, 2, NBASE, NS) X6Q_SB                                                           \
+    X6Q_LDB(b2, 2, NBASE, NS) X6Q_SB H3                                                                               \
+    X6Q_MM(a1, b1) X6Q_SB                                                                                             \
+    X6Q_LDA(a1, 1, NBASE, NS) X6Q_SB H3                                                                               \
+    X6Q_LDB(b1, 1, NBASE, NS) X6Q_SB                                                                                  \
+    X6Q_MM(A0C, B0C) X6Q_SB H1
+#else
 #define X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, H3, H1)                                                              \
     X6Q_LDA(A0N, 0, NBASE, NS) X6Q_LDB(B0N, 0, NBASE, NS) X6Q_SB                                                      \
     X6Q_MM(a2, B0C) X6Q_SB X6Q_LDA(a2, 2, NBASE, NS) X6Q_SB                                                           \
@@ -1289,6 +1301,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
     X6Q_MM(a1, B0C) X6Q_SB X6Q_LDA(a1, 1, NBASE, NS) X6Q_SB H3                                                        \
     X6Q_MM(A0C, b1) X6Q_SB X6Q_LDB(b1, 1, NBASE, NS) X6Q_SB                                                           \
     X6Q_MM(A0C, B0C) X6Q_SB H1
+#endif
 #define X6Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS) X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, X6Q_NOHOOK, X6Q_NOHOOK)
 #define X6Q_SLICE_H(A0C, B0C, A0N, B0N, NBASE, NS) X6Q_SLICE_(A0C, B0C, A0N, B0N, NBASE, NS, X6Q_HOOK3, X6Q_HOOK)
     // one K step = two k-slices around the flat-tile barrier

@@ -818,6 +818,27 @@ class AddRowVec(Function):
         return g, gv, None
 
 
+class SplitRows(Function):
+    """Row blocks (views, no copies) of a packed parameter -- nn.MultiheadAttention's in_proj_weight / in_proj_bias -- whose
+    gradient comes back as ONE concatenation instead of a zero-fill + slice copy per block + an accumulation of the
+    full-size pieces (five small launches per block pair in autograd's slice backward)."""
+
+    @staticmethod
+    def forward(ctx, w, *sizes):
+        ctx.sizes, ctx.tail = sizes, tuple(w.shape[1:])
+        return tuple(w.split(list(sizes), 0))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        parts = [g if g is not None else gs_zero(ctx, n, gs) for g, n in zip(gs, ctx.sizes)]
+        return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
+
+
+def gs_zero(ctx, n, gs):
+    ref = next(g for g in gs if g is not None)
+    return torch.zeros((n,) + ctx.tail, device=ref.device, dtype=ref.dtype)
+
+
 class Dot(Function):
     """sum(a*b) -> 0-d tensor."""
 

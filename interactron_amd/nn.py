@@ -92,13 +92,15 @@ class MultiheadAttention(nn.Module):
         H, hd = self.num_heads, self.head_dim
         W, B = self.in_proj_weight, self.in_proj_bias
         if qk_same:   # self-attention with q = k input: one GEMM for both projections
-            qk = ops.linear(query, W[:2 * E], B[:2 * E])
+            (Wqk, Wv), (Bqk, Bv) = ops.SplitRows.apply(W, 2 * E, E), ops.SplitRows.apply(B, 2 * E, E)
+            qk = ops.linear(query, Wqk, Bqk)
             q, k, q_ld, k_ld, q_off, k_off = qk, qk, 2 * E, 2 * E, 0, E
         else:
-            q = ops.linear(query, W[:E], B[:E])
-            k = ops.linear(key, W[E:2 * E], B[E:2 * E])
+            (Wq, Wk, Wv), (Bq, Bk, Bv) = ops.SplitRows.apply(W, E, E, E), ops.SplitRows.apply(B, E, E, E)
+            q = ops.linear(query, Wq, Bq)
+            k = ops.linear(key, Wk, Bk)
             q_ld, k_ld, q_off, k_off = E, E, 0, 0
-        v = ops.linear(value, W[2 * E:], B[2 * E:])
+        v = ops.linear(value, Wv, Bv)
         mask = None
         if key_padding_mask is not None:
             mask = key_padding_mask.to(torch.uint8).contiguous()

@@ -17,7 +17,8 @@ def t(M, N, K, b, akc, bkc, th, sh=0, reps=20):
     for _ in range(reps): run()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
-for (M, N, K, b, akc, bkc) in [(50, 32, 361, 640, 1, 0), (256, 256, 4000, 1, 0, 0), (256, 256, 250, 16, 0, 0), (250, 256, 256, 16, 1, 0),
-                               (50, 32, 50, 640, 0, 0), (4000, 256, 256, 1, 1, 0), (256, 256, 5776, 1, 0, 0), (50, 256, 256, 16, 1, 0)]:
+for (M, N, K, b, akc, bkc) in [(256, 256, 4000, 1, 0, 0), (256, 256, 250, 16, 0, 0), (250, 256, 256, 16, 1, 0), (250, 256, 256, 16, 1, 1),
+                               (4000, 256, 256, 1, 1, 0), (4000, 256, 256, 1, 1, 1), (256, 256, 5776, 1, 0, 0), (4000, 256, 512, 1, 1, 0),
+                               (50, 256, 256, 16, 1, 0), (800, 256, 256, 1, 1, 0), (256, 256, 361, 16, 0, 0)]:
     print("M%d N%d K%d b%d kc%d%d: auto %6.1f us   fp32 tile64 %6.1f   fp32 tile128 %6.1f   bf16x6 %6.1f us"
           % (M, N, K, b, akc, bkc, t(M, N, K, b, akc, bkc, 0), t(M, N, K, b, akc, bkc, 64), t(M, N, K, b, akc, bkc, 128), t(M, N, K, b, akc, bkc, 1128)), flush=True)
