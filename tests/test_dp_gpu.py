@@ -100,6 +100,7 @@ def test_two_ranks_equal_one_process():
     assert abs(t0 - t1) <= 1e-6 * t0 and abs(d0 - d1) <= 1e-6 * max(d0, 1e-12)   # replicas stay identical
     assert abs(t0 - ref_total) <= 3e-2 * ref_total, (t0, ref_total)
     assert abs(d0 - ref_delta) <= 5e-2 * ref_delta, (d0, ref_delta)
+    rel, num, den = {}, 0.0, 0.0
     for k, r in ref.items():
         a, b = g0[k], g1[k]
         assert (a is None) == (r is None), k
@@ -107,9 +108,19 @@ def test_two_ranks_equal_one_process():
             continue
         assert torch.equal(a, b), k                    # SUM all-reduce: bit-identical on both ranks
         n0, n1 = float(r.double().norm()), float(a.double().norm())
+        d = float((a - r).double().norm())
+        num, den = num + d * d, den + n0 * n0
         if max(n0, n1) < 1e-6:
             continue
-        # float32 summation-order noise between the episode-batched pass and two single-episode passes (see
-        # test_episode_batched_equals_sequential_schedule): a missing or doubled episode would be off by ~50 %
-        assert abs(n0 - n1) <= 5e-2 * n0 + 1e-7, (k, n0, n1)
-        assert float((a - r).double().norm()) <= 1.5e-1 * n0 + 1e-7, (k, n0, n1)
+        rel[k] = d / n0
+    # float32 summation-order noise between the episode-batched pass and two single-episode passes (see
+    # test_episode_batched_equals_sequential_schedule; split-K and row-sum atomics make it vary run to run, and single
+    # small second-order tensors move by tens of per cent when one clipped element or ReLU kink flips): a missing or
+    # doubled episode would put EVERY tensor off by ~50 % / 100 %.  So: the whole gradient within 3 %, the median tensor
+    # within 2 %, at most 2 % of the tensors beyond 15 %, none beyond 60 %.
+    vals = sorted(rel.values())
+    assert (num / den) ** 0.5 <= 3e-2, (num, den)
+    assert vals[len(vals) // 2] <= 2e-2, vals[len(vals) // 2]
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
+    assert sum(v > 1.5e-1 for v in vals) <= max(1, len(vals) // 50), worst
+    assert vals[-1] <= 6e-1, worst
