@@ -169,7 +169,11 @@ def launch_ranks(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():   # exactly the JSON line (libraries print to stdout too: "[Gloo] Rank 0 is connected ...")
+        if ln.startswith('{"metric"'):
+            sys.stdout.write(ln + "\n")
+        else:
+            sys.stderr.write(ln + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -372,6 +376,9 @@ def build_roofline(kms, kfl, kn, fms, ffl, fmf, fn):
                                  "gflop_per_step": total_fl / 1e9, "kernel_ms_per_step": total_ms}}
 
 
+JSON_FD = 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,6 +405,13 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:   # plain `python bench.py --gpus N`: become the launcher (no GPU call yet)
         return launch_ranks(args)
+
+    # stdout carries exactly ONE line, the JSON: everything libraries write to file descriptor 1 from here on (gloo prints
+    # "[Gloo] Rank 0 is connected ..." there) goes to stderr, and the line is written to the saved descriptor at the end
+    global JSON_FD
+    sys.stdout.flush()
+    JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -459,7 +473,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and args.size <= 800 and args.attention_dtype == "fp32":
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(JSON_FD, (json.dumps(line) + "\n").encode())   # the one line on the real stdout
     if world > 1:
         dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
