@@ -130,14 +130,30 @@ class _Adaptive(_EpisodeModel):
         det = [p for p in self.detector.parameters() if p.requires_grad and id(p) not in theta_ids]
         return [p for p in self.fusion.parameters() if p.requires_grad] + det
 
+    def _real_parameters(self):
+        """get_parameters(detector) at the start of an episode pass, while every module still holds its own nn.Parameters
+        (set_parameters swaps the adapted ones for plain tensors afterwards); also records the identity of ALL of the
+        model's Parameters for _inner_grad."""
+        self.__dict__["_param_ids"] = frozenset(id(p) for p in self.parameters())
+        return get_parameters(self.detector)
+
+    def _inner_grad(self, learned, dtheta, create_graph):
+        """d learned / d dtheta -- the MAML inner gradient.  Only the per-episode copies `dtheta` are asked for; the
+        weight-gradient contractions of every nn.Parameter on the way (fusion Linears, in_proj blocks) are skipped
+        (hipops.skip_param_grads; their first-order gradients come from the supervisor / detector backward passes)."""
+        ids = self.__dict__["_param_ids"]
+        assert not any(id(t) in ids for t in dtheta)
+        with ops.skip_param_grads(ids):
+            return torch.autograd.grad(learned, dtheta, create_graph=create_graph, retain_graph=create_graph,
+                                       allow_unused=True)
+
     def _adapt(self, img, mask, create_graph):
         dtheta = [p.detach().requires_grad_(True) for p in self._theta]
         set_parameters(self.detector, dtheta)
         pre = _lift(self.detector(NestedTensor(img, mask)))
         fusion_out = self.fusion(pre)
         learned_loss = ops.l2_norm(fusion_out["loss"])
-        grads = torch.autograd.grad(learned_loss, dtheta, create_graph=create_graph, retain_graph=create_graph,
-                                    allow_unused=True)
+        grads = self._inner_grad(learned_loss, dtheta, create_graph)
         return dtheta, grads, fusion_out
 
     def predict(self, data):
@@ -145,7 +161,7 @@ class _Adaptive(_EpisodeModel):
         if b > 1:
             return self._predict_batched(data)
         img, mask = data["frames"].view(s, c, w, h), data["masks"].view(s, w, h)
-        self._theta = get_parameters(self.detector)
+        self._theta = self._real_parameters()
         try:
             with torch.enable_grad():
                 dtheta, grads, _ = self._adapt(img, mask, create_graph=False)
@@ -163,7 +179,7 @@ class _Adaptive(_EpisodeModel):
         ``forward``; returns the same keys with shape [b, 1, ...]."""
         b, s, c, w, h = data["frames"].shape
         chunk = max(1, int(getattr(self.config, "EPISODE_CHUNK", 16)))
-        self._theta = theta = get_parameters(self.detector)
+        self._theta = theta = self._real_parameters()
         outs = []
         try:
             for e0 in range(0, b, chunk):
@@ -180,7 +196,7 @@ class _Adaptive(_EpisodeModel):
                     pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
                     loss_map = self.fusion(pre)["loss"].reshape(E, -1)
                     learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
-                    grads = torch.autograd.grad(learned, dtheta, allow_unused=True)
+                    grads = self._inner_grad(learned, dtheta, False)
                     set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
                 with torch.no_grad():
                     first = NestedTensor(frames[0::s], masks[0::s])
@@ -204,7 +220,7 @@ class _Adaptive(_EpisodeModel):
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
-        self._theta = theta = get_parameters(self.detector)
+        self._theta = theta = self._real_parameters()
         targets2 = self._second_order_targets()
         lr = self.config.ADAPTIVE_LR
         actions_host = data["actions"].tolist() if self.use_policy else None   # one D2H up front
@@ -233,7 +249,7 @@ class _Adaptive(_EpisodeModel):
                 pt.mark("2 fusion fwd")
                 loss_map = fusion_out["loss"].reshape(E, -1)
                 learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
-                grads = torch.autograd.grad(learned, dtheta, create_graph=True, retain_graph=True, allow_unused=True)
+                grads = self._inner_grad(learned, dtheta, True)
                 pt.mark("3 learned-loss grad (create_graph)")
                 set_parameters(self.detector, sgd_step(dtheta, grads, lr))
                 post = self.detector(nt)
@@ -346,7 +362,7 @@ class _Adaptive(_EpisodeModel):
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
-        self._theta = theta = get_parameters(self.detector)
+        self._theta = theta = self._real_parameters()
         targets2 = self._second_order_targets()
         try:
             for task in range(b):

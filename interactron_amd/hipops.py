@@ -165,11 +165,45 @@ def _run_gemm(a, b, bias, sp, fill=True):
     return out
 
 
+# ---- gradients nobody asked for -------------------------------------------------------------------------------------
+# torch.autograd.grad(loss, inputs) prunes NODES that do not lead to `inputs`, but a custom Function's backward is a black
+# box to the engine: it computes every input gradient and the engine drops the unused ones.  The MAML inner step asks for
+# the gradient w.r.t. the per-episode copies of the detector's fast parameters only, yet every Linear of the fusion
+# transformer (and the detector's in_proj blocks) would still run its weight-gradient contraction -- a third of all those
+# contractions in a training step.  `skip_param_grads(params)` names the nn.Parameters whose gradient the running backward
+# does not need; Gemm.backward consults it for its weight / bias operand (by object identity: the fast weights are other
+# tensor objects, even where they share storage with a Parameter).
+_unwanted = None
+
+
+class skip_param_grads:
+    def __init__(self, ids):
+        self.ids = ids
+
+    def __enter__(self):
+        global _unwanted
+        self.prev, _unwanted = _unwanted, self.ids
+        return self
+
+    def __exit__(self, *exc):
+        global _unwanted
+        _unwanted = self.prev
+        return False
+
+
+def _param_key(t):
+    """identity under which skip_param_grads knows a weight operand: the Parameter itself, or the Parameter a SplitRows view
+    was cut from"""
+    return getattr(t, "_ix_of_param", id(t))
+
+
 class Gemm(Function):
     """out = alpha * A B (+ bias) for strided views A of `a` and B of `b`; see GemmSpec."""
 
     @staticmethod
     def forward(ctx, a, b, bias, sp):
+        ctx.b_key = _param_key(b)
+        ctx.bias_key = _param_key(bias) if bias is not None else None
         a, b = _req(a, "gemm A"), _req(b, "gemm B")
         ctx.sp = sp
         ctx.has_bias = bias is not None
@@ -186,14 +220,15 @@ class Gemm(Function):
         a, b = ctx.saved_tensors
         sp = ctx.sp
         dc = dc.contiguous()
-        need_bias = ctx.has_bias and ctx.needs_input_grad[2]
+        skip = _unwanted
+        need_b = ctx.needs_input_grad[1] and not (skip is not None and ctx.b_key in skip)
+        need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not (skip is not None and ctx.bias_key in skip)
         # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
         # A-producer waves of that launch sum the dC tiles they stream anyway) whenever dC is its plain m-contiguous A operand
-        fuse = (GEMM_ROWSUM and need_bias and ctx.needs_input_grad[1] and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
+        fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
                 and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
                 and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
-        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, ctx.needs_input_grad[0],
-                                ctx.needs_input_grad[1] and not fuse)
+        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, ctx.needs_input_grad[0], need_b and not fuse)
         dbias = None
         if fuse:
             s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
@@ -826,7 +861,10 @@ class SplitRows(Function):
     @staticmethod
     def forward(ctx, w, *sizes):
         ctx.sizes, ctx.tail = sizes, tuple(w.shape[1:])
-        return tuple(w.split(list(sizes), 0))
+        parts = tuple(w.split(list(sizes), 0))
+        for t in parts:
+            t._ix_of_param = id(w)   # (skip_param_grads: the blocks stand for the Parameter they were cut from)
+        return parts
 
     @staticmethod
     def backward(ctx, *gs):
