@@ -302,7 +302,10 @@ class _Adaptive(_EpisodeModel):
                     tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
                     total = tl if total is None else total + tl
                 pt.mark("6 criterion + matcher + path storage")
-                torch.autograd.backward(total, inputs=targets2)
+                # (the supervisor backward ends in the fusion parameters and the in_proj blocks; nothing keeps a gradient of
+                #  the per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
+                with ops.skip_param_grads(frozenset(id(t) for t in dtheta)):
+                    torch.autograd.backward(total, inputs=targets2)
                 del grads, dtheta, fusion_out, pre, post, post_lb, sups, gts, sup, total, tl, loss_map, learned, actions_out
 
                 # criterion of the first-order branch: host work that overlaps the second-order backward on the GPU
@@ -386,7 +389,8 @@ class _Adaptive(_EpisodeModel):
                     sup["policy_reward"] = gt
                 sup_losses.append({k: v.detach() for k, v in sup.items()})
                 total = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
-                torch.autograd.backward(total, inputs=targets2)
+                with ops.skip_param_grads(frozenset(id(t) for t in dtheta)):   # (see the batched schedule)
+                    torch.autograd.backward(total, inputs=targets2)
 
                 # first-order detector update through the adapted weights (reference interactron.py:126-134)
                 fast1 = sgd_step(theta, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)

@@ -191,6 +191,14 @@ class skip_param_grads:
         return False
 
 
+def weight_view(w, *shape):
+    """w.reshape(shape) that keeps standing for `w` in skip_param_grads (a view is a new tensor object)"""
+    v = w.reshape(*shape)
+    if v is not w:
+        v._ix_of_param = _param_key(w)
+    return v
+
+
 def _param_key(t):
     """identity under which skip_param_grads knows a weight operand: the Parameter itself, or the Parameter a SplitRows view
     was cut from"""
@@ -202,7 +210,7 @@ class Gemm(Function):
 
     @staticmethod
     def forward(ctx, a, b, bias, sp):
-        ctx.b_key = _param_key(b)
+        ctx.a_key, ctx.b_key = _param_key(a), _param_key(b)
         ctx.bias_key = _param_key(bias) if bias is not None else None
         a, b = _req(a, "gemm A"), _req(b, "gemm B")
         ctx.sp = sp
@@ -221,6 +229,7 @@ class Gemm(Function):
         sp = ctx.sp
         dc = dc.contiguous()
         skip = _unwanted
+        need_a = ctx.needs_input_grad[0] and not (skip is not None and ctx.a_key in skip)
         need_b = ctx.needs_input_grad[1] and not (skip is not None and ctx.b_key in skip)
         need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not (skip is not None and ctx.bias_key in skip)
         # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
@@ -228,7 +237,7 @@ class Gemm(Function):
         fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
                 and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
                 and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
-        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, ctx.needs_input_grad[0], need_b and not fuse)
+        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, need_a, need_b and not fuse)
         dbias = None
         if fuse:
             s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
@@ -1296,6 +1305,7 @@ class ConvFwd(Function):
 
     @staticmethod
     def forward(ctx, x, w, cg):
+        ctx.w_key = _param_key(w)
         x, w = _req(x, "conv x"), _req(w, "conv weight")
         ctx.cg = cg
         ctx.save_for_backward(x, w)
@@ -1305,14 +1315,16 @@ class ConvFwd(Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
+        need_w = ctx.needs_input_grad[1] and not (_unwanted is not None and ctx.w_key in _unwanted)
         dx = ConvBwdData.call(dy, w, ctx.cg) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeight.call(dy, x, ctx.cg, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        dw = ConvBwdWeight.call(dy, x, ctx.cg, tuple(w.shape)) if need_w else None
         return dx, dw, None
 
 
 class ConvBwdData(Function):
     @staticmethod
     def forward(ctx, dy, w, cg):
+        ctx.w_key = _param_key(w)
         dy, w = _req(dy, "conv dy"), _req(w, "conv weight")
         ctx.cg = cg
         ctx.save_for_backward(dy, w)
@@ -1322,8 +1334,9 @@ class ConvBwdData(Function):
     def backward(ctx, g):
         dy, w = ctx.saved_tensors
         g = g.contiguous()
+        need_w = ctx.needs_input_grad[1] and not (_unwanted is not None and ctx.w_key in _unwanted)
         ddy = ConvFwd.call(g, w, ctx.cg) if ctx.needs_input_grad[0] else None
-        dw = ConvBwdWeight.call(dy, g, ctx.cg, tuple(w.shape)) if ctx.needs_input_grad[1] else None
+        dw = ConvBwdWeight.call(dy, g, ctx.cg, tuple(w.shape)) if need_w else None
         return ddy, dw, None
 
 
@@ -1352,24 +1365,24 @@ def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
         E, Cout, KH, KW, Cin = weight.shape
         assert Cin == C and n % E == 0
         if KH == 1 and KW == 1 and stride == 1 and pad == 0:
-            return linear(x, weight.reshape(E, Cout, Cin))
+            return linear(x, weight_view(weight, E, Cout, Cin))
         g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
         cg = ConvGemmGeom(E, n // E, H, W, Cin, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
         if conv_gemm_supported(cg):
             return ConvFwd.call(x, weight, cg)
         cols = Im2Col.call(x, g)
         assert g.Kp == KH * KW * Cin, "episode-batched convs need KH*KW*Cin % 4 == 0"
-        return linear(cols.reshape(E, -1, g.Kp), weight.reshape(E, Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
+        return linear(cols.reshape(E, -1, g.Kp), weight_view(weight, E, Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
     Cout, KH, KW, Cin = weight.shape
     assert Cin == C
     if KH == 1 and KW == 1 and stride == 1 and pad == 0:
-        return linear(x, weight.reshape(Cout, Cin))
+        return linear(x, weight_view(weight, Cout, Cin))
     g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
     cg = ConvGemmGeom(1, n, H, W, Cin, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
     if conv_gemm_supported(cg):
         return ConvFwd.call(x, weight, cg)
     cols = Im2Col.call(x, g)
-    return linear(cols, weight.reshape(Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
+    return linear(cols, weight_view(weight, Cout, KH * KW * Cin)).reshape(n, g.OH, g.OW, Cout)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -66,7 +66,7 @@ class PointwiseConv2d(nn.Module):
 
     def forward(self, x):
         w = self.weight   # [out, in, 1, 1], or [E, out, in, 1, 1] for episode-batched fast weights
-        return ops.linear(x, w.reshape(w.shape[:-2]), self.bias)
+        return ops.linear(x, ops.weight_view(w, w.shape[:-2]), self.bias)
 
 
 class MultiheadAttention(nn.Module):
