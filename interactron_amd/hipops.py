@@ -174,11 +174,12 @@ def _run_gemm(a, b, bias, sp, fill=True):
 # does not need; Gemm.backward consults it for its weight / bias operand (by object identity: the fast weights are other
 # tensor objects, even where they share storage with a Parameter).
 _unwanted = None
+SKIP_UNUSED_GRADS = os.environ.get("IX_SKIP_UNUSED_GRADS", "1") == "1"   # "0": compute them all (A/B runs, tests)
 
 
 class skip_param_grads:
     def __init__(self, ids):
-        self.ids = ids
+        self.ids = ids if SKIP_UNUSED_GRADS else None
 
     def __enter__(self):
         global _unwanted

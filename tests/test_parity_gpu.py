@@ -218,6 +218,47 @@ def test_g13_g16_meta_train_step_and_outer_update(golden):
         assert abs(dn - rec["norm"]) <= 2e-2 * max(rec["norm"], 1e-9) + 1e-9, (k, dn, rec["norm"])
 
 
+def test_skipped_gradients_change_nothing_but_the_launch_count():
+    """hipops.skip_param_grads: the weight-gradient contractions nobody asked for (nn.Parameters in the MAML inner
+    gradient, the per-episode copies in the supervisor backward) are not launched.  Same model, same episodes, with and
+    without the skip: identical losses and None-pattern, gradients equal up to split-K summation order, fewer launches."""
+    import ctypes
+    from interactron_amd import Config, build_model, _lib, hipops
+    lib = _lib.load()
+    data = to_gpu(synthetic_episodes(2, height=128, width=160, tag="skip"))
+    res = []
+    for skip in (True, False):
+        hipops.SKIP_UNUSED_GRADS = skip
+        try:
+            m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", EPISODE_CHUNK=2)))
+            load_procedural(m.fusion, "fusion.")
+            m = m.cuda().eval()
+            m.zero_grad()
+            random.seed(5)
+            lib.ix_gemm_stats(None, None, 1)
+            _, losses = m(data)
+            torch.cuda.synchronize()
+            fl, n = ctypes.c_double(), ctypes.c_int64()
+            lib.ix_gemm_stats(ctypes.byref(fl), ctypes.byref(n), 1)
+            res.append((losses, {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}, fl.value, n.value))
+        finally:
+            hipops.SKIP_UNUSED_GRADS = True
+    (l1, g1, f1, n1), (l0, g0, f0, n0) = res
+    assert n1 < n0 - 50 and f1 < 0.97 * f0, (n1, n0, f1, f0)
+    for k in l0:
+        assert abs(float(l0[k]) - float(l1[k])) <= 1e-4 * max(abs(float(l0[k])), 1.0), k   # (two runs differ by this much)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is None:
+            continue
+        d, n = float((g0[k] - g1[k]).double().norm()), float(g0[k].double().norm())
+        if n < 1e-6:
+            continue   # mathematically zero gradient (rounding noise on both sides)
+        # two runs of the SAME code differ by 1e-3 .. 1e-2 on single tensors (atomic split-K sums in another order, then
+        # ~50 ReLU layers and the clipped inner step); a dropped term would be O(1)
+        assert d <= 3e-2 * n + 1e-9, (k, d, n)
+
+
 def test_episode_batched_equals_sequential_schedule():
     """EPISODE_CHUNK > 1 (episodes of a batch run together with per-episode fast weights [E, ...]) must reproduce the
     reference's task-by-task schedule (EPISODE_CHUNK = 0): same losses, same accumulated gradients."""
