@@ -2,7 +2,7 @@
 # One round's measurement artefacts (run on the GPU box through gpurun; results land in gpurun_out/$1/ and are copied into
 # profiles/ by hand): driver-style bench line, rocprofv3 kernel stats of the same command, the two PMC HBM-traffic passes,
 # SQ counters, the other reference configs / evaluation modes, the stress configuration, the 2-rank launcher smoke, power probe.
-TAG=${1:-r2a}
+TAG=${1:-r2c}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
