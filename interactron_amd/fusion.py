@@ -40,9 +40,14 @@ class SelfAttention(nn.Module):
         B, T, C = x.shape
         H = self.NUM_HEADS
         hd = C // H
-        k, q, v = self.key(x), self.query(x), self.value(x)
-        y = ops.attention(q, k, v, B, H, T, T, hd, C, C, 0, 0, C, 0, 1.0 / math.sqrt(hd), None, self.attn_drop.p,
-                          self.attn_drop.training)
+        # the three projections of the same input as ONE contraction (N = 3C instead of three N = C launches, one
+        # input-gradient contraction and no gradient sums over x); the attention kernels read [k | q | v] in place and hand
+        # the gradient back as one buffer of that layout
+        w = ops.CatParams.apply(self.key.weight, self.query.weight, self.value.weight)
+        b = ops.CatParams.apply(self.key.bias, self.query.bias, self.value.bias)
+        kqv = ops.linear(x, w, b)
+        y = ops.attention(kqv, kqv, kqv, B, H, T, T, hd, 3 * C, 3 * C, C, 0, 3 * C, 2 * C, 1.0 / math.sqrt(hd), None,
+                          self.attn_drop.p, self.attn_drop.training)
         return self.proj(y)   # (resid_drop is applied fused with the residual add in Block.forward)
 
 

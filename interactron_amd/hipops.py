@@ -200,6 +200,35 @@ def weight_view(w, *shape):
     return v
 
 
+def _is_unwanted(key, skip):
+    """`key` stands for one Parameter (an id) or for several (a tuple of ids: cat_params) -- all of them have to be named"""
+    if skip is None:
+        return False
+    if isinstance(key, tuple):
+        return all(k in skip for k in key)
+    return key in skip
+
+
+class CatParams(Function):
+    """torch.cat(params, 0) whose result keeps standing for its sources in skip_param_grads (fusion key / query / value
+    projections evaluated as one contraction); the gradient goes back as row views."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.sizes = [w.shape[0] for w in ws]
+        out = torch.cat(ws, 0)
+        keys = []
+        for w in ws:
+            k = _param_key(w)
+            keys.extend(k if isinstance(k, tuple) else (k,))
+        out._ix_of_param = tuple(keys)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.sizes, 0))
+
+
 def _param_key(t):
     """identity under which skip_param_grads knows a weight operand: the Parameter itself, or the Parameter a SplitRows view
     was cut from"""
@@ -230,9 +259,9 @@ class Gemm(Function):
         sp = ctx.sp
         dc = dc.contiguous()
         skip = _unwanted
-        need_a = ctx.needs_input_grad[0] and not (skip is not None and ctx.a_key in skip)
-        need_b = ctx.needs_input_grad[1] and not (skip is not None and ctx.b_key in skip)
-        need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not (skip is not None and ctx.bias_key in skip)
+        need_a = ctx.needs_input_grad[0] and not _is_unwanted(ctx.a_key, skip)
+        need_b = ctx.needs_input_grad[1] and not _is_unwanted(ctx.b_key, skip)
+        need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not _is_unwanted(ctx.bias_key, skip)
         # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
         # A-producer waves of that launch sum the dC tiles they stream anyway) whenever dC is its plain m-contiguous A operand
         fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
@@ -666,7 +695,10 @@ class FlashAttention(Function):
         q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
         out, lse, pl = flash_forward(q, k, v, g, mask, p, seed, need_backward=not isinstance(ctx, _NullCtx))
         ctx.g, ctx.p, ctx.seed, ctx.pl = g, p, seed, pl
-        ctx.same_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape   # packed [q | k] projection buffer
+        # packed projection buffers: [q | k] (nn.MultiheadAttention self-attention) or [k | q | v] (fusion blocks) in one tensor
+        same_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape
+        same_qv = q.data_ptr() == v.data_ptr() and q.shape == v.shape
+        ctx.same_qk = (same_qk, same_qv)
         ctx.save_for_backward(q, k, v, out, lse)
         return out
 
@@ -677,14 +709,18 @@ class FlashAttention(Function):
         return gq, gk, gv, None, None, None, None
 
 
-def _grad_buffers(g, q, k, v, same_qk):
-    """Gradient buffers in the operands' own (packed) layouts; columns that belong to other tensors stay zero."""
+def _grad_buffers(g, q, k, v, same):
+    """Gradient buffers in the operands' own (packed) layouts; columns that belong to other tensors stay zero.
+    same = (k shares q's tensor, v shares q's tensor): shared tensors get ONE buffer."""
+    same_qk, same_qv = same
     E, dev = g.heads * g.hd, q.device
     full = lambda ld, off: ld == E and off == 0
-    packed = same_qk and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]   # [q | k] buffer: fully covered
-    gq = (torch.empty if packed or full(g.q_ld, g.q_off) else torch.zeros)(q.shape, dtype=torch.float32, device=dev)
+    packed2 = same_qk and not same_qv and g.q_ld == 2 * E and sorted((g.q_off, g.k_off)) == [0, E]   # [q | k]: fully covered
+    packed3 = same_qk and same_qv and g.q_ld == 3 * E and sorted((g.q_off, g.k_off, g.v_off)) == [0, E, 2 * E]
+    gq = (torch.empty if packed2 or packed3 or (full(g.q_ld, g.q_off) and not (same_qk or same_qv)) else torch.zeros)(
+        q.shape, dtype=torch.float32, device=dev)
     gk = gq if same_qk else (torch.empty if full(g.k_ld, g.k_off) else torch.zeros)(k.shape, dtype=torch.float32, device=dev)
-    gv = (torch.empty if full(g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
+    gv = gq if same_qv else (torch.empty if full(g.v_ld, g.v_off) else torch.zeros)(v.shape, dtype=torch.float32, device=dev)
     return gq, gk, gv
 
 
@@ -709,9 +745,8 @@ class FlashAttentionBwd(Function):
         ctx.g, ctx.p, ctx.seed, ctx.same_qk = g, p, seed, same_qk
         ctx.pl = dict(pl, do=dop, delta=delta)
         ctx.save_for_backward(q, k, v, out, lse, do)
-        if same_qk:   # one buffer carries both gradients: hand it to q, nothing to k
-            return gq, None, gv
-        return gq, gk, gv
+        # a shared buffer carries the gradients of everything packed in it: hand it to q, nothing to the others
+        return gq, (None if same_qk[0] else gk), (None if same_qk[1] else gv)
 
     @staticmethod
     @once_differentiable
@@ -722,11 +757,14 @@ class FlashAttentionBwd(Function):
         Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
         zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)
         hq = _req(hq.contiguous()) if hq is not None else zeros(q)
-        if ctx.same_qk:
-            hk = hq          # one cotangent buffer [q | k] for the packed gradient buffer
+        if ctx.same_qk[0]:
+            hk = hq          # one cotangent buffer for the packed gradient buffer
         else:
             hk = _req(hk.contiguous()) if hk is not None else zeros(k)
-        hv = _req(hv.contiguous()) if hv is not None else zeros(v)
+        if ctx.same_qk[1]:
+            hv = hq
+        else:
+            hv = _req(hv.contiguous()) if hv is not None else zeros(v)
         hqp = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
         hkp = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
         hvp = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
@@ -741,7 +779,8 @@ class FlashAttentionBwd(Function):
                                        g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, E, 0, g.scale, ctx.p, ctx.seed,
                                        ws.data_ptr(), need.value, _stream()), "ix_flash_bwd_bwd_f32")
         need_in = ctx.needs_input_grad
-        return (dq if need_in[0] else None, (None if ctx.same_qk else dk) if need_in[1] else None, dv if need_in[2] else None,
+        return (dq if need_in[0] else None, (None if ctx.same_qk[0] else dk) if need_in[1] else None,
+                (None if ctx.same_qk[1] else dv) if need_in[2] else None,
                 None, None, ddo if need_in[5] else None, None, None, None, None, None)
 
 
@@ -1316,7 +1355,7 @@ class ConvFwd(Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        need_w = ctx.needs_input_grad[1] and not (_unwanted is not None and ctx.w_key in _unwanted)
+        need_w = ctx.needs_input_grad[1] and not _is_unwanted(ctx.w_key, _unwanted)
         dx = ConvBwdData.call(dy, w, ctx.cg) if ctx.needs_input_grad[0] else None
         dw = ConvBwdWeight.call(dy, x, ctx.cg, tuple(w.shape)) if need_w else None
         return dx, dw, None
@@ -1335,7 +1374,7 @@ class ConvBwdData(Function):
     def backward(ctx, g):
         dy, w = ctx.saved_tensors
         g = g.contiguous()
-        need_w = ctx.needs_input_grad[1] and not (_unwanted is not None and ctx.w_key in _unwanted)
+        need_w = ctx.needs_input_grad[1] and not _is_unwanted(ctx.w_key, _unwanted)
         ddy = ConvFwd.call(g, w, ctx.cg) if ctx.needs_input_grad[0] else None
         dw = ConvBwdWeight.call(dy, g, ctx.cg, tuple(w.shape)) if need_w else None
         return ddy, dw, None

@@ -755,6 +755,35 @@ def test_flash_attention_second_order_packed_qk(ops):
         close(a, b, 6e-5, "packed second-order " + name)
 
 
+@pytest.mark.parametrize("hd,pdrop", [(64, 0.0), (32, 0.1)])
+def test_flash_attention_packed_kqv_buffer(ops, hd, pdrop):
+    """k, q and v read out of ONE [n, L, 3E] projection buffer (the fusion blocks' three projections as one contraction):
+    forward, the single gradient buffer of that layout, and its double backward against float64."""
+    n, H, L = 2, 4, 150
+    E = H * hd
+    kqv = rnd(n, L, 3 * E, seed=1)
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, L, hd, 3 * E, 3 * E, E, 0, 3 * E, 2 * E, scale)
+    seed = 0x1234567
+    drop = ops.flash_dropmask(n * H, L, L, pdrop, seed).cpu().double() if pdrop > 0 else None
+    gy, w1 = rnd(n, L, E, seed=9), rnd(n, L, 3 * E, seed=10)
+
+    def run(dev, dt, fn):
+        a = kqv.to(dev, dt).requires_grad_(True)
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        out = fn(a)
+        (g1,) = torch.autograd.grad(out, [a], gyd, create_graph=True)
+        return out, g1, torch.autograd.grad((g1 * w1.to(dev, dt)).sum(), [a, gyd])
+
+    oh, g1h, g2h = run("cuda", torch.float32, lambda a: ops.FlashAttention.apply(a, a, a, g, None, pdrop, seed))
+    orf, g1r, g2r = run("cpu", torch.float64,
+                        lambda a: _ref_attention_drop(a[..., E:2 * E], a[..., :E], a[..., 2 * E:], H, scale, None, drop))
+    close(oh, orf, 2e-5, "packed kqv forward")
+    close(g1h, g1r, 3e-5, "packed kqv gradient")
+    for name, a, b in zip(["kqv", "dO"], g2h, g2r):
+        close(a, b, 6e-5, "packed kqv second-order " + name)
+
+
 @pytest.mark.parametrize("n,H,L,S,hd,masked", [(2, 8, 361, 361, 32, True), (1, 8, 300, 517, 64, False), (2, 4, 50, 130, 64, True)])
 def test_flash_forward_fp8(ops, n, H, L, S, hd, masked):
     """The opt-in fp8 forward (e4m3 operands: 3 mantissa bits, 6 % per element; fp32 accumulate and softmax) against
