@@ -49,6 +49,10 @@ def load():
         raise HipLibraryError(
             "HIP kernel library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C interactron_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # PyTorch first: its wheel bundles its own HIP runtime (torch/lib/libamdhip64.so).  Loaded after it, this library binds
+    # to that same runtime instance; loaded BEFORE torch it would pull in /opt/rocm's copy as a second runtime in the
+    # process, and kernels launched on torch's streams then fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
