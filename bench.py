@@ -393,7 +393,7 @@ def main():
                     help="train (default, the headline): meta-train step; predict: model.predict per episode (eval adapt, "
                          "reference interactron.py:31-59); interactive: predict + 4 x get_next_action per episode (SURVEY 8d iii)")
     ap.add_argument("--chunk", type=int, default=16, help="EPISODE_CHUNK: episodes run together as one batched pass (0 = sequential)")
-    ap.add_argument("--n800-episodes", type=int, default=4,
+    ap.add_argument("--n800-episodes", type=int, default=8,
                     help="episodes per GPU per step of the north-star sub-measurement (5 x 3x800x800 frames each; 0 = skip it)")
     ap.add_argument("--attention-dtype", default="fp32", choices=["fp32", "fp8"],
                     help="fp8: the forward attention products on OCP e4m3 MFMA (BASELINE.json configs[4], the 1600 / 200-query "

@@ -2,15 +2,15 @@
 # One round's measurement artefacts (run on the GPU box through gpurun; results land in gpurun_out/$1/ and are copied into
 # profiles/ by hand): driver-style bench line, rocprofv3 kernel stats of the same command, the two PMC HBM-traffic passes,
 # SQ counters, the other reference configs / evaluation modes, the stress configuration, the 2-rank launcher smoke, power probe.
-TAG=${1:-r2c}
+TAG=${1:-r2d}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_p300_e16_profiled.json 2> $OUT/prof.err
 cp $OUT/prof/p_kernel_stats.csv $OUT/${TAG}_bench_p300_e16_kernel_stats.csv; rm -rf $OUT/prof
-rocprofv3 --kernel-trace --stats -d $OUT/prof8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 4 --chunk 4 --steps 2 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_800_e4_profiled.json 2> $OUT/prof8.err
-cp $OUT/prof8/p_kernel_stats.csv $OUT/${TAG}_bench_800_e4_kernel_stats.csv; rm -rf $OUT/prof8
+rocprofv3 --kernel-trace --stats -d $OUT/prof8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 8 --chunk 8 --steps 2 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_800_e8_profiled.json 2> $OUT/prof8.err
+cp $OUT/prof8/p_kernel_stats.csv $OUT/${TAG}_bench_800_e8_kernel_stats.csv; rm -rf $OUT/prof8
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
 python tools/pmc_summary.py $OUT/pf/p_counter_collection.csv $OUT/pw/p_counter_collection.csv $OUT/${TAG}_pmc_hbm_traffic.json > /dev/null; rm -rf $OUT/pf $OUT/pw
