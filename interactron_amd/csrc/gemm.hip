@@ -5,9 +5,12 @@
 //
 // Every contraction on the Interactron hot path is routed here: the Linear layers of the DETR
 // encoder/decoder and of the GPT fusion (reference models/detr_models/transformer.py:148-232,
-// models/gpt.py:39-78), the per-head QK^T / PV products of both attentions, the ResNet-50 convolutions after
-// an NHWC im2col (reference models/detr_models/backbone.py:88-90), and all of their first- and second-order
-// derivatives, which are again GEMMs of this form with the operand layouts flipped.
+// models/gpt.py:39-78), the ResNet-50 convolutions (reference models/detr_models/backbone.py:88-90) as implicit
+// GEMMs (ConvGather / ix_conv_gemm_f32 below: the producer waves gather the NHWC taps), and all of their first-
+// and second-order derivatives, which are again contractions of this form with the operand layouts flipped.
+// (The attention products live in flash.hip.)  File layout: the exact-fp32 MFMA kernel first (this header describes
+// it), then the bf16x6 kernel family (the dominant kernel: "fp32 GEMM on the bf16 matrix cores" further down), the
+// host-side choice between them (gemm_impl), the ride-alongs (row sums, convolution gathers) and the profiling hooks.
 //
 // Operand layouts (so that no transposed copy is ever materialised):
 //   A_KC : A(m,k) = A[m*lda + k]   else A(m,k) = A[k*lda + m]

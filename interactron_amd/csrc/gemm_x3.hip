@@ -8,7 +8,7 @@
 // fp16 planes  x 2^e = h + l  (22-23 significant bits) with one power-of-two scale per block of 32 rows taken over the
 // WHOLE contracted extent, and the GEMM kernel streams 16-bit planes (no conversion arithmetic at all) and issues the three
 // terms  l.h + h.l + h.h  on v_mfma_f32_32x32x16_f16 -- the arithmetic of the attention kernels' head-dim products
-// (flash.hip), accuracy class of an fp32 dot product (tests/test_ops_gpu.py::test_f16x3_contraction_is_fp32_grade).
+// (flash.hip), accuracy class of an fp32 dot product (tests/test_ops_gpu.py::test_f16x3_presplit_contraction_is_fp32_grade).
 // The block scales of the two operands are undone by one multiply per 32x32 accumulator block in the epilogue.
 //
 // Canonical operand form: BOTH operands as row-major planes [batch][rows padded to 128][K padded to 32] with the
