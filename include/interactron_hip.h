@@ -66,6 +66,12 @@ int ix_gemm_rowsum_f32(const float* A, const float* B, float* C, int M, int N, i
                        int64_t ldb, int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, float alpha,
                        float* rowsum, int64_t rowsum_stride, ix_stream_t stream);
 
+/* Test hook like ix_gemm_set_mode: 1 = 128-wide tiles of eligible contractions run the fp16x3 form of the 12-wave kernel
+ * (two fp16 planes + one exponent per 32 x 32 sub-block found by the producer waves, three v_mfma_f32_32x32x16_f16 per
+ * k-slice; opt-in, also IX_GEMM_KERNEL=x3 in the environment), 0 (default) = the bf16x6 form everywhere.  Returns the
+ * previous setting. */
+int ix_gemm_set_x3(int on);
+
 /* Launch statistics of ix_gemm_f32 (HOST pointers; process-global, single host thread): executed FLOPs
  * (2*M*N*K*batch) and launch count since the last reset; with ix_gemm_prof_enable(1) every launch is bracketed by a
  * hipEvent pair on its stream and ix_gemm_prof_read returns the summed kernel time (it waits for the events). */

@@ -16,6 +16,22 @@ def check_record(rec, t, atol=1e-5, rtol=1e-4, what=""):
     assert abs(n - rec["norm"]) <= rtol * 10 * max(rec["norm"], 1e-12) + atol, (what, n, rec["norm"])
 
 
+_RATIOS = {}   # IX_TEST_RECORD=<file>: worst observed / allowed ratio per check kind instead of asserting (tolerance survey)
+
+
+def _judge(kind, what, value, bound, detail):
+    import os
+    path = os.environ.get("IX_TEST_RECORD")
+    if not path:
+        assert value <= bound, (what, kind) + tuple(detail)
+        return
+    r = value / max(bound, 1e-300)
+    if r > _RATIOS.get(kind, (0.0, ""))[0]:
+        _RATIOS[kind] = (r, what)
+        with open(path, "a") as f:
+            f.write("%s %.4f %s\n" % (kind, r, what))
+
+
 def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
     """Compare a gradient against a ``grad_record`` entry (None flag, L2 norm, first 8 values, 256 values on an even
     stride over the whole tensor -- a slice routed to the wrong place keeps the norm but not the strided sample).
@@ -41,26 +57,32 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
         # SGD step or a ReLU sitting on its kink flips with the summation order); there are no other elements to average
         # that out of the norm (tools/scalar_spread.py)
         rel = max(rel, 5e-2)
-    assert abs(n - rec["norm"]) <= rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (what, n, rec["norm"], norm64)
+    # Norm: 2 x rel.  Measured (IX_TEST_RECORD survey, 14 runs per test of the SAME binary, round 2): on the second-order
+    # configurations single backbone tensors move by up to 0.7 % of their norm from run to run (atomic split-K / row-sum
+    # orders decide which side of a ReLU kink or of the inner step's clip an element falls on -- discrete flips, heavy
+    # tails); the first-order configurations stay below 0.03 x the bound.
+    _judge("norm", what, abs(n - rec["norm"]), 2 * rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (n, rec["norm"], norm64))
     scale = max(rec["norm"] / max(g.numel(), 1) ** 0.5, 1e-12)
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
-    assert err <= 20 * rel * scale + ref_noise + 1e-9, (what, err, scale)
+    _judge("head", what, err, 20 * rel * scale + ref_noise + 1e-9, (err, scale))
     if "sample" in rec:
         # 256 values on an even stride over the whole tensor.  Float32 summation-order noise is relative to the tensor's
         # RMS, not to each element, and in the second-order gradients single elements move discretely (an element of the
         # clipped inner step or a ReLU on its kink flips -- run to run on the same binary, split-K atomics): so the
-        # sample must agree in L2 within 4 x rel, at most 2 % of its elements may be off by more than 20 x rel x RMS, and
+        # sample must agree in L2 within 20 x rel, at most 2 % of its elements may be off by more than 20 x rel x RMS, and
         # none by more than 100 x rel x RMS.  A slice routed to the wrong place is off by O(RMS) on EVERY element it covers.
         got = g.reshape(-1)[rec["idx"]].double()
         ref = rec["sample"].double()
         diff = (got - ref).abs()
         bound = 20 * rel * scale + ref_noise + 1e-9
         outliers = int((diff > bound).sum())
-        assert outliers <= max(1, len(ref) // 50), (what, "strided sample: elements off", outliers, float(diff.max()), scale)
-        assert float(diff.max()) <= 5 * bound, (what, "strided sample: worst element", float(diff.max()), scale)
+        _judge("strided outliers", what, outliers, max(1, len(ref) // 50), (outliers, float(diff.max()), scale))
+        _judge("strided worst element", what, float(diff.max()), 5 * bound, (float(diff.max()), scale))
         rn = float(ref.norm())
-        assert float(diff.norm()) <= 4 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9, \
-            (what, "strided sample L2", float(diff.norm()), rn)
+        # (the same survey: up to 12 x rel on layer2 / layer3 convolution weights of the second-order configurations,
+        #  0.25 x 4 rel on the first-order ones; a mis-routed slice is off by ~100 x rel)
+        _judge("strided sample L2", what, float(diff.norm()), 20 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9,
+               (float(diff.norm()), rn))
 
 
 def image_key(t):

@@ -493,6 +493,55 @@ def test_bf16x6_contraction_is_fp32_grade(ops, akc, bkc):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_f16x3_kernel_is_fp32_grade(ops, akc, bkc):
+    """The fp16x3 form of the 12-wave contraction kernel (two fp16 planes with one exponent per 32 x 32 sub-block found by
+    the producer waves, three fp16 MFMAs per k-slice, accumulators rescaled when a sub-block's exponent grows) against
+    float64 and against the bf16x6 form: every operand layout, ragged M / N / K, batch, bias, alpha, split-K, and operands
+    whose magnitude ramps UP and DOWN by 2^40 along K (the exponent then changes many times inside an item) or differs by
+    e^+-8 between rows; an all-zero operand; a sub-block of denormals."""
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(7)
+    cases = [(130, 180, 256, 2, 1, "plain"), (300, 260, 1808, 2, 3, "plain"), (1804, 512, 260, 1, 1, "rows"),
+             (260, 132, 2048, 1, 1, "ramp_up"), (260, 132, 2048, 1, 1, "ramp_down"), (256, 256, 4000, 1, 4, "ramp_up"),
+             (128, 128, 512, 1, 1, "zeros"), (128, 128, 512, 1, 1, "denormal")]
+    for (M, N, K, b, split, kind) in cases:
+        a, w = rnd(b, M, K, seed=1), rnd(b, K, N, seed=3)
+        if kind == "rows":
+            a = a * (2.0 * rnd(b, M, 1, seed=2)).exp()
+            w = w * (2.0 * rnd(b, 1, N, seed=5)).exp()
+        if kind in ("ramp_up", "ramp_down"):
+            ramp = torch.exp2(torch.linspace(-20, 20, K) * (1 if kind == "ramp_up" else -1))
+            a = a * ramp[None, None, :]
+            w = w * torch.exp2(6 * torch.rand(K, generator=gen) - 3)[None, :, None]
+        if kind == "zeros":
+            a = torch.zeros_like(a)
+        if kind == "denormal":
+            a[:, :32, :64] *= 1e-42
+        a, w = a.cuda(), w.cuda()
+        bias = rnd(N, seed=4).cuda()
+        ref = 0.75 * (a.double() @ w.double()) + bias.double()
+        scale = 0.75 * (a.double().abs() @ w.double().abs()) + bias.double().abs() + 1e-300
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        errs = {}
+        for form in (1, 0):
+            old = lib.ix_gemm_set_x3(form)
+            try:
+                C = torch.full((b, M, N), float("nan"), device="cuda")
+                rc = lib.ix_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc,
+                                     K if akc else M, K if bkc else N, N, b, 1, M * K, 0, K * N, 0, M * N, 0, 0, 0.75, 1128,
+                                     split, stream)
+                assert rc == 0, lib.ix_last_error()
+                errs[form] = float(((C.double() - ref).abs() / scale).max())
+            finally:
+                lib.ix_gemm_set_x3(old)
+        assert errs[1] <= (1.5e-6 if kind.startswith("ramp") else 6e-7), (M, N, K, kind, errs)   # (ramps: bf16x6 7.8e-7, exact fp32 1.3e-6)
+        assert errs[1] <= 2.5 * errs[0] + 1e-7, (M, N, K, kind, errs)
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     """The pre-split fp16x3 route of ix_gemm_f32_ws (two fp16 planes + one power-of-two scale per 32 rows, three fp16 MFMA
     terms) against float64: every operand layout, ragged M/N/K, batches, shared operands (stride 0), bias, alpha, the
