@@ -561,17 +561,22 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         }
         // wave maximum without the LDS crossbar (six ds_bpermute shuffles cost the producers 8 % of the kernel): the bit
         // pattern of a non-negative float orders like an integer; DPP row shifts, then row broadcasts; lane 63 has it
-        int mi = (int)__float_as_uint(mx);
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x111, 0xf, 0xf, false));   // row_shr:1
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x112, 0xf, 0xf, false));   // row_shr:2
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x114, 0xf, 0xf, false));   // row_shr:4
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x118, 0xf, 0xf, false));   // row_shr:8  (lane 15 of a row: row maximum)
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
-        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
-        const int eb = (__builtin_amdgcn_readlane(mi, 63) >> 23) & 0xff;
-        // zero / denormal / inf sub-block: keep the running exponent (its values convert to 0 / inf whatever the scale)
-        int E = (eb < 16 || eb > 250) ? erun : eb - 141;   // x * 2^-E has its maximum in [2^14, 2^15)
-        erun = max(erun, E);
+        // E only has to change when some value would leave [0, 2^15) under the running scale -- one compare and a vote;
+        // the reduction itself (six dependent DPP steps + a readlane) then runs once per item and whenever the data grows
+        const float lim = erun <= -1000 ? 0.f : __uint_as_float((unsigned)(142 + erun) << 23);   // 2^(15 + erun)
+        if (__ballot(mx >= lim) != 0) {
+            int mi = (int)__float_as_uint(mx);
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x111, 0xf, 0xf, false));   // row_shr:1
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x112, 0xf, 0xf, false));   // row_shr:2
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x114, 0xf, 0xf, false));   // row_shr:4
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x118, 0xf, 0xf, false));   // row_shr:8  (lane 15 of a row: row maximum)
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1, 3
+            mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2, 3
+            const int eb = (__builtin_amdgcn_readlane(mi, 63) >> 23) & 0xff;
+            // zero / denormal / inf sub-block: keep the running exponent (its values convert to 0 / inf whatever the scale)
+            const int E = (eb < 16 || eb > 250) ? erun : eb - 141;   // x * 2^-E has its maximum in [2^14, 2^15)
+            erun = max(erun, E);
+        }
         const float sc = erun <= -1000 ? 1.f : __uint_as_float((unsigned)(127 - erun) << 23);
         if ((tid & 63) == 0) *expo = erun;
 #pragma unroll
@@ -1743,10 +1748,11 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
 #undef X3Q_EXPO
 }
 
-// Opt-in (IX_GEMM_KERNEL=x3, or ix_gemm_set_x3 from the tests).  Measured on the step's 24 heaviest shapes: 94.8 vs 105.1 ms
-// (-9.8 %; the diagnostic bound without any conversion / exponent work was -27 %: the wave maximum, the scale multiply and
-// the fp16 round trip cost the producers what the consumers save), whole step 324 vs 329 ms -- not enough to move the
-// default off the bf16x6 form, whose parity record is two rounds old.
+// Opt-in (IX_GEMM_KERNEL=x3, or ix_gemm_set_x3 from the tests).  Measured on the step's 24 heaviest shapes: 93.4 vs 108.4 ms
+// (-13.8 %; the diagnostic bound without any conversion / exponent work was -27 %), whole step 325-327 vs 338 ms (246 vs 237
+// frames/s) with the convolutions still on the bf16x6 form.  Not the default in this round: under its own peak (2500 / 3
+// TFLOP/s) its roofline fraction reads 0.23 where the bf16x6 form reads 0.39-0.40 of 2500 / 6, and the bf16x6 form's parity
+// record is two rounds old.
 static int g_x3k = -1;
 static bool x3k_enabled() {
     if (g_x3k < 0) {
