@@ -315,8 +315,14 @@ def test_episode_batched_equals_sequential_schedule():
         # backbone weights between ANY two summation orders (the reference's own float32 is 0.1-0.3 % off float64 on
         # the norms of these tensors at 300x300, more on the 8x10-token maps used here); a mis-routed episode weight
         # would show up as O(1) differences
-        assert abs(n0 - n1) <= 2e-2 * n0 + 1e-7, (k, n0, n1)
-        assert float((g0[k] - g1[k]).double().norm()) <= 1e-1 * n0 + 1e-7, (k, n0, n1)
+        # (per tensor 5 % / 15 %: two runs of one binary reach 3 % on single tensors of these small maps; the whole
+        #  gradient is compared below)
+        assert abs(n0 - n1) <= 5e-2 * n0 + 1e-7, (k, n0, n1)
+        assert float((g0[k] - g1[k]).double().norm()) <= 1.5e-1 * n0 + 1e-7, (k, n0, n1)
+    have = [k for k in g0 if g0[k] is not None]
+    num = sum(float((g0[k] - g1[k]).double().norm()) ** 2 for k in have)
+    den = sum(float(g0[k].double().norm()) ** 2 for k in have)
+    assert (num / den) ** 0.5 <= 2e-2, (num, den)
 
 
 def test_batched_predict_equals_per_episode_predict():
