@@ -362,6 +362,14 @@ def build_roofline(kms, kfl, kn, fms, ffl, fmf, fn):
                         for i in range(1, 7) if fms[i] > 0}}
     total_ms = kms[0] + kms[1] + fms[0]
     total_fl = kfl[0] + kfl[1] + ffl[0]
+    if os.environ.get("IX_GEMM_KERNEL", "") == "x3" and k == 1:
+        # opt-in fp16x3 form: its 128-wide tiles issue three fp16 MFMAs per product, the rest (narrow tiles, convolution
+        # gathers) still six bf16 ones, and the launch records do not tell them apart -- no single peak prices this mix
+        return {"bound": "mfma", "kernel": "gemm_f32_f16x3_p12_kernel + gemm_f32_bf16x6_p12_kernel (IX_GEMM_KERNEL=x3)",
+                "achieved": tf[k], "peak": None, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9, "kernel_ms_per_step": kms[k],
+                "note": "mixed kernel forms: peaks 2500/3 (fp16x3 tiles) and 2500/6 (bf16x6 tiles); compare kernel_ms_per_step "
+                        "with the default run's", "attention_kernels": attn}
     return {"bound": "mfma", "kernel": kname, "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak,
             "traffic": pmc_traffic(kname), "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
             "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
