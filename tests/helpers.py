@@ -106,8 +106,11 @@ class ReferenceMatching:
     comparison is about arithmetic, not about tie-breaking."""
 
     # Share of images whose own optimum may differ from the recorded assignment (always by a tie, see above) before the
-    # run is declared a failure: measured 0-3 % on the RNG-free weights; a matcher or cost-kernel bug flips most images.
+    # run is declared a failure: measured 0-3 % on the RNG-free weights over the large fixtures; a matcher or cost-kernel
+    # bug flips most images (and breaks the tie assertion first).  Small tests see 0-2 flips among their 6 images (config
+    # 3: 2 of 6 once in 30 runs), hence the additive slack of 3.
     MAX_FLIP_SHARE = 0.10
+    FLIP_SLACK = 3
 
     def __init__(self, recorded, max_flip_share=None):
         self.recorded = recorded
@@ -149,5 +152,5 @@ class ReferenceMatching:
         self._cls.assign = self._orig
         print("ReferenceMatching: %d of %d images matched differently from the reference (ties)" % (self.flips, self.calls))
         if exc[0] is None:
-            assert self.flips <= self.max_flip_share * max(self.calls, 1) + 1, \
+            assert self.flips <= self.max_flip_share * max(self.calls, 1) + self.FLIP_SLACK, \
                 "HIP matcher disagrees with the reference's assignment on %d of %d images" % (self.flips, self.calls)
