@@ -268,6 +268,13 @@ int ix_sine_pos_f32(const uint8_t* mask, float* pos, int n, int h, int w, int nu
                     float scale, ix_stream_t stream);
 int ix_mask_nearest_u8(const uint8_t* in, uint8_t* out, int n, int H, int W, int h, int w, ix_stream_t stream);
 
+/* Episode expansion of a parameter list and its adjoint, all tensors in one launch set (HOST arrays of device pointers;
+ * sizes[i] = elements of one copy).  expand: out_i[E][n_i] = E copies of src_i[n_i] -- the per-episode copies of theta the
+ * episode-batched step differentiates (reference models/interactron.py:86-90, clone_parameters per task);  reduce:
+ * out_i[n_i] = sum over the E copies of src_i[E][n_i], in a fixed order -- the reference's gradient accumulation over tasks. */
+int ix_expand_multi_f32(const float* const* src, float* const* out, const int64_t* sizes, int ntensors, int E, ix_stream_t stream);
+int ix_reduce_multi_f32(const float* const* src, float* const* out, const int64_t* sizes, int ntensors, int E, ix_stream_t stream);
+
 /* ---- MAML fast weights (utils/meta_utils.py:135-142) and outer step (engine/interactron_trainer.py:107-111) --
  * p / g / out / G are HOST arrays of `ntensors` device pointers, sizes a HOST array of element counts. */
 int ix_sgd_clip_multi_f32(const float* const* p, const float* const* g, float* const* out, const int64_t* sizes,

@@ -57,6 +57,77 @@ static int launch_multi(const char* name, const float* const* a, const float* co
     return IX_OK;
 }
 
+// Episode expansion of the fast weights and its adjoint, all tensors of a parameter list in one launch set
+// (reference models/interactron.py:86-90: theta_task = clone(theta) per task; here the E copies of a chunk):
+//   expand:  out_i[e * n_i + k] = src_i[k]            (e < E)        m.n = E * n_i output elements
+//   reduce:  out_i[k] = sum_e src_i[e * n_i + k]                     m.n = n_i output elements (fixed order: deterministic)
+__global__ __launch_bounds__(256) void multi_expand_kernel(MultiArgs m, int E) {
+    int t = 0;
+    while (t + 1 < m.count && (int)blockIdx.x >= m.block_start[t + 1]) ++t;
+    const int64_t base = (int64_t)(blockIdx.x - m.block_start[t]) * MT_CHUNK;
+    const int64_t end = base + MT_CHUNK < m.n[t] ? base + MT_CHUNK : m.n[t];
+    const int64_t n = m.n[t] / E;
+    const float* a = m.a[t];
+    float* o = m.o[t];
+    for (int64_t k = base + threadIdx.x; k < end; k += 256) o[k] = a[k % n];
+}
+
+__global__ __launch_bounds__(256) void multi_reduce_kernel(MultiArgs m, int E) {
+    int t = 0;
+    while (t + 1 < m.count && (int)blockIdx.x >= m.block_start[t + 1]) ++t;
+    const int64_t base = (int64_t)(blockIdx.x - m.block_start[t]) * MT_CHUNK;
+    const int64_t n = m.n[t];
+    const int64_t end = base + MT_CHUNK < n ? base + MT_CHUNK : n;
+    const float* a = m.a[t];
+    float* o = m.o[t];
+    for (int64_t k = base + threadIdx.x; k < end; k += 256) {
+        float s = 0.f;
+        for (int e = 0; e < E; ++e) s += a[(int64_t)e * n + k];
+        o[k] = s;
+    }
+}
+
+// sizes[i] = elements of ONE copy (n_i); expand: src [n_i] -> out [E, n_i]; reduce: src [E, n_i] -> out [n_i]
+static int launch_multi_e(const char* name, bool expand, const float* const* src, float* const* out, const int64_t* sizes,
+                          int ntensors, int E, hipStream_t stream) {
+    IX_CHECK_ARG(ntensors >= 0 && E >= 1 && (ntensors == 0 || (src && out && sizes)), "%s: bad args", name);
+    int i = 0;
+    while (i < ntensors) {
+        MultiArgs m;
+        int cnt = 0, blocks = 0;
+        while (i < ntensors && cnt < MT_MAX) {
+            if (sizes[i] > 0) {
+                IX_CHECK_ARG(src[i] && out[i], "%s: null tensor %d", name, i);
+                const int64_t n_out = expand ? sizes[i] * E : sizes[i];
+                m.a[cnt] = src[i]; m.b[cnt] = nullptr; m.o[cnt] = out[i]; m.n[cnt] = n_out;
+                m.block_start[cnt] = blocks;
+                blocks += (int)((n_out + MT_CHUNK - 1) / MT_CHUNK);
+                ++cnt;
+            }
+            ++i;
+        }
+        if (cnt == 0) break;
+        m.block_start[cnt] = blocks;
+        m.count = cnt;
+        if (expand)
+            hipLaunchKernelGGL(multi_expand_kernel, dim3(blocks), dim3(256), 0, stream, m, E);
+        else
+            hipLaunchKernelGGL(multi_reduce_kernel, dim3(blocks), dim3(256), 0, stream, m, E);
+        IX_CHECK_LAUNCH(name);
+    }
+    return IX_OK;
+}
+
+extern "C" int ix_expand_multi_f32(const float* const* src, float* const* out, const int64_t* sizes, int ntensors, int E,
+                                   hipStream_t stream) {
+    return launch_multi_e("ix_expand_multi_f32", true, src, out, sizes, ntensors, E, stream);
+}
+
+extern "C" int ix_reduce_multi_f32(const float* const* src, float* const* out, const int64_t* sizes, int ntensors, int E,
+                                   hipStream_t stream) {
+    return launch_multi_e("ix_reduce_multi_f32", false, src, out, sizes, ntensors, E, stream);
+}
+
 // out_i = p_i - clamp(lr*g_i, -clip, clip) for every tensor i (host arrays of device pointers)
 extern "C" int ix_sgd_clip_multi_f32(const float* const* p, const float* const* g, float* const* out,
                                      const int64_t* sizes, int ntensors, float lr, float clip, hipStream_t stream) {

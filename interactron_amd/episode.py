@@ -187,8 +187,7 @@ class _Adaptive(_EpisodeModel):
                 frames = data["frames"][e0:e0 + E].reshape(E * s, c, w, h)
                 masks = data["masks"][e0:e0 + E].reshape(E * s, w, h)
                 with torch.enable_grad():
-                    dtheta = [ops.BcastRows.apply(p.detach().reshape(-1), E).reshape((E,) + tuple(p.shape)).requires_grad_(True)
-                              for p in theta]
+                    dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
                     set_parameters(self.detector, dtheta)
                     nt = NestedTensor(frames, masks)
                     nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
@@ -232,8 +231,7 @@ class _Adaptive(_EpisodeModel):
                 labels = [_labels(data, t) for t in ep]
                 frames, masks = img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)
                 # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
-                dtheta = [ops.BcastRows.apply(p.detach().reshape(-1), E).reshape((E,) + tuple(p.shape)).requires_grad_(True)
-                          for p in theta]
+                dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
                 set_parameters(self.detector, dtheta)
                 # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
                 nt = NestedTensor(frames, masks)
@@ -264,7 +262,7 @@ class _Adaptive(_EpisodeModel):
                 # not on the criterion: its forward is queued NOW, so that the GPU works on it while the host runs the
                 # Hungarian assignment and builds the criterion.  The expansion of theta is differentiable; its backward
                 # sums the per-episode gradients into theta.grad.
-                attached = [ops.BcastRows.apply(p.reshape(-1), E).reshape((E,) + tuple(p.shape)) for p in theta]
+                attached = list(ops.ExpandEpisodes.apply(E, *theta))
                 fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
                 set_parameters(self.detector, fast1)
                 nt1 = NestedTensor(frames[sel], masks[sel])

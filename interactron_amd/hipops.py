@@ -1657,6 +1657,52 @@ def _size_array(tensors):
     return arr
 
 
+class ExpandEpisodes(Function):
+    """apply(E, p_1..p_n) -> ([E, *p_1.shape], ..): the per-episode copies of a parameter list in one multi-tensor launch
+    set (199 single-tensor launches before).  Backward = ReduceEpisodes: the sum over the E copies, i.e. the reference's
+    gradient accumulation over the tasks of a batch, in a fixed order (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, E, *ps):
+        pc = [_req(p) for p in ps]
+        outs = [torch.empty((E,) + tuple(p.shape), device=p.device, dtype=torch.float32) for p in pc]
+        _chk(_L().ix_expand_multi_f32(_ptr_array(pc), _ptr_array(outs), _size_array(pc), len(pc), E, _stream()),
+             "ix_expand_multi_f32")
+        ctx.E = E
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        idx = [i for i, g in enumerate(gs) if g is not None and ctx.needs_input_grad[1 + i]]
+        res = [None] * len(gs)
+        if idx:
+            for i, r in zip(idx, ReduceEpisodes.call(ctx.E, *[gs[i] for i in idx])):
+                res[i] = r
+        return (None,) + tuple(res)
+
+
+class ReduceEpisodes(Function):
+    """apply(E, g_1..g_n) with g_i [E, ...] -> (sum over the leading dim, ..) in one multi-tensor launch set."""
+
+    @staticmethod
+    def forward(ctx, E, *gs):
+        gc = [_req(g) for g in gs]
+        outs = [torch.empty(tuple(g.shape[1:]), device=g.device, dtype=torch.float32) for g in gc]
+        _chk(_L().ix_reduce_multi_f32(_ptr_array(gc), _ptr_array(outs), _size_array(outs), len(gc), E, _stream()),
+             "ix_reduce_multi_f32")
+        ctx.E = E
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *hs):
+        idx = [i for i, h in enumerate(hs) if h is not None and ctx.needs_input_grad[1 + i]]
+        res = [None] * len(hs)
+        if idx:
+            for i, r in zip(idx, ExpandEpisodes.call(ctx.E, *[hs[i] for i in idx])):
+                res[i] = r
+        return (None,) + tuple(res)
+
+
 class ClippedSGD(Function):
     """fast_i = p_i - clamp(lr*g_i, +-clip) for all tensors in one multi-tensor launch set.
 

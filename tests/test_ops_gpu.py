@@ -414,6 +414,26 @@ def test_clipped_sgd_first_and_second_order(ops):
         close(a, b, 1e-6, "sgd grad")
 
 
+def test_expand_and_reduce_episodes_multi_tensor(ops):
+    """ExpandEpisodes / ReduceEpisodes (one launch set for a whole parameter list): values, the gradient (a sum over the
+    copies) and the gradient of that (an expansion again)."""
+    E = 5
+    ps = [rnd(7, 3, seed=1), rnd(4100, seed=2), rnd(2, 3, 3, 4, seed=3), rnd(1, seed=4)] + [rnd(11, seed=10 + i) for i in range(60)]
+    xh = [p.cuda().requires_grad_(True) for p in ps]
+    outs = ops.ExpandEpisodes.apply(E, *xh)
+    for o, p in zip(outs, ps):
+        assert tuple(o.shape) == (E,) + tuple(p.shape)
+        assert torch.equal(o.cpu(), p.unsqueeze(0).expand((E,) + tuple(p.shape)))
+    ws = [rnd(*o.shape, seed=100 + i).cuda().requires_grad_(True) for i, o in enumerate(outs)]
+    gs = torch.autograd.grad(outs, xh, ws, create_graph=True)
+    for g, w in zip(gs, ws):
+        close(g, w.detach().double().sum(0), 1e-6, "reduce over episodes")
+    vs = [rnd(*g.shape, seed=200 + i).cuda() for i, g in enumerate(gs)]
+    hs = torch.autograd.grad(gs, ws, vs)
+    for h, v in zip(hs, vs):
+        assert torch.equal(h, v.unsqueeze(0).expand_as(h))
+
+
 def test_lsap_matches_scipy(ops):
     from scipy.optimize import linear_sum_assignment
     rng = np.random.default_rng(0)
