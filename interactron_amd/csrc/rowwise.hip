@@ -595,8 +595,12 @@ extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float
                                     int groups, hipStream_t stream) {
     IX_CHECK_ARG(dgamma && dbeta && groups >= 1 && groups <= 65535, "ix_layernorm_bwd_f32: bad dgamma/dbeta/groups");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_f32: D=%d unsupported (1..1024)", D);
-    hipMemsetAsync(dgamma, 0, sizeof(float) * D * groups, stream);
-    hipMemsetAsync(dbeta, 0, sizeof(float) * D * groups, stream);
+    if (dbeta == dgamma + (size_t)D * groups) {   // one allocation [2][groups][D] (hipops does that): one fill
+        hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * D * groups, stream);
+    } else {
+        hipMemsetAsync(dgamma, 0, sizeof(float) * D * groups, stream);
+        hipMemsetAsync(dbeta, 0, sizeof(float) * D * groups, stream);
+    }
     if (rows <= 0) return IX_OK;
     IX_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ix_layernorm_bwd_f32: null pointer");
     const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);

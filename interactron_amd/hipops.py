@@ -1509,8 +1509,8 @@ class LayerNormBwd(Function):
         G = gamma.shape[0] if gamma.dim() == 2 else 1
         rows = x.numel() // D
         dx = torch.empty_like(x)
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(dgamma)
+        both = torch.empty((2,) + tuple(gamma.shape), device=gamma.device, dtype=torch.float32)   # (one fill for the two)
+        dgamma, dbeta = both[0], both[1]
         _chk(_L().ix_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                        dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows // G, D, G, _stream()),
              "ix_layernorm_bwd_f32")
