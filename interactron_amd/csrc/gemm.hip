@@ -2264,12 +2264,10 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     a.split_k = split;
     a.k_per_split = kps;
     if (split > 1) {
-        if (ldc == N && (nbatch == 1 || (batch_inner == 1 && sCo == (int64_t)M * N))) {   // dense output: one fill
-            hipMemsetAsync(C, 0, sizeof(float) * (size_t)M * N * nbatch, stream);
-        } else {
-            dim3 zg(ix_grid_1d((int64_t)M * N, 256), nbatch);
-            hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, C, M, N, ldc, sCo, sCi, batch_inner);
-        }
+        // (a kernel, not hipMemsetAsync: inside the policy step's captured HIP graph a memset node in front of the atomics
+        //  replayed differently from eager -- tests/test_parity_gpu.py::test_policy_step_graph_replay_equals_eager)
+        dim3 zg(ix_grid_1d((int64_t)M * N, 256), nbatch);
+        hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, C, M, N, ldc, sCo, sCi, batch_inner);
     }
     if (rowsum) {
         if (use_x6 && !a_kcontig && batch_inner == 1 && g_x6 == 3) {
