@@ -53,28 +53,42 @@ def nms(boxes, scores, iou_threshold):
 
 
 def match_predictions_to_detections(ious):
-    """Deferred-acceptance matching of predictions (rows) to ground-truth boxes (columns) by IoU preference
-    (reference utils/detection_utils.py:401-421) -> (best IoU per GT, prediction index per GT or -1)."""
+    """Which prediction (row) answers for which ground-truth box (column): a proposal game on the IoU table
+    -> (IoU of the holder per GT, holder index per GT or -1).  Pinned by fixture G15 against the reference's
+    utils/detection_utils.py:401-421, whose observable behaviour (it defines the AP metric) is:
+
+    * every prediction keeps a cursor into its own ranking of the GT boxes (best IoU first) and, each round, points at the
+      box under the cursor -- also while it is holding a box;
+    * boxes are visited in index order; a box hands itself to the pointer with the largest IoU (lowest index on ties).  A
+      box nobody points at with a positive IoU falls to prediction 0 -- the arg-max of an all-zero column -- and that
+      still counts as "prediction 0 is taken";
+    * a prediction displaced from a box becomes loose again, loose predictions move their cursor on after the round, and
+      the game stops after one round per box or once min(#predictions, #boxes) predictions are taken;
+    * holders with IoU 0 are reported as "no match" (-1).
+    The bookkeeping runs on host lists (the reference loops over tensors element by element)."""
     n_p, n_g = ious.shape
-    prefs = torch.argsort(ious, dim=1, descending=True)
-    pref_idx = torch.zeros((n_p,), dtype=torch.long, device=ious.device)
-    free = torch.ones((n_p,), device=ious.device).bool()
-    tentative = -torch.ones(n_g, dtype=torch.long, device=ious.device)
+    table = ious.tolist()
+    ranking = torch.argsort(ious, dim=1, descending=True).tolist()   # (tie order inside a row: torch's, as in the reference)
+    cursor, taken, holder = [0] * n_p, [False] * n_p, [-1] * n_g
     for _ in range(n_g):
-        proposals = prefs[torch.arange(0, n_p), pref_idx]
+        pointed = [ranking[p][cursor[p]] for p in range(n_p)]
         for j in range(n_g):
-            new_match = torch.argmax(ious[:, j] * (proposals == j))
-            if tentative[j] != -1 and tentative[j] != new_match:
-                free[tentative[j]] = True
-            tentative[j] = new_match
-            free[tentative[j]] = False
-        pref_idx[free] += 1
-        if torch.count_nonzero(~free) >= min(n_p, n_g):
+            winner, top = 0, 0.0
+            for p in range(n_p):
+                if pointed[p] == j and table[p][j] > top:
+                    winner, top = p, table[p][j]
+            if holder[j] not in (-1, winner):
+                taken[holder[j]] = False
+            holder[j] = winner
+            taken[winner] = True
+        for p in range(n_p):
+            if not taken[p]:
+                cursor[p] += 1
+        if sum(taken) >= min(n_p, n_g):
             break
-    best_idx = tentative
-    best_iou = torch.zeros(best_idx.shape[0], device=ious.device)
-    best_iou[best_idx != -1] = ious[best_idx[best_idx != -1], best_idx != -1]
-    best_idx[best_iou == 0.0] = -1
+    held = [table[h][j] if h != -1 else 0.0 for j, h in enumerate(holder)]
+    best_iou = torch.tensor(held, dtype=torch.float32, device=ious.device).reshape(n_g)
+    best_idx = torch.tensor([h if v != 0.0 else -1 for h, v in zip(holder, held)], dtype=torch.long, device=ious.device).reshape(n_g)
     return best_iou, best_idx
 
 
