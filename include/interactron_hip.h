@@ -42,12 +42,17 @@ int ix_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
                 int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride_outer, float alpha,
                 int tile_hint, int split_k_hint, ix_stream_t stream);
 
-/* ix_gemm_f32_ws: the same contraction with caller-provided scratch memory.  With `workspace` (device, at least
- * ix_workspace_bytes_gemm_f32(...) bytes; that function returns 0 for calls that do not need any) eligible contractions run
- * on the pre-split fp16x3 kernel (csrc/gemm_x3.hip): each operand is converted ONCE into two fp16 planes with a power-of-two
- * scale per block of 32 rows (taken over the whole contracted extent), the GEMM kernel streams those planes and issues three
- * v_mfma_f32_32x32x16_f16 terms per 16 contracted elements -- fp32-grade accuracy at half the matrix instructions of the
- * bf16x6 kernel and without its per-tile conversion work.  Without a workspace the call is ix_gemm_f32. */
+/* ix_gemm_f32_ws: the same contraction with caller-provided scratch memory (the section-8b workspace convention).
+ * `workspace`: device memory, 16-byte aligned, at least ix_workspace_bytes_gemm_f32(...) bytes (0 for calls that need none).
+ * What it is used for:
+ *   - split-K (skinny outputs with a long contracted extent; the plan is a pure function of the shapes): every split writes
+ *     its partial sums into its own plane of the workspace with plain stores and one reduction launch adds the planes IN
+ *     ORDER into C -- two runs give the same bits.  ix_gemm_f32 (no workspace) keeps the older scheme, fp32 atomics onto a
+ *     zero-filled C, whose rounding depends on arrival order; the Python package always passes a workspace.
+ *   - after ix_gemm_presplit_enable(1) (opt-in, off by default): eligible contractions run on the pre-split fp16x3 kernel
+ *     (csrc/gemm_x3.hip): each operand is converted ONCE into two fp16 planes with a power-of-two scale per block of 32 rows,
+ *     three v_mfma_f32_32x32x16_f16 terms per 16 contracted elements.
+ * The workspace may be reused by the next call on the same stream. */
 int ix_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int a_kcontig,
                    int b_kcontig, int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo,
                    int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride_outer, float alpha,
@@ -55,6 +60,7 @@ int ix_gemm_f32_ws(const float* A, const float* B, float* C, const float* bias, 
 int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda, int64_t ldb, int batch_outer,
                                 int batch_inner, int64_t sAo, int64_t sBo, const float* A, const float* B, int tile_hint,
                                 int split_k_hint, size_t* out_host);
+int ix_gemm_presplit_enable(int on);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls); /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
 
 /* ix_gemm_rowsum_f32: C = alpha A B and, from the same launch, rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  With A
@@ -64,7 +70,9 @@ int ix_prof_x3(double* ms, double* flops, int64_t* calls); /* profiled ix_gemm_f
  * kernel does not take fall back to ix_gemm_f32 + ix_colsum_f32 inside the call (A must then be contiguous). */
 int ix_gemm_rowsum_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
                        int64_t ldb, int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, float alpha,
-                       float* rowsum, int64_t rowsum_stride, ix_stream_t stream);
+                       float* rowsum, int64_t rowsum_stride, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+/* (workspace: as ix_gemm_f32_ws, sized by ix_workspace_bytes_gemm_f32 of the same contraction; split-K partial row sums go
+ *  through it as well) */
 
 /* Test hook like ix_gemm_set_mode: 1 = 128-wide tiles of eligible contractions run the fp16x3 form of the 12-wave kernel
  * (two fp16 planes + one exponent per 32 x 32 sub-block found by the producer waves, three v_mfma_f32_32x32x16_f16 per
@@ -103,7 +111,11 @@ int ix_gemm_prof_dump(const char* path_host); /* per-launch CSV (shape, tile, sp
 int ix_conv_gemm_supported(int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
                            int pad, int dil);
 int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W, int Cin,
-                     int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, ix_stream_t stream);
+                     int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, void* workspace,
+                     size_t workspace_bytes, ix_stream_t stream);
+/* split-K planes of one convolution kind (deterministic ordered reduction, as ix_gemm_f32_ws; workspace NULL = atomics) */
+int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
+                                     int KW, size_t* out_host);
 
 int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,
                   int64_t sxc, int KH, int KW, int stride, int pad, int dil, int Kp, ix_stream_t stream);
@@ -147,8 +159,17 @@ int ix_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed
 /* grouped forms: a/out [groups, rows, C], v [groups, C] (groups = episodes processed together; 1 = plain) */
 int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
 int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
-int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
-int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
+/* Reductions that span several workgroups (column sums, dot, LayerNorm parameter gradients, weighted-CE sums, the clip norm)
+ * take the section-8b workspace: [IX_TICKET_BYTES = 65536 bytes of tickets, ZERO on first use and left zero by every call]
+ * [partials].  Each workgroup stores one partial, the last one to arrive adds them in index order: one launch, no zero-fill,
+ * and the same bits on every run (they replaced fp32 atomics, whose rounding depended on arrival order -- autograd's bias /
+ * LayerNorm gradients, reference transformer.py / gpt.py under torch.autograd).  Pass the same zero-initialised buffer to
+ * every call of a stream; ix_colsum_f32 alone accepts NULL (atomics onto a zero-filled output). */
+int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                  ix_stream_t stream);
+int ix_workspace_bytes_colsum_f32(int64_t rows, int C, int groups, size_t* out_host);
+int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, void* workspace, size_t workspace_bytes,
+               ix_stream_t stream); /* workspace: IX_TICKET_BYTES + 1024 bytes */
 
 /* ---- wavefront-reduction kernels: softmax (transformer.py MHA, gpt.py:50) and LayerNorm ---------------------
  * LayerNorm: x [groups, rows, D]; gamma/beta (and dgamma/dbeta/grad_gamma, Gg/Gb) [groups, D]; groups = 1 is the plain
@@ -173,10 +194,14 @@ int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const float* y, c
 int ix_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                          int64_t rows, int D, float eps, int groups, ix_stream_t stream);
 int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                         float* dx, float* dgamma, float* dbeta, int64_t rows, int D, int groups, ix_stream_t stream);
+                         float* dx, float* dgamma, float* dbeta, int64_t rows, int D, int groups, void* workspace,
+                         size_t workspace_bytes, ix_stream_t stream);
 int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy, const float* x,
                              const float* gamma, const float* mean, const float* rstd, float* grad_dy, float* grad_x,
-                             float* grad_gamma, int64_t rows, int D, int groups, ix_stream_t stream);
+                             float* grad_gamma, int64_t rows, int D, int groups, void* workspace, size_t workspace_bytes,
+                             ix_stream_t stream);
+/* scratch of both (ticket layout, see ix_colsum_f32); rows = rows per group */
+int ix_workspace_bytes_layernorm_bwd(int64_t rows, int D, int groups, size_t* out_host);
 
 /* ---- flash-style attention (no [L, S] tensor in HBM) ------------------------------------------------------------
  * O = dropout(softmax(scale Q K^T + key bias)) V per (batch, head), and its first and second derivative, in fp32-grade
@@ -257,7 +282,9 @@ int ix_match_cost_f32(const float* logits, const float* boxes, const int64_t* tg
                       ix_stream_t stream);
 int ix_lsap_f32(const float* cost_host, int64_t nr, int64_t nc, int64_t* row_idx_host, int64_t* col_idx_host);
 int ix_weighted_ce_fwd_f32(const float* logits, const int64_t* target, const float* weight, float* lse,
-                           int64_t* argmax, float* sums, int rows, int C, ix_stream_t stream);
+                           int64_t* argmax, float* sums, int rows, int C, void* workspace, size_t workspace_bytes,
+                           ix_stream_t stream);
+int ix_workspace_bytes_weighted_ce(int rows, size_t* out_host); /* ticket layout, see ix_colsum_f32 */
 int ix_weighted_ce_bwd_f32(const float* logits, const int64_t* target, const float* weight, const float* lse,
                            const float* sums, const float* gout, float* dlogits, int rows, int C, ix_stream_t stream);
 int ix_box_loss_fwd_f32(const float* pred, const int64_t* src_idx, const float* tgt, float* out, int K,
@@ -281,7 +308,8 @@ int ix_sgd_clip_multi_f32(const float* const* p, const float* const* g, float* c
                           int ntensors, float lr, float clip, ix_stream_t stream);
 int ix_sgd_clip_bwd_multi_f32(const float* const* G, const float* const* g, float* const* out, const int64_t* sizes,
                               int ntensors, float lr, float clip, ix_stream_t stream);
-int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, ix_stream_t stream);
+int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                       ix_stream_t stream); /* workspace: IX_TICKET_BYTES + 4096 bytes (ticket layout, see ix_colsum_f32) */
 int ix_adam_step_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      int step, const float* sumsq, float max_norm, int zero_grad, ix_stream_t stream);
 

@@ -44,7 +44,31 @@ static inline int ix_grid_1d(int64_t work_items, int block) {
     return (int)g;
 }
 
+// ---- ordered multi-block reductions ---------------------------------------------------------------------------------
+// Column / scalar reductions that span several workgroups write one partial per workgroup into caller scratch; the LAST
+// workgroup to arrive (a ticket counter, CUDA's threadFenceReduction pattern) adds the partials in index order.  One
+// launch, no zero-fill, and the same bits on every run (the fp32 atomics this replaces rounded in arrival order).
+// Workspace layout: [IX_TICKET_BYTES of tickets, zero on entry, left zero][partials ...].
+#define IX_TICKET_BYTES 65536
+#define IX_MAX_TICKETS (IX_TICKET_BYTES / 4)
+static inline bool ix_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 #ifdef __HIPCC__
+// call after this workgroup's partial stores; true in exactly one workgroup per ticket, after all `nblk` have arrived
+__device__ __forceinline__ bool ix_last_block(unsigned int* ticket, unsigned int nblk) {
+    __shared__ int ix_last_flag;
+    __threadfence();   // this thread's partial stores are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(ticket, 1u);
+        ix_last_flag = (t == nblk - 1);
+        if (ix_last_flag) atomicExch(ticket, 0u);   // ready for the next launch (stream-ordered)
+    }
+    __syncthreads();
+    const bool last = ix_last_flag != 0;
+    if (last) __threadfence();   // acquire: the other workgroups' partials
+    return last;
+}
 __device__ __forceinline__ float ix_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -75,52 +75,92 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
                                                       const int64_t* __restrict__ target,
                                                       const float* __restrict__ weight, float* __restrict__ lse,
                                                       int64_t* __restrict__ argmax, float* __restrict__ sums, int rows,
-                                                      int C) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* lr = logits + (int64_t)row * C;
-    float mx = -INFINITY;
-    int am = 0;
-    for (int c = lane; c < C; c += 64) {
-        const float v = lr[c];
-        if (v > mx) {
-            mx = v;
-            am = c;
+                                                      int C, float* __restrict__ part, unsigned int* tickets) {
+    __shared__ float sw[4][2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    float wnll = 0.f, wt = 0.f;
+    if (row < rows) {
+        const float* lr = logits + (int64_t)row * C;
+        float mx = -INFINITY;
+        int am = 0;
+        for (int c = lane; c < C; c += 64) {
+            const float v = lr[c];
+            if (v > mx) {
+                mx = v;
+                am = c;
+            }
         }
-    }
-    // wave arg-max, ties to the lowest index (torch.argmax semantics on CPU)
+        // wave arg-max, ties to the lowest index (torch.argmax semantics on CPU)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(mx, o, 64);
-        const int oi = __shfl_xor(am, o, 64);
-        if (ov > mx || (ov == mx && oi < am)) {
-            mx = ov;
-            am = oi;
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(mx, o, 64);
+            const int oi = __shfl_xor(am, o, 64);
+            if (ov > mx || (ov == mx && oi < am)) {
+                mx = ov;
+                am = oi;
+            }
+        }
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += __expf(lr[c] - mx);
+        s = ix_wave_sum(s);
+        if (lane == 0) {
+            const float l = mx + __logf(s);
+            const int64_t t = target[row];
+            const float w = weight[t];
+            lse[row] = l;
+            argmax[row] = am;
+            wnll = w * (l - lr[t]);
+            wt = w;
         }
     }
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += __expf(lr[c] - mx);
-    s = ix_wave_sum(s);
     if (lane == 0) {
-        const float l = mx + __logf(s);
-        const int64_t t = target[row];
-        const float w = weight[t];
-        lse[row] = l;
-        argmax[row] = am;
-        unsafeAtomicAdd(&sums[0], w * (l - lr[t]));
-        unsafeAtomicAdd(&sums[1], w);
+        sw[wv][0] = wnll;
+        sw[wv][1] = wt;
+    }
+    __syncthreads();
+    // ordered sums: rows of a workgroup in row order, workgroups in index order by the last one to arrive
+    if (gridDim.x == 1) {
+        if (threadIdx.x < 2) sums[threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
+        return;
+    }
+    if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
+    if (!ix_last_block(tickets, gridDim.x)) return;
+    if (threadIdx.x < 2) {
+        float t = 0.f;
+        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(part + b * 2 + threadIdx.x);
+        sums[threadIdx.x] = t;
     }
 }
 
+extern "C" int ix_workspace_bytes_weighted_ce(int rows, size_t* out) {
+    IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_weighted_ce: null out");
+    *out = rows > 4 ? IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)ix_div_up(rows, 4) : 0;
+    return IX_OK;
+}
+
+__global__ void wce_zero2_kernel(float* sums) {
+    if (threadIdx.x < 2) sums[threadIdx.x] = 0.f;
+}
+
+// workspace (ix_workspace_bytes_weighted_ce; tickets zero on entry, left zero): the two sums are added in row order -- the
+// same bits on every run
 extern "C" int ix_weighted_ce_fwd_f32(const float* logits, const int64_t* target, const float* weight, float* lse,
-                                      int64_t* argmax, float* sums, int rows, int C, hipStream_t stream) {
+                                      int64_t* argmax, float* sums, int rows, int C, void* workspace, size_t workspace_bytes,
+                                      hipStream_t stream) {
     IX_CHECK_ARG(sums, "ix_weighted_ce_fwd_f32: null sums");
-    hipMemsetAsync(sums, 0, 2 * sizeof(float), stream);
-    if (rows <= 0) return IX_OK;
+    if (rows <= 0) {
+        hipLaunchKernelGGL(wce_zero2_kernel, dim3(1), dim3(64), 0, stream, sums);
+        return IX_OK;
+    }
     IX_CHECK_ARG(logits && target && weight && lse && argmax && C > 0, "ix_weighted_ce_fwd_f32: bad args");
-    hipLaunchKernelGGL(wce_fwd_kernel, dim3(ix_div_up(rows, 4)), dim3(256), 0, stream, logits, target, weight, lse,
-                       argmax, sums, rows, C);
+    const int g = ix_div_up(rows, 4);
+    if (g > 1)
+        IX_CHECK_ARG(workspace && workspace_bytes >= IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)g && ix_al16(workspace),
+                     "ix_weighted_ce_fwd_f32: workspace of %zu bytes needed", IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)g);
+    hipLaunchKernelGGL(wce_fwd_kernel, dim3(g), dim3(256), 0, stream, logits, target, weight, lse, argmax, sums, rows, C,
+                       g > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + IX_TICKET_BYTES) : nullptr,
+                       static_cast<unsigned int*>(workspace));
     IX_CHECK_LAUNCH("ix_weighted_ce_fwd_f32");
     return IX_OK;
 }
@@ -259,10 +299,15 @@ __global__ void box_loss_bwd_kernel(const float* __restrict__ pred, const int64_
     }
 }
 
+__global__ void box_zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) p[k] = 0.f;
+}
+
 extern "C" int ix_box_loss_bwd_f32(const float* pred, const int64_t* src_idx, const float* tgt, const float* gout,
                                    float* dpred, int R, int K, hipStream_t stream) {
     IX_CHECK_ARG(dpred && gout, "ix_box_loss_bwd_f32: null pointer");
-    hipMemsetAsync(dpred, 0, sizeof(float) * 4 * (size_t)R, stream);
+    hipLaunchKernelGGL(box_zero_kernel, dim3(ix_grid_1d((int64_t)4 * R, 256)), dim3(256), 0, stream, dpred, (int64_t)4 * R);
     if (K <= 0) return IX_OK;
     IX_CHECK_ARG(pred && src_idx && tgt, "ix_box_loss_bwd_f32: null pointer");
     hipLaunchKernelGGL(box_loss_bwd_kernel, dim3(1), dim3(256), 0, stream, pred, src_idx, tgt, gout, dpred, K);

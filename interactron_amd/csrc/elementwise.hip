@@ -278,31 +278,51 @@ extern "C" int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C
     return IX_OK;
 }
 
-// Each block owns a band of rows and a 256-wide band of columns; lanes walk down rows (coalesced across columns),
-// then one atomic per column per block.
+// Each block owns a band of rows and a 256-wide band of columns; lanes walk down rows (coalesced across columns).  With
+// several row bands the band sums go to `part[group][band][c]` and the last band to finish adds them in band order
+// (ix_last_block); part == nullptr: one atomic per column per block onto a zero-filled out (legacy, order-dependent).
+__device__ __forceinline__ void colsum_finish(float* __restrict__ out, float* __restrict__ part, unsigned int* tickets, int C,
+                                              int c0, int ncols) {
+    // this block's partial for columns [c0, c0 + ncols) is already stored in part[(z * gridDim.y + y) * C + c]
+    if (!ix_last_block(tickets + blockIdx.z * gridDim.x + blockIdx.x, gridDim.y)) return;
+    const float* base = part + (int64_t)blockIdx.z * gridDim.y * C;
+    for (int c = c0 + threadIdx.x; c < c0 + ncols && c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (unsigned int y = 0; y < gridDim.y; ++y) s += __builtin_nontemporal_load(base + (int64_t)y * C + c);
+        out[(int64_t)blockIdx.z * C + c] = s;
+    }
+}
+
 __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C,
-                              int rows_per_block) {
+                              int rows_per_block, float* __restrict__ part, unsigned int* tickets) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    x += (int64_t)blockIdx.z * rows * C;   // blockIdx.z = group
-    out += (int64_t)blockIdx.z * C;
+    const float* xg = x + (int64_t)blockIdx.z * rows * C;   // blockIdx.z = group
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * C + c];
-    unsafeAtomicAdd(&out[c], s);
+    if (c < C)
+        for (int64_t r = r0; r < r1; ++r) s += xg[r * C + c];
+    if (gridDim.y == 1) {
+        if (c < C) out[(int64_t)blockIdx.z * C + c] = s;
+        return;
+    }
+    if (!part) {
+        if (c < C) unsafeAtomicAdd(&out[(int64_t)blockIdx.z * C + c], s);
+        return;
+    }
+    if (c < C) part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c] = s;
+    colsum_finish(out, part, tickets, C, blockIdx.x * blockDim.x, blockDim.x);
 }
 
 // 16-byte form (C % 4 == 0, aligned rows): a thread owns 4 adjacent columns, the block's 4 waves take rows r, r+1, r+2,
-// r+3 of the band with two independent accumulator sets (8 row loads in flight per thread), LDS-reduced to one atomic
-// per column per block.
+// r+3 of the band with two independent accumulator sets (8 row loads in flight per thread), LDS-reduced per block.
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows,
-                                                         int C, int rows_per_block) {
+                                                         int C, int rows_per_block, float* __restrict__ part,
+                                                         unsigned int* tickets) {
     __shared__ float4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4;
     x += (int64_t)blockIdx.z * rows * C;
-    out += (int64_t)blockIdx.z * C;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
@@ -321,52 +341,117 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     }
     red[wave][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (wave == 0 && c < C) {
         const float4 a = red[0][lane], b = red[1][lane], d = red[2][lane], e = red[3][lane];
-        unsafeAtomicAdd(&out[c + 0], (a.x + b.x) + (d.x + e.x));
-        unsafeAtomicAdd(&out[c + 1], (a.y + b.y) + (d.y + e.y));
-        unsafeAtomicAdd(&out[c + 2], (a.z + b.z) + (d.z + e.z));
-        unsafeAtomicAdd(&out[c + 3], (a.w + b.w) + (d.w + e.w));
+        t = make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
     }
+    float* og = out + (int64_t)blockIdx.z * C;
+    if (gridDim.y == 1) {
+        if (wave == 0 && c < C) *reinterpret_cast<float4*>(og + c) = t;
+        return;
+    }
+    if (!part) {
+        if (wave == 0 && c < C) {
+            unsafeAtomicAdd(&og[c + 0], t.x);
+            unsafeAtomicAdd(&og[c + 1], t.y);
+            unsafeAtomicAdd(&og[c + 2], t.z);
+            unsafeAtomicAdd(&og[c + 3], t.w);
+        }
+        return;
+    }
+    if (wave == 0 && c < C) *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) = t;
+    colsum_finish(out, part, tickets, C, blockIdx.x * 256, 256);
 }
 
-// out[g, c] = sum_r x[g, r, c]
-extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, hipStream_t stream) {
+__global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) p[k] = 0.f;
+}
+
+static int colsum_bands(int64_t rows, int* rpb_out) {
+    // few rows: one band (single pass, nothing to combine); else bands of >= 64 rows, at most 2048 of them
+    int rpb = rows <= 256 ? 256 : 64;
+    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
+    *rpb_out = rpb;
+    return (int)((rows + rpb - 1) / rpb);
+}
+
+extern "C" int ix_workspace_bytes_colsum_f32(int64_t rows, int C, int groups, size_t* out) {
+    IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_colsum_f32: null out");
+    int rpb;
+    const int nby = rows > 0 ? colsum_bands(rows, &rpb) : 1;
+    *out = nby > 1 ? IX_TICKET_BYTES + sizeof(float) * (size_t)nby * (size_t)C * (size_t)(groups > 0 ? groups : 1) : 0;
+    return IX_OK;
+}
+
+// out[g, c] = sum_r x[g, r, c].  workspace (ix_workspace_bytes_colsum_f32; first IX_TICKET_BYTES zero on entry, left zero):
+// ordered, run-to-run identical sums in ONE launch; NULL: atomics onto a zero-filled out.
+extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
     IX_CHECK_ARG(out && C >= 0 && groups >= 0 && groups <= 65535, "ix_colsum_f32: bad args");
     if (C == 0 || groups == 0) return IX_OK;
-    hipMemsetAsync(out, 0, sizeof(float) * C * groups, stream);
-    if (rows <= 0) return IX_OK;
+    if (rows <= 0) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(ix_grid_1d((int64_t)C * groups, 256)), dim3(256), 0, stream, out, (int64_t)C * groups);
+        return IX_OK;
+    }
     IX_CHECK_ARG(x, "ix_colsum_f32: null input");
-    int rpb = 64;
-    while ((rows + rpb - 1) / rpb > 2048) rpb *= 2;
-    dim3 grid(ix_div_up(C, 256), (unsigned)((rows + rpb - 1) / rpb), groups);
-    if ((C & 3) == 0 && al16(x))
-        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
+    int rpb;
+    const int nby = colsum_bands(rows, &rpb);
+    dim3 grid(ix_div_up(C, 256), (unsigned)nby, groups);
+    float* part = nullptr;
+    unsigned int* tickets = nullptr;
+    if (nby > 1 && workspace) {
+        const size_t need = IX_TICKET_BYTES + sizeof(float) * (size_t)nby * (size_t)C * (size_t)groups;
+        if (workspace_bytes < need || !ix_al16(workspace) || (int64_t)grid.x * groups > IX_MAX_TICKETS) {
+            ix_set_error("ix_colsum_f32: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
+            return IX_ERR_WORKSPACE;
+        }
+        tickets = static_cast<unsigned int*>(workspace);
+        part = reinterpret_cast<float*>(static_cast<char*>(workspace) + IX_TICKET_BYTES);
+    } else if (nby > 1) {
+        hipLaunchKernelGGL(zero_f32_kernel, dim3(ix_grid_1d((int64_t)C * groups, 256)), dim3(256), 0, stream, out, (int64_t)C * groups);
+    }
+    if ((C & 3) == 0 && al16(x) && al16(out))
+        hipLaunchKernelGGL(colsum_vec_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb, part, tickets);
     else
-        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, x, out, rows, C, rpb, part, tickets);
     IX_CHECK_LAUNCH("ix_colsum_f32");
     return IX_OK;
 }
 
+// block partials -> part[block]; the last block adds them in order (ix_last_block).  tickets[0] is this launch's counter.
 __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                           int64_t n) {
+                           int64_t n, float* __restrict__ part, unsigned int* tickets) {
     __shared__ float red[4];
     float s = 0.f;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) s += a[k] * b[k];
     s = ix_block_sum_256(s, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) *out = s;
+        return;
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (!ix_last_block(tickets, gridDim.x)) return;
+    float t = 0.f;
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(part + i);   // (gridDim.x <= 256)
+    t = ix_block_sum_256(t, red);
+    if (threadIdx.x == 0) *out = t;
 }
 
-// out[0] = sum_i a[i]*b[i]
-extern "C" int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, hipStream_t stream) {
+// out[0] = sum_i a[i]*b[i].  workspace: IX_TICKET_BYTES (zero on entry, left zero) + 1 KiB of partials; required once the
+// vectors are long enough for several workgroups (n > 4096).
+extern "C" int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
     IX_CHECK_ARG(out, "ix_dot_f32: null output");
-    hipMemsetAsync(out, 0, sizeof(float), stream);
-    if (n <= 0) return IX_OK;
-    IX_CHECK_ARG(a && b, "ix_dot_f32: null input");
-    int g = ix_grid_1d(n, 256);
+    IX_CHECK_ARG(n <= 0 || (a && b), "ix_dot_f32: null input");
+    int g = n > 4096 ? ix_grid_1d(n, 1024) : 1;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, stream, a, b, out, n);
+    if (g > 1) IX_CHECK_ARG(workspace && workspace_bytes >= IX_TICKET_BYTES + 1024 && ix_al16(workspace), "ix_dot_f32: workspace of %d bytes needed", IX_TICKET_BYTES + 1024);
+    hipLaunchKernelGGL(dot_kernel, dim3(g), dim3(256), 0, stream, a, b, out, n > 0 ? n : 0,
+                       g > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + IX_TICKET_BYTES) : nullptr,
+                       static_cast<unsigned int*>(workspace));
     IX_CHECK_LAUNCH("ix_dot_f32");
     return IX_OK;
 }

@@ -78,12 +78,15 @@ struct GemmArgs {
     int batch_inner;
     int split_k;
     int k_per_split;
+    int atomic;        // split-K partial sums: 1 = fp32 atomics onto a zero-filled C (legacy, order-dependent rounding), 0 = every
+    int64_t sSplit;    // split writes its own plane C + ks * sSplit (a workspace) and splitk_reduce_kernel sums them in order
     float alpha;
     int a_vec, b_vec, c_vec;
     int tiles_m, tiles_n;
     struct ConvGather cg;   // implicit-GEMM convolution operands (ix_conv_gemm_f32); mode 0 for plain contractions
     float* rowsum;          // optional side output (bf16x6 kernel, A stored m-contiguous): rowsum[bo][m] = sum_k A(m, k)
     int64_t sRowsum;
+    int64_t sSplitRowsum;   // plane stride of the per-split partial row sums (0 with atomics)
 };
 
 // XCD-aware, bijective remap: consecutive logical tiles land on the same XCD (same L2).
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
     const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
     const float* A = p.A + bo * p.sAo + bi * p.sAi;
     const float* B = p.B + bo * p.sBo + bi * p.sBi;
-    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    float* C = p.C + bo * p.sCo + bi * p.sCi + ks * p.sSplit;
     const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
     const int kbeg = ks * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_kernel(GemmArgs p) {
                 if (row < p.M) {
                     const float v = p.alpha * acc[i][j][r] + bv;
                     float* dst = C + (int64_t)row * p.ldc + col;
-                    if (p.split_k > 1)
+                    if (p.atomic)
                         unsafeAtomicAdd(dst, v);
                     else
                         *dst = v;
@@ -717,14 +720,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
         // nothing may still be in flight when this wave ends (its registers go to another wave; the compiler does not
         // know about the inline-asm loads)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.split_k > 1 || !p.c_vec) return;   // (consumers store straight from registers in those cases)
+        if (p.atomic || !p.c_vec) return;   // (consumers store straight from registers in those cases)
         __syncthreads();                          // C tile staged in LDS by the consumers: help writing it out
-        x6_store_tile<BN>(reinterpret_cast<const float*>(&lds[0][0]), p.C + bo * p.sCo + bi * p.sCi, p.ldc, m0, n0, p.M, p.N, tid);
+        x6_store_tile<BN>(reinterpret_cast<const float*>(&lds[0][0]), p.C + bo * p.sCo + bi * p.sCi + ks * p.sSplit, p.ldc, m0, n0, p.M, p.N, tid);
         return;
     }
 
     // ---------------------------------------------------- consumers ----------------------------------------------------
-    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    float* C = p.C + bo * p.sCo + bi * p.sCi + ks * p.sSplit;
     const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
 #undef X6_MMA
 
     const bool add_bias = bias != nullptr && ks == 0;
-    if (p.split_k == 1 && p.c_vec) {
+    if (!p.atomic && p.c_vec) {
         // Epilogue through LDS: the MFMA C layout gives every lane 16 scattered dwords per accumulator (one 4-byte store
         // each, store-issue bound); staged as a row-major tile the whole workgroup (producers included) writes it out
         // as 16-byte stores, 512 contiguous bytes per row.  The operand buffers are dead after the last K-step barrier.
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_kernel(GemmArgs p) {
                 if (row < p.M) {
                     const float v = p.alpha * acc[i][j][r] + bv;
                     float* dst = C + (int64_t)row * p.ldc + col;
-                    if (p.split_k > 1)
+                    if (p.atomic)
                         unsafeAtomicAdd(dst, v);
                     else
                         *dst = v;
@@ -855,9 +858,9 @@ __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
     it.A = p.A + bo * p.sAo + bi * p.sAi;
     it.B = p.B + bo * p.sBo + bi * p.sBi;
-    it.C = p.C + bo * p.sCo + bi * p.sCi;
+    it.C = p.C + bo * p.sCo + bi * p.sCi + ks * p.sSplit;
     it.bias = p.bias ? p.bias + bo * p.sBias : nullptr;
-    it.rowsum = (p.rowsum && it.n0 == 0) ? p.rowsum + bo * p.sRowsum : nullptr;
+    it.rowsum = (p.rowsum && it.n0 == 0) ? p.rowsum + bo * p.sRowsum + ks * p.sSplitRowsum : nullptr;
     it.ks = ks;
     it.kbeg = ks * p.k_per_split;
     it.kend = min(p.K, it.kbeg + p.k_per_split);
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
     const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= last) return;
-    const bool staged = p.split_k == 1 && p.c_vec;
+    const bool staged = !p.atomic && p.c_vec;
 
     if (wave >= 4) {
         // ------------------------------------------------ producers ------------------------------------------------
@@ -1148,7 +1151,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
                         if (row < p.M) {
                             const float v = p.alpha * acc[i][j][r] + bv;
                             float* dst = it.C + (int64_t)row * p.ldc + col;
-                            if (p.split_k > 1)
+                            if (p.atomic)
                                 unsafeAtomicAdd(dst, v);
                             else
                                 *dst = v;
@@ -1225,7 +1228,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         if ((pt & 7) == 0) {                                                                                \
             const int m = itS.m0 + (pt >> 3) * 4;                                                           \
             float* dst = itS.rowsum + m;                                                                    \
-            if (p.split_k > 1) {                                                                            \
+            if (p.atomic) {                                                                                 \
                 if (m + 0 < p.M) unsafeAtomicAdd(dst + 0, rsum.x);                                          \
                 if (m + 1 < p.M) unsafeAtomicAdd(dst + 1, rsum.y);                                          \
                 if (m + 2 < p.M) unsafeAtomicAdd(dst + 2, rsum.z);                                          \
@@ -1322,7 +1325,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
     const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= last) return;
-    const bool staged = p.split_k == 1 && p.c_vec;
+    const bool staged = !p.atomic && p.c_vec;
 
     if (wave >= NC + 4) {
         x6q_produce<BN, BN, B_KC, true, DEFER, GB>(p, w, stride, last, &lds[0][0], BUF, 3 * PLANE_A, tid - (NC + 4) * 64);
@@ -1531,7 +1534,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
                         if (row < p.M) {
                             const float v = p.alpha * acc[i][j][r] + bv;
                             float* dst = it.C + (int64_t)row * p.ldc + col;
-                            if (p.split_k > 1)
+                            if (p.atomic)
                                 unsafeAtomicAdd(dst, v);
                             else
                                 *dst = v;
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= last) return;
-    const bool staged = p.split_k == 1 && p.c_vec;
+    const bool staged = !p.atomic && p.c_vec;
 
     if (wave >= NC + 4) {
         x6q_produce<BN, BN, B_KC, true, false, GB, true>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
@@ -1730,7 +1733,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
                         if (row < p.M) {
                             const float v = p.alpha * __builtin_amdgcn_ldexpf(acc[i][j][r], u) + bv;
                             float* dst = it.C + (int64_t)row * p.ldc + col;
-                            if (p.split_k > 1)
+                            if (p.atomic)
                                 unsafeAtomicAdd(dst, v);
                             else
                                 *dst = v;
@@ -1894,7 +1897,9 @@ static void launch_cfg(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStre
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, false, false>), grid, dim3(256), 0, stream, a);
 }
 
-extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, hipStream_t stream);
+extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream);
+extern "C" int ix_workspace_bytes_colsum_f32(int64_t rows, int C, int groups, size_t* out);
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- launch statistics (bench.py's roofline object) ----------------------------------------------------------
@@ -2092,12 +2097,174 @@ void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops
 }
 void ix_prof_end(hipStream_t stream) { prof_mark(stream); }
 
+// ---- tile / split-K plan ------------------------------------------------------------------------------------------
+// Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
+// shared resource: a CU that receives n workgroups spends n * ksteps * step_cycles on MFMAs, while the fixed
+// prologue/epilogue latencies of its (up to two) co-resident workgroups overlap.  Split-K adds a second launch
+// and s passes over C.  This replaces "fill the chip" thresholds, which lose up to 2x to wave quantisation
+// (e.g. 540 workgroups on 512 resident slots).
+struct TilePlan {
+    int bm, split, kps;
+};
+static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int tile_hint, int split_k_hint) {
+    int bm = 64, split = 1;
+    double best = 1e300;
+    const int cand_tiles[2] = {128, 64};
+    const int cand_split[14] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
+    for (int ti = 0; ti < 2; ++ti) {
+        const int t = cand_tiles[ti];
+        if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
+        const int bk = t == 128 ? 32 : 64;
+        // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
+        const double step_cycles = t == 128 ? (want_x6 ? 1900.0 : 4096.0) : 2048.0 * 1.15;
+        const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
+        for (int si = 0; si < 14; ++si) {
+            int sp = cand_split[si];
+            if (split_k_hint > 0) sp = split_k_hint;
+            if (sp > 1 && K < 2 * bk * sp) break;
+            int kps = ix_div_up(ix_div_up(K, sp), bk) * bk;
+            if (kps < bk) kps = bk;
+            const int real_split = K > 0 ? ix_div_up(K, kps) : 1;
+            const int ksteps = ix_div_up(kps, bk);
+            const int64_t blocks = tl * real_split;
+            const int64_t per_cu = (blocks + 255) / 256;
+            double cost = (double)per_cu * ksteps * step_cycles + (double)((per_cu + 1) / 2) * 7000.0;
+            if (real_split > 1) {
+                const double cbytes = 4.0 * (double)M * (double)N * (double)nbatch;
+                cost += 6000.0 + cbytes / 2048.0 + cbytes * real_split / 1024.0;  // reduction launch + partial planes
+            }
+            if (cost < best) {
+                best = cost;
+                bm = t;
+                split = real_split;
+            }
+            if (split_k_hint > 0) break;
+        }
+    }
+    const int bk = bm == 128 ? 32 : 64;
+    int kps = ix_div_up(ix_div_up(K, split), bk) * bk;
+    if (kps < bk) kps = bk;
+    split = K > 0 ? ix_div_up(K, kps) : 1;
+    return TilePlan{bm, split, kps};
+}
+
+// bytes of the partial planes a split-K contraction writes ([split][batch][M][N] + [split][batch_outer][M] row sums)
+static size_t splitk_plane_bytes(int split, int nbatch, int batch_outer, int M, int N) {
+    if (split <= 1) return 0;
+    return ((size_t)split * (size_t)nbatch * (size_t)M * (size_t)N + (size_t)split * (size_t)batch_outer * (size_t)M) * sizeof(float);
+}
+
+// Deterministic split-K: the s-th split of a contraction writes its partial tile sums into plane s of a caller-provided
+// workspace with plain stores; this kernel adds the planes IN ORDER (s = 0, 1, ...) into C.  Two runs of one binary give the
+// same bits (the fp32 atomics this replaces rounded in arrival order).  blockIdx.y == nbatch: the partial row sums.
+__global__ void splitk_reduce_kernel(const float* __restrict__ planes, float* __restrict__ C, int M, int N, int64_t ldc,
+                                     int64_t sCo, int64_t sCi, int batch_inner, int nbatch, int split, int64_t sSplit, int vec,
+                                     const float* __restrict__ rs_planes, float* __restrict__ rowsum, int64_t rowsum_stride,
+                                     int64_t sSplitRowsum, int batch_outer) {
+    const int zb = blockIdx.y;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (zb == nbatch) {
+        const int64_t total = (int64_t)batch_outer * M;
+        for (int64_t i = t0; i < total; i += gs) {
+            float v = rs_planes[i];
+            for (int s = 1; s < split; ++s) v += rs_planes[s * sSplitRowsum + i];
+            rowsum[(i / M) * rowsum_stride + (i % M)] = v;
+        }
+        return;
+    }
+    const float* src = planes + (int64_t)zb * M * N;
+    float* c = C + (zb / batch_inner) * sCo + (zb % batch_inner) * sCi;
+    if (vec) {
+        const int N4 = N >> 2;
+        const int64_t total = (int64_t)M * N4;
+        for (int64_t i = t0; i < total; i += gs) {
+            float4 v = reinterpret_cast<const float4*>(src)[i];
+            for (int s = 1; s < split; ++s) {
+                const float4 u = reinterpret_cast<const float4*>(src + s * sSplit)[i];
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            }
+            *reinterpret_cast<float4*>(c + (i / N4) * ldc + (i % N4) * 4) = v;
+        }
+    } else {
+        const int64_t total = (int64_t)M * N;
+        for (int64_t i = t0; i < total; i += gs) {
+            float v = src[i];
+            for (int s = 1; s < split; ++s) v += src[s * sSplit + i];
+            c[(i / N) * ldc + (i % N)] = v;
+        }
+    }
+}
+
+// Points a planned contraction at its split-K planes (workspace given) or falls back to atomics on a zero-filled C.
+// Returns IX_OK / IX_ERR_WORKSPACE.  `real` keeps what splitk_finish needs.
+struct SplitReal {
+    float* C;
+    int64_t ldc, sCo, sCi;
+    int c_vec;
+    float* rowsum;
+    int64_t rowsum_stride;
+    bool planes;
+};
+static int splitk_begin(GemmArgs& a, int nbatch, int batch_outer, bool rowsum_in_kernel, void* workspace, size_t workspace_bytes,
+                        SplitReal& real, const char* who, hipStream_t stream) {
+    real.planes = false;
+    a.atomic = 0;
+    a.sSplit = 0;
+    a.sSplitRowsum = 0;
+    if (a.split_k <= 1) return IX_OK;
+    if (!workspace) {   // legacy: fp32 atomics onto a zero-filled C (order-dependent rounding)
+        a.atomic = 1;
+        dim3 zg(ix_grid_1d((int64_t)a.M * a.N, 256), nbatch);
+        hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, a.C, a.M, a.N, a.ldc, a.sCo, a.sCi, a.batch_inner);
+        if (rowsum_in_kernel) {
+            dim3 rg(ix_grid_1d((int64_t)a.M, 256), batch_outer);
+            hipLaunchKernelGGL(zero_strided_kernel, rg, dim3(256), 0, stream, a.rowsum, 1, a.M, (int64_t)a.M, a.sRowsum, (int64_t)0, 1);
+        }
+        return IX_OK;
+    }
+    const size_t need = splitk_plane_bytes(a.split_k, nbatch, batch_outer, a.M, a.N);
+    if (workspace_bytes < need || !aligned16(workspace)) {
+        ix_set_error("%s: split-K workspace of %zu bytes (16-byte aligned) needed, %zu given", who, need, workspace_bytes);
+        return IX_ERR_WORKSPACE;
+    }
+    real.planes = true;
+    real.C = a.C; real.ldc = a.ldc; real.sCo = a.sCo; real.sCi = a.sCi; real.c_vec = a.c_vec;
+    real.rowsum = a.rowsum; real.rowsum_stride = a.sRowsum;
+    const int64_t mn = (int64_t)a.M * a.N;
+    a.C = static_cast<float*>(workspace);
+    a.ldc = a.N;
+    a.sCo = (int64_t)a.batch_inner * mn;
+    a.sCi = mn;
+    a.sSplit = (int64_t)nbatch * mn;
+    a.c_vec = (a.N % 4 == 0) ? 1 : 0;
+    if (rowsum_in_kernel) {
+        a.rowsum = a.C + (int64_t)a.split_k * a.sSplit;
+        a.sRowsum = a.M;
+        a.sSplitRowsum = (int64_t)batch_outer * a.M;
+    }
+    return IX_OK;
+}
+static void splitk_finish(const GemmArgs& a, int nbatch, int batch_outer, bool rowsum_in_kernel, const SplitReal& real,
+                          hipStream_t stream) {
+    if (!real.planes) return;
+    const int vec = (a.N % 4 == 0) && real.c_vec;
+    dim3 grid(ix_grid_1d((int64_t)a.M * a.N / (vec ? 4 : 1), 256), nbatch + (rowsum_in_kernel ? 1 : 0));
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, stream, a.C, real.C, a.M, a.N, real.ldc, real.sCo, real.sCi,
+                       a.batch_inner, nbatch, a.split_k, a.sSplit, vec, rowsum_in_kernel ? a.rowsum : nullptr, real.rowsum,
+                       real.rowsum_stride, a.sSplitRowsum, batch_outer);
+}
+
 // Which contractions ix_gemm_f32_ws can run on the pre-split fp16x3 kernel (gemm_x3.hip): 16-byte-aligned operands, one
 // batch level, no tile or split hint, enough work that two conversion launches pay (>= 0.25 GFLOP), K and N large enough
 // for its 128 x {128, 64} tiles.  The caller opts in per call by passing a workspace (hipops: IX_GEMM_X3=1).
+static int g_presplit = 0;   // ix_gemm_presplit_enable: route eligible ix_gemm_f32_ws calls to the pre-split fp16x3 kernel (opt-in)
+extern "C" int ix_gemm_presplit_enable(int on) {
+    g_presplit = on ? 1 : 0;
+    return IX_OK;
+}
 static bool x3_eligible(int M, int N, int K, int batch_outer, int batch_inner, int64_t lda, int64_t ldb, int64_t sAo,
                         int64_t sBo, const float* A, const float* B, int tile_hint, int split_k_hint) {
-    if (g_x6 == 0 || tile_hint != 0 || split_k_hint != 0 || batch_inner != 1) return false;
+    if (!g_presplit || g_x6 == 0 || tile_hint != 0 || split_k_hint != 0 || batch_inner != 1) return false;
     if (K < 64 || N < 48 || M < 64) return false;
     if ((lda % 4) || (ldb % 4) || (sAo % 4) || (sBo % 4) || !aligned16(A) || !aligned16(B)) return false;
     return 2.0 * (double)M * (double)N * (double)K * (double)batch_outer >= 0.25e9;
@@ -2108,8 +2275,28 @@ extern "C" int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, i
                                            const float* B, int tile_hint, int split_k_hint, size_t* out) {
     IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_gemm_f32: null out");
     (void)a_kcontig; (void)b_kcontig;
-    *out = x3_eligible(M, N, K, batch_outer, batch_inner, lda, ldb, sAo, sBo, A, B, tile_hint, split_k_hint)
-               ? ix_x3_workspace_bytes(M, N, K, sAo ? batch_outer : 1, sBo ? batch_outer : 1) : 0;
+    if (x3_eligible(M, N, K, batch_outer, batch_inner, lda, ldb, sAo, sBo, A, B, tile_hint, split_k_hint)) {
+        *out = IX_TICKET_BYTES + ix_x3_workspace_bytes(M, N, K, sAo ? batch_outer : 1, sBo ? batch_outer : 1);
+        return IX_OK;
+    }
+    // split-K planes (+ partial row sums): an upper bound over the two kernel families the call may be planned for
+    const int nbatch = batch_outer * batch_inner;
+    size_t need = 0;
+    if (M > 0 && N > 0 && nbatch > 0) {
+        for (int x6 = 0; x6 < 2; ++x6) {
+            const TilePlan pl = plan_tiles(M, N, K, nbatch, x6 != 0, tile_hint, split_k_hint);
+            const size_t b = splitk_plane_bytes(pl.split, nbatch, batch_outer, M, N);
+            if (b > need) need = b;
+        }
+    }
+    if (need) need += IX_TICKET_BYTES;
+    // ix_gemm_rowsum_f32 on shapes the producers do not sum: a separate ordered column sum of A (K rows of M)
+    if (!a_kcontig && batch_inner == 1 && M > 0 && K > 0) {
+        size_t cs = 0;
+        ix_workspace_bytes_colsum_f32(K, M, batch_outer, &cs);
+        if (cs > need) need = cs;
+    }
+    *out = need;
     return IX_OK;
 }
 
@@ -2144,10 +2331,15 @@ extern "C" int ix_gemm_f32_ws(const float* A, const float* B, float* C, const fl
 // Other layouts / kernels: a separate column-sum launch (needs A contiguous: lda = M, sAo = K * M, rowsum_stride = M).
 extern "C" int ix_gemm_rowsum_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig,
                                   int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo,
-                                  float alpha, float* rowsum, int64_t rowsum_stride, hipStream_t stream) {
+                                  float alpha, float* rowsum, int64_t rowsum_stride, void* workspace, size_t workspace_bytes,
+                                  hipStream_t stream) {
     IX_CHECK_ARG(rowsum != nullptr, "ix_gemm_rowsum_f32: null rowsum");
-    return gemm_impl(A, B, C, nullptr, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, 1, sAo, 0, sBo, 0, sCo, 0, 0, alpha,
-                     0, 0, nullptr, 0, rowsum, rowsum_stride, stream);
+    const int presplit = g_presplit;   // (the row sums ride on the bf16x6 / fp16x3 producers, never on the pre-split route)
+    g_presplit = 0;
+    const int rc = gemm_impl(A, B, C, nullptr, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, batch_outer, 1, sAo, 0, sBo, 0, sCo, 0, 0,
+                             alpha, 0, 0, workspace, workspace_bytes, rowsum, rowsum_stride, stream);
+    g_presplit = presplit;
+    return rc;
 }
 
 static int gemm_impl(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
@@ -2160,6 +2352,14 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     const int nbatch = batch_outer * batch_inner;
     if (M == 0 || N == 0 || nbatch == 0) return IX_OK;
     IX_CHECK_ARG(nbatch <= 65535, "ix_gemm_f32: batch %d > 65535", nbatch);
+    // workspace layout shared by every entry point: [IX_TICKET_BYTES of reduction tickets][scratch]
+    void* const workspace_all = workspace;
+    const size_t workspace_all_bytes = workspace_bytes;
+    if (workspace) {
+        IX_CHECK_ARG(workspace_bytes >= IX_TICKET_BYTES && aligned16(workspace), "ix_gemm_f32_ws: workspace below %d bytes or unaligned", IX_TICKET_BYTES);
+        workspace = static_cast<char*>(workspace) + IX_TICKET_BYTES;
+        workspace_bytes -= IX_TICKET_BYTES;
+    }
     if (workspace && x3_eligible(M, N, K, batch_outer, batch_inner, lda, ldb, sAo, sBo, A, B, tile_hint, split_k_hint)) {
         const size_t need = ix_x3_workspace_bytes(M, N, K, sAo ? batch_outer : 1, sBo ? batch_outer : 1);
         if (workspace_bytes < need) {
@@ -2212,79 +2412,34 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
                        (int64_t)ix_div_up(M, 128) * ix_div_up(N, 32) * nbatch * 64 < ((int64_t)1 << 30);   // (item index fits an int)
     const bool want_x6 = x6_ok && (tile_hint == 1128 || (g_x6 && tile_hint != 128));
 
-    // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the
-    // shared resource: a CU that receives n workgroups spends n * ksteps * step_cycles on MFMAs, while the fixed
-    // prologue/epilogue latencies of its (up to two) co-resident workgroups overlap.  Split-K adds a zero-fill launch
-    // and s atomic passes over C.  This replaces "fill the chip" thresholds, which lose up to 2x to wave quantisation
-    // (e.g. 540 workgroups on 512 resident slots).
-    int bm = 64, split = 1;
-    {
-        double best = 1e300;
-        const int cand_tiles[2] = {128, 64};
-        const int cand_split[14] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32, 48, 64};
-        for (int ti = 0; ti < 2; ++ti) {
-            const int t = cand_tiles[ti];
-            if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
-            const int bk = t == 128 ? 32 : 64;
-            // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
-            const double step_cycles = t == 128 ? (want_x6 ? 1900.0 : 4096.0) : 2048.0 * 1.15;
-            const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
-            for (int si = 0; si < 14; ++si) {
-                int sp = cand_split[si];
-                if (split_k_hint > 0) sp = split_k_hint;
-                if (sp > 1 && K < 2 * bk * sp) break;
-                int kps = ix_div_up(ix_div_up(K, sp), bk) * bk;
-                if (kps < bk) kps = bk;
-                const int real_split = K > 0 ? ix_div_up(K, kps) : 1;
-                const int ksteps = ix_div_up(kps, bk);
-                const int64_t blocks = tl * real_split;
-                const int64_t per_cu = (blocks + 255) / 256;
-                double cost = (double)per_cu * ksteps * step_cycles + (double)((per_cu + 1) / 2) * 7000.0;
-                if (real_split > 1) {
-                    const double cbytes = 4.0 * (double)M * (double)N * (double)nbatch;
-                    cost += 6000.0 + cbytes / 2048.0 + cbytes * real_split / 1024.0;  // zero-fill launch + fill + atomics
-                }
-                if (cost < best) {
-                    best = cost;
-                    bm = t;
-                    split = real_split;
-                }
-                if (split_k_hint > 0) break;
-            }
-        }
-    }
-    const int bk = bm == 128 ? 32 : 64;
+    const TilePlan plan = plan_tiles(M, N, K, nbatch, want_x6, tile_hint, split_k_hint);
+    const int bm = plan.bm, split = plan.split;
     const bool use_x6 = bm == 128 && want_x6;
     const int bn = use_x6 ? (N > 64 ? 128 : (N > 32 ? 64 : 32)) : bm;   // narrow bf16x6 tiles for N = head dim
     a.tiles_m = ix_div_up(M, bm);
     a.tiles_n = ix_div_up(N, bn);
-    int kps = ix_div_up(ix_div_up(K, split), bk) * bk;
-    if (kps < bk) kps = bk;
-    split = K > 0 ? ix_div_up(K, kps) : 1;
     a.split_k = split;
-    a.k_per_split = kps;
-    if (split > 1) {
-        // (a kernel, not hipMemsetAsync: inside the policy step's captured HIP graph a memset node in front of the atomics
-        //  replayed differently from eager -- tests/test_parity_gpu.py::test_policy_step_graph_replay_equals_eager)
-        dim3 zg(ix_grid_1d((int64_t)M * N, 256), nbatch);
-        hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, C, M, N, ldc, sCo, sCi, batch_inner);
-    }
+    a.k_per_split = plan.kps;
+    bool rowsum_in_kernel = false;
     if (rowsum) {
         if (use_x6 && !a_kcontig && batch_inner == 1 && g_x6 == 3) {
+            rowsum_in_kernel = true;
             a.rowsum = rowsum;
             a.sRowsum = rowsum_stride;
-            if (split > 1) {   // split-K items add their partial sums
-                if (rowsum_stride == M || batch_outer == 1)
-                    hipMemsetAsync(rowsum, 0, sizeof(float) * ((size_t)(batch_outer - 1) * rowsum_stride + M), stream);
-                else
-                    for (int b = 0; b < batch_outer; ++b) hipMemsetAsync(rowsum + b * rowsum_stride, 0, sizeof(float) * M, stream);
-            }
         } else {
             IX_CHECK_ARG(!a_kcontig && lda == M && batch_inner == 1 && (batch_outer == 1 || (sAo == (int64_t)K * M && rowsum_stride == M)),
                          "ix_gemm_rowsum_f32: the separate column-sum path needs a contiguous m-fastest A");
-            const int rc = ix_colsum_f32(A, rowsum, K, M, batch_outer, stream);
+            const int rc = ix_colsum_f32(A, rowsum, K, M, batch_outer, workspace_all, workspace_all_bytes, stream);
             if (rc != IX_OK) return rc;
         }
+    }
+    // split-K partial sums: planes in the caller's workspace + an ordered reduction (deterministic); without a workspace
+    // fp32 atomics onto a zero-filled C (a kernel, not hipMemsetAsync: inside the policy step's captured HIP graph a
+    // memset node in front of the atomics replayed differently from eager)
+    SplitReal real;
+    {
+        const int rc = splitk_begin(a, nbatch, batch_outer, rowsum_in_kernel, workspace, workspace_bytes, real, "ix_gemm_f32", stream);
+        if (rc != IX_OK) return rc;
     }
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
@@ -2317,6 +2472,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else
         launch_cfg<64, 64, 64>(a, a_kcontig, b_kcontig, grid, stream);
+    splitk_finish(a, nbatch, batch_outer, rowsum_in_kernel, real, stream);
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_gemm_f32");
     return IX_OK;
@@ -2378,9 +2534,32 @@ extern "C" int ix_conv_gemm_supported(int groups, int imgs, int H, int W, int Ci
     return 1;
 }
 
+// (M, N, K) of the contraction behind one convolution kind
+static void conv_gemm_dims(int kind, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int T, int* M, int* N, int* K) {
+    if (kind == 0) { *M = imgs * OH * OW; *N = Cout; *K = T * Cin; }
+    else if (kind == 1) { *M = imgs * H * W; *N = Cin; *K = T * Cout; }
+    else { *M = Cout; *N = T * Cin; *K = imgs * OH * OW; }
+}
+static int conv_split(int M, int N, int K, int groups, int* kps_out) {
+    int split = x6_pick_split(M, N, K, groups);
+    const int kps = ix_div_up(ix_div_up(K, split), 32) * 32;
+    *kps_out = kps;
+    return ix_div_up(K, kps);
+}
+
+extern "C" int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout,
+                                                int KH, int KW, size_t* out) {
+    IX_CHECK_ARG(out != nullptr && kind >= 0 && kind <= 2, "ix_workspace_bytes_conv_gemm_f32: bad args");
+    int M, N, K, kps;
+    conv_gemm_dims(kind, imgs, H, W, Cin, OH, OW, Cout, KH * KW, &M, &N, &K);
+    *out = splitk_plane_bytes(conv_split(M, N, K, groups, &kps), groups, groups, M, N);
+    if (*out) *out += IX_TICKET_BYTES;
+    return IX_OK;
+}
+
 extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W,
                                 int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                                hipStream_t stream) {
+                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
     IX_CHECK_ARG(src && other && out, "ix_conv_gemm_f32: null operand");
     IX_CHECK_ARG(kind >= 0 && kind <= 2, "ix_conv_gemm_f32: kind %d", kind);
     IX_CHECK_ARG(ix_conv_gemm_supported(groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil),
@@ -2445,14 +2624,19 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     const int bn = (kind == 2 ? (Cin % 128 == 0) : (a.N > 64)) ? 128 : 64;
     a.tiles_m = ix_div_up(a.M, 128);
     a.tiles_n = ix_div_up(a.N, bn);
-    int split = x6_pick_split(a.M, a.N, a.K, groups);
-    int kps = ix_div_up(ix_div_up(a.K, split), 32) * 32;
-    split = ix_div_up(a.K, kps);
+    int kps;
+    const int split = conv_split(a.M, a.N, a.K, groups, &kps);
     a.split_k = split;
     a.k_per_split = kps;
-    if (split > 1) {
-        dim3 zg(ix_grid_1d((int64_t)a.M * a.N, 256), groups);
-        hipLaunchKernelGGL(zero_strided_kernel, zg, dim3(256), 0, stream, a.C, a.M, a.N, a.ldc, a.sCo, (int64_t)0, 1);
+    if (workspace) {   // [IX_TICKET_BYTES of reduction tickets][scratch], as every entry point
+        IX_CHECK_ARG(workspace_bytes >= IX_TICKET_BYTES && aligned16(workspace), "ix_conv_gemm_f32: workspace below %d bytes or unaligned", IX_TICKET_BYTES);
+        workspace = static_cast<char*>(workspace) + IX_TICKET_BYTES;
+        workspace_bytes -= IX_TICKET_BYTES;
+    }
+    SplitReal real;
+    {
+        const int rc = splitk_begin(a, groups, groups, false, workspace, workspace_bytes, real, "ix_conv_gemm_f32", stream);
+        if (rc != IX_OK) return rc;
     }
     const int64_t items64 = (int64_t)a.tiles_m * a.tiles_n * groups * split;
     IX_CHECK_ARG(items64 < (1 << 30), "ix_conv_gemm_f32: too many tiles");
@@ -2468,6 +2652,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     prof_mark(stream);
     if (bn == 128) launch_conv_bn<128>(a, kind, items, stream);
     else launch_conv_bn<64>(a, kind, items, stream);
+    splitk_finish(a, groups, groups, false, real, stream);
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_conv_gemm_f32");
     return IX_OK;

@@ -147,7 +147,8 @@ extern "C" int ix_sgd_clip_bwd_multi_f32(const float* const* G, const float* con
 }
 
 // ---- flat-buffer outer step ------------------------------------------------------------------------------
-__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out, float* __restrict__ part,
+                             unsigned int* tickets) {
     __shared__ float red[4];
     float s = 0.f;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
@@ -158,16 +159,32 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
     }
     for (int64_t k = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) s += x[k] * x[k];
     s = ix_block_sum_256(s, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, s);
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) *out += s;
+        return;
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (!ix_last_block(tickets, gridDim.x)) return;   // the last workgroup adds the partials in index order
+    float t = 0.f;
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(part + i);
+    t = ix_block_sum_256(t, red);
+    if (threadIdx.x == 0) *out += t;
 }
 
-// out[0] += sum x^2   (caller zeroes out; lets several buffers accumulate into one total norm)
-extern "C" int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, hipStream_t stream) {
+// out[0] += sum x^2   (caller zeroes out; lets several buffers accumulate into one total norm).  workspace:
+// IX_TICKET_BYTES of tickets (zero on entry, left zero) + 4 KiB of partials -- ordered, run-to-run identical sum.
+extern "C" int ix_sumsq_accum_f32(const float* x, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                                  hipStream_t stream) {
     if (n <= 0) return IX_OK;
     IX_CHECK_ARG(x && out && ((uintptr_t)x & 15) == 0, "ix_sumsq_accum_f32: bad args (x must be 16-byte aligned)");
     int g = ix_grid_1d((n + 3) / 4, 256);
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, stream, x, n, out);
+    if (g > 1)
+        IX_CHECK_ARG(workspace && workspace_bytes >= IX_TICKET_BYTES + 4096 && ix_al16(workspace),
+                     "ix_sumsq_accum_f32: workspace of %d bytes needed", IX_TICKET_BYTES + 4096);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(g), dim3(256), 0, stream, x, n, out,
+                       g > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + IX_TICKET_BYTES) : nullptr,
+                       static_cast<unsigned int*>(workspace));
     IX_CHECK_LAUNCH("ix_sumsq_accum_f32");
     return IX_OK;
 }

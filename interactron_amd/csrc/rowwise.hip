@@ -534,7 +534,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int64_t rows, int D, int row_groups) {
+                                                     int64_t rows, int D, int row_groups, float* __restrict__ part,
+                                                     unsigned int* tickets) {
     __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
     __shared__ float sb[ROWS_PER_BLOCK][64 * NREG];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -584,28 +585,81 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         sb[w][lane + 64 * i] = ab[i];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) {
-        unsafeAtomicAdd(&dgamma[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
-        unsafeAtomicAdd(&dbeta[c], sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+    // column sums over the rows of a group: one partial per workgroup, added in workgroup order by the last one to arrive
+    if (gridDim.x == 1) {
+        for (int c = threadIdx.x; c < D; c += 256) {
+            dgamma[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+            dbeta[c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+        }
+        return;
     }
+    float* pg = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        pg[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+        pg[D + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+    }
+    if (!ix_last_block(tickets + blockIdx.y, gridDim.x)) return;
+    const float* base = part + (int64_t)blockIdx.y * gridDim.x * 2 * D;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        float t = 0.f;
+        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(base + (int64_t)b * 2 * D + c);
+        if (c < D) dgamma[c] = t; else dbeta[c - D] = t;
+    }
+}
+
+static int ln_row_groups(int64_t rows) { return rows > 4096 ? 8 : (rows > 512 ? 2 : 1); }
+static unsigned ln_grid_x(int64_t rows) {
+    const int rg = ln_row_groups(rows);
+    return (unsigned)((rows + ROWS_PER_BLOCK * rg - 1) / (ROWS_PER_BLOCK * rg));
+}
+// scratch of the LayerNorm backward / double backward: IX_TICKET_BYTES of tickets (zero on entry, left zero) + one partial
+// (dgamma, dbeta) pair per workgroup.  rows = rows PER GROUP.
+extern "C" int ix_workspace_bytes_layernorm_bwd(int64_t rows, int D, int groups, size_t* out) {
+    IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_layernorm_bwd: null out");
+    const unsigned gx = rows > 0 ? ln_grid_x(rows) : 1;
+    *out = gx > 1 ? IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)D * (size_t)gx * (size_t)(groups > 0 ? groups : 1) : 0;
+    return IX_OK;
+}
+
+static int ln_scratch(const char* who, int64_t rows, int D, int groups, int vecs, void* workspace, size_t workspace_bytes,
+                      float** part, unsigned int** tickets) {
+    *part = nullptr;
+    *tickets = nullptr;
+    if (rows <= 0 || ln_grid_x(rows) <= 1) return IX_OK;
+    const size_t need = IX_TICKET_BYTES + sizeof(float) * vecs * (size_t)D * (size_t)ln_grid_x(rows) * (size_t)groups;
+    if (!workspace || workspace_bytes < need || !ix_al16(workspace) || groups > IX_MAX_TICKETS) {
+        ix_set_error("%s: workspace of %zu bytes (16-byte aligned) needed, %zu given", who, need, workspace ? workspace_bytes : (size_t)0);
+        return IX_ERR_WORKSPACE;
+    }
+    *tickets = static_cast<unsigned int*>(workspace);
+    *part = reinterpret_cast<float*>(static_cast<char*>(workspace) + IX_TICKET_BYTES);
+    return IX_OK;
+}
+
+__global__ void ln_zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) p[k] = 0.f;
 }
 
 extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* mean,
                                     const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
-                                    int groups, hipStream_t stream) {
+                                    int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     IX_CHECK_ARG(dgamma && dbeta && groups >= 1 && groups <= 65535, "ix_layernorm_bwd_f32: bad dgamma/dbeta/groups");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_f32: D=%d unsupported (1..1024)", D);
-    if (dbeta == dgamma + (size_t)D * groups) {   // one allocation [2][groups][D] (hipops does that): one fill
-        hipMemsetAsync(dgamma, 0, sizeof(float) * 2 * D * groups, stream);
-    } else {
-        hipMemsetAsync(dgamma, 0, sizeof(float) * D * groups, stream);
-        hipMemsetAsync(dbeta, 0, sizeof(float) * D * groups, stream);
+    if (rows <= 0) {
+        const int64_t n = (int64_t)D * groups;
+        hipLaunchKernelGGL(ln_zero_kernel, dim3(ix_grid_1d(n, 256)), dim3(256), 0, stream, dgamma, n);
+        hipLaunchKernelGGL(ln_zero_kernel, dim3(ix_grid_1d(n, 256)), dim3(256), 0, stream, dbeta, n);
+        return IX_OK;
     }
-    if (rows <= 0) return IX_OK;
     IX_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "ix_layernorm_bwd_f32: null pointer");
-    const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups)), groups), block(256);
-#define LNB(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups)
+    float* part;
+    unsigned int* tickets;
+    const int rc = ln_scratch("ix_layernorm_bwd_f32", rows, D, groups, 2, workspace, workspace_bytes, &part, &tickets);
+    if (rc != IX_OK) return rc;
+    const int row_groups = ln_row_groups(rows);
+    dim3 grid(ln_grid_x(rows), groups), block(256);
+#define LNB(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups, part, tickets)
     if (D <= 256) LNB(4);
     else if (D <= 512) LNB(8);
     else LNB(16);
@@ -628,7 +682,8 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ grad_dy,
                                                          float* __restrict__ grad_x, float* __restrict__ grad_gamma,
-                                                         int64_t rows, int D, int row_groups) {
+                                                         int64_t rows, int D, int row_groups, float* __restrict__ part,
+                                                         unsigned int* tickets) {
     __shared__ float sg[ROWS_PER_BLOCK][64 * NREG];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     {   // blockIdx.y = group
@@ -705,22 +760,40 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < NREG; ++i) sg[w][lane + 64 * i] = ag[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256)
-        unsafeAtomicAdd(&grad_gamma[c], sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    if (gridDim.x == 1) {
+        for (int c = threadIdx.x; c < D; c += 256) grad_gamma[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+        return;
+    }
+    float* pg = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D;
+    for (int c = threadIdx.x; c < D; c += 256) pg[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
+    if (!ix_last_block(tickets + blockIdx.y, gridDim.x)) return;
+    const float* base = part + (int64_t)blockIdx.y * gridDim.x * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float t = 0.f;
+        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(base + (int64_t)b * D + c);
+        grad_gamma[c] = t;
+    }
 }
 
 extern "C" int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy,
                                         const float* x, const float* gamma, const float* mean, const float* rstd,
                                         float* grad_dy, float* grad_x, float* grad_gamma, int64_t rows, int D,
-                                        int groups, hipStream_t stream) {
+                                        int groups, void* workspace, size_t workspace_bytes, hipStream_t stream) {
     IX_CHECK_ARG(grad_gamma && groups >= 1 && groups <= 65535, "ix_layernorm_bwd_bwd_f32: bad grad_gamma/groups");
     IX_CHECK_ARG(D > 0 && D <= 1024, "ix_layernorm_bwd_bwd_f32: D=%d unsupported (1..1024)", D);
-    hipMemsetAsync(grad_gamma, 0, sizeof(float) * D * groups, stream);
-    if (rows <= 0) return IX_OK;
+    if (rows <= 0) {
+        const int64_t n = (int64_t)D * groups;
+        hipLaunchKernelGGL(ln_zero_kernel, dim3(ix_grid_1d(n, 256)), dim3(256), 0, stream, grad_gamma, n);
+        return IX_OK;
+    }
     IX_CHECK_ARG(dy && x && gamma && mean && rstd && grad_dy && grad_x, "ix_layernorm_bwd_bwd_f32: null pointer");
-    const int row_groups = rows > 4096 ? 8 : (rows > 512 ? 2 : 1);
-    dim3 grid((unsigned)((rows + ROWS_PER_BLOCK * row_groups - 1) / (ROWS_PER_BLOCK * row_groups)), groups), block(256);
-#define LNBB(N) hipLaunchKernelGGL(ln_bwd_bwd_kernel<N>, grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups)
+    float* part;
+    unsigned int* tickets;
+    const int rc = ln_scratch("ix_layernorm_bwd_bwd_f32", rows, D, groups, 1, workspace, workspace_bytes, &part, &tickets);
+    if (rc != IX_OK) return rc;
+    const int row_groups = ln_row_groups(rows);
+    dim3 grid(ln_grid_x(rows), groups), block(256);
+#define LNBB(N) hipLaunchKernelGGL(ln_bwd_bwd_kernel<N>, grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups, part, tickets)
     if (D <= 256) LNBB(4);
     else if (D <= 512) LNBB(8);
     else LNBB(16);

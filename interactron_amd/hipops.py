@@ -128,20 +128,70 @@ def _numel(shape):
 # contracted index contiguous and N >= 1024 (the operand-split passes amortise over N), slower elsewhere -- so only those
 # shapes are routed, and the default stays bf16x6 for every contraction.
 GEMM_X3 = os.environ.get("IX_GEMM_X3", "0") == "1"
-_ws_bytes = {}   # contraction signature -> scratch bytes of its fp16x3 route (0: bf16x6 / fp32 kernels)
+_ws_bytes = {}   # contraction signature -> scratch bytes (split-K planes; fp16x3 operand planes on the opt-in route)
+
+# ---- the contraction scratch -----------------------------------------------------------------------------------------
+# Split-K contractions write one partial plane per split into caller-provided scratch and add the planes in order
+# (ix_gemm_f32_ws; deterministic, unlike the fp32 atomics of the workspace-free entry point).  ONE scratch tensor per
+# process serves every call: launches are stream-ordered on the process's single compute stream, so the next contraction
+# can only overwrite it after the previous reduction has read it.  It grows geometrically; superseded buffers are kept
+# alive because captured HIP graphs hold their addresses.
+_scratch = [None]
+_scratch_retired = []
+
+
+TICKET_BYTES = 65536   # IX_TICKET_BYTES of csrc/common.h: the head of the scratch holds the reduction tickets
+
+
+def _workspace(nbytes, device):
+    """-> the process's scratch tensor, at least `nbytes` long.  Layout (include/interactron_hip.h): [TICKET_BYTES of
+    tickets, zero when the buffer is created and left zero by every kernel][split-K planes / reduction partials]."""
+    t = _scratch[0]
+    if t is None or t.numel() < nbytes:
+        if t is not None:
+            _scratch_retired.append(t)
+        t = _scratch[0] = torch.empty(max(2 * nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        t[:TICKET_BYTES].zero_()
+    return t
+
+
+_red_ws = {}
+
+
+def _reduce_ws(kind, rows, C, groups, device):
+    """(pointer, bytes) of the scratch for one multi-workgroup reduction (sizes cached per signature)."""
+    key = (kind, rows, C, groups)
+    n = _red_ws.get(key)
+    if n is None:
+        out = ctypes.c_size_t(0)
+        L = _L()
+        if kind == "colsum":
+            _chk(L.ix_workspace_bytes_colsum_f32(rows, C, groups, ctypes.byref(out)), "ix_workspace_bytes_colsum_f32")
+        elif kind == "ln":
+            _chk(L.ix_workspace_bytes_layernorm_bwd(rows, C, groups, ctypes.byref(out)), "ix_workspace_bytes_layernorm_bwd")
+        elif kind == "wce":
+            _chk(L.ix_workspace_bytes_weighted_ce(rows, ctypes.byref(out)), "ix_workspace_bytes_weighted_ce")
+        else:   # scalar reductions: tickets + 4 KiB of partials
+            out.value = TICKET_BYTES + 4096
+        n = _red_ws[key] = out.value
+    if n == 0:
+        return None, 0
+    return _workspace(n, device).data_ptr(), n
 
 
 def _gemm_workspace_bytes(pa, pb, sp):
-    if not GEMM_X3 or sp.A.trans or not sp.B.trans or sp.N < 1024 or sp.M < 1024:
-        return 0
-    key = (sp.M, sp.N, sp.K, sp.bo, sp.bi, sp.A.ld, sp.B.ld, sp.A.so, sp.B.so, pa & 15, pb & 15)
+    x3 = GEMM_X3 and not sp.A.trans and sp.B.trans and sp.N >= 1024 and sp.M >= 1024
+    key = (sp.M, sp.N, sp.K, sp.bo, sp.bi, sp.A.trans, sp.B.trans, sp.A.ld, sp.B.ld, sp.A.so, sp.B.so, pa & 15, pb & 15, x3)
     n = _ws_bytes.get(key)
     if n is None:
         out = ctypes.c_size_t(0)
-        _chk(_L().ix_workspace_bytes_gemm_f32(sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0, sp.A.ld,
-                                              sp.B.ld, sp.bo, sp.bi, sp.A.so, sp.B.so, pa, pb, 0, 0, ctypes.byref(out)),
+        L = _L()
+        L.ix_gemm_presplit_enable(1 if x3 else 0)
+        _chk(L.ix_workspace_bytes_gemm_f32(sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0, sp.A.ld,
+                                           sp.B.ld, sp.bo, sp.bi, sp.A.so, sp.B.so, pa, pb, 0, 0, ctypes.byref(out)),
              "ix_workspace_bytes_gemm_f32")
-        n = _ws_bytes[key] = out.value
+        L.ix_gemm_presplit_enable(0)
+        n = _ws_bytes[key] = (out.value, x3)
     return n
 
 
@@ -153,14 +203,19 @@ def _run_gemm(a, b, bias, sp, fill=True):
     assert not sp.C.trans
     esz = 4
     pa, pb = a.data_ptr() + sp.A.offset * esz, b.data_ptr() + sp.B.offset * esz
-    nws = _gemm_workspace_bytes(pa, pb, sp)
-    ws = torch.empty(nws, dtype=torch.uint8, device=a.device) if nws else None
-    rc = _L().ix_gemm_f32_ws(pa, pb,
-                             out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
-                             sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
-                             sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
-                             sp.N if (bias is not None and bias.dim() == 2) else 0, sp.alpha, 0, 0,
-                             ws.data_ptr() if nws else None, nws, _stream())
+    nws, x3 = _gemm_workspace_bytes(pa, pb, sp)
+    ws = _workspace(nws, a.device) if nws else None
+    L = _L()
+    if x3:
+        L.ix_gemm_presplit_enable(1)
+    rc = L.ix_gemm_f32_ws(pa, pb,
+                          out.data_ptr() + sp.C.offset * esz, bias.data_ptr() if bias is not None else None,
+                          sp.M, sp.N, sp.K, 0 if sp.A.trans else 1, 1 if sp.B.trans else 0,
+                          sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.bi, sp.A.so, sp.A.si, sp.B.so, sp.B.si, sp.C.so, sp.C.si,
+                          sp.N if (bias is not None and bias.dim() == 2) else 0, sp.alpha, 0, 0,
+                          ws.data_ptr() if nws else None, nws, _stream())
+    if x3:
+        L.ix_gemm_presplit_enable(0)
     _chk(rc, "ix_gemm_f32_ws")
     return out
 
@@ -319,9 +374,13 @@ class GemmRowsum(Function):
         covered = sp.bo * sp.M * sp.N == _numel(sp.out_shape)
         out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
         rs = torch.empty((groups, sp.M) if groups else (sp.M,), device=a.device, dtype=torch.float32)
-        _chk(_L().ix_gemm_rowsum_f32(a.data_ptr(), b.data_ptr() + sp.B.offset * 4, out.data_ptr() + sp.C.offset * 4,
+        pa, pb = a.data_ptr(), b.data_ptr() + sp.B.offset * 4
+        nws, _ = _gemm_workspace_bytes(pa, pb, sp)
+        ws = _workspace(nws, a.device) if nws else None
+        _chk(_L().ix_gemm_rowsum_f32(pa, pb, out.data_ptr() + sp.C.offset * 4,
                                      sp.M, sp.N, sp.K, 0, 1 if sp.B.trans else 0, sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.A.so,
-                                     sp.B.so, sp.C.so, sp.alpha, rs.data_ptr(), sp.M, _stream()), "ix_gemm_rowsum_f32")
+                                     sp.B.so, sp.C.so, sp.alpha, rs.data_ptr(), sp.M, ws.data_ptr() if nws else None, nws,
+                                     _stream()), "ix_gemm_rowsum_f32")
         return out, rs
 
     @staticmethod
@@ -811,7 +870,8 @@ class ColSum(Function):
             (rows, C), G = x.shape, 1
             out = torch.empty(C, device=x.device, dtype=torch.float32)
         ctx.rows = rows
-        _chk(_L().ix_colsum_f32(x.data_ptr(), out.data_ptr(), rows, C, G, _stream()), "ix_colsum_f32")
+        wp, wn = _reduce_ws("colsum", rows, C, G, x.device)
+        _chk(_L().ix_colsum_f32(x.data_ptr(), out.data_ptr(), rows, C, G, wp, wn, _stream()), "ix_colsum_f32")
         return out
 
     @staticmethod
@@ -934,7 +994,8 @@ class Dot(Function):
         a, b = _req(a), _req(b)
         ctx.save_for_backward(a, b)
         out = torch.empty((), device=a.device, dtype=torch.float32)
-        _chk(_L().ix_dot_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ix_dot_f32")
+        wp, wn = _reduce_ws("scalar", 0, 0, 0, a.device)
+        _chk(_L().ix_dot_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), wp, wn, _stream()), "ix_dot_f32")
         return out
 
     @staticmethod
@@ -1332,10 +1393,21 @@ def conv_gemm_supported(cg):
     return ok
 
 
+_conv_ws = {}
+
+
 def _conv_gemm(kind, src, other, out_shape, cg):
     out = torch.empty(out_shape, device=src.device, dtype=torch.float32)
+    nws = _conv_ws.get((kind, cg))
+    if nws is None:
+        n = ctypes.c_size_t(0)
+        _chk(_L().ix_workspace_bytes_conv_gemm_f32(kind, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW,
+                                                   ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
+        nws = _conv_ws[(kind, cg)] = n.value
+    ws = _workspace(nws, src.device) if nws else None
     _chk(_L().ix_conv_gemm_f32(kind, src.data_ptr(), other.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin,
-                               cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil, _stream()), "ix_conv_gemm_f32")
+                               cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil, ws.data_ptr() if nws else None,
+                               nws, _stream()), "ix_conv_gemm_f32")
     return out
 
 
@@ -1511,8 +1583,9 @@ class LayerNormBwd(Function):
         dx = torch.empty_like(x)
         both = torch.empty((2,) + tuple(gamma.shape), device=gamma.device, dtype=torch.float32)   # (one fill for the two)
         dgamma, dbeta = both[0], both[1]
+        wp, wn = _reduce_ws("ln", rows // G, D, G, x.device)
         _chk(_L().ix_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                       dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows // G, D, G, _stream()),
+                                       dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows // G, D, G, wp, wn, _stream()),
              "ix_layernorm_bwd_f32")
         ctx.save_for_backward(dy, x, gamma, mean, rstd)
         return dx, dgamma, dbeta
@@ -1529,11 +1602,12 @@ class LayerNormBwd(Function):
         Gb = _req(Gb) if Gb is not None else None
         gdy, gx = torch.empty_like(x), torch.empty_like(x)
         ggamma = torch.empty_like(gamma)
+        wp, wn = _reduce_ws("ln", rows // G, D, G, x.device)
         _chk(_L().ix_layernorm_bwd_bwd_f32(Gx.data_ptr() if Gx is not None else None,
                                            Gg.data_ptr() if Gg is not None else None,
                                            Gb.data_ptr() if Gb is not None else None, dy.data_ptr(), x.data_ptr(),
                                            gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gdy.data_ptr(),
-                                           gx.data_ptr(), ggamma.data_ptr(), rows // G, D, G, _stream()),
+                                           gx.data_ptr(), ggamma.data_ptr(), rows // G, D, G, wp, wn, _stream()),
              "ix_layernorm_bwd_bwd_f32")
         return gdy, gx, ggamma, None, None
 
@@ -1581,8 +1655,9 @@ class WeightedCE(Function):
         argmax = torch.empty(R, device=logits.device, dtype=torch.int64)
         sums = torch.empty(2, device=logits.device, dtype=torch.float32)
         target = target.contiguous()
+        wp, wn = _reduce_ws("wce", R, 0, 0, logits.device)
         _chk(_L().ix_weighted_ce_fwd_f32(logits.data_ptr(), target.data_ptr(), weight.data_ptr(), lse.data_ptr(),
-                                         argmax.data_ptr(), sums.data_ptr(), R, C, _stream()), "ix_weighted_ce_fwd_f32")
+                                         argmax.data_ptr(), sums.data_ptr(), R, C, wp, wn, _stream()), "ix_weighted_ce_fwd_f32")
         ctx.save_for_backward(logits, target, weight, lse, sums)
         ctx.mark_non_differentiable(argmax)
         return sums[0] / sums[1], argmax
@@ -1764,7 +1839,8 @@ class _ClippedSGDBwd(Function):
 
 
 def sumsq_accum(x_flat, out_scalar):
-    _chk(_L().ix_sumsq_accum_f32(x_flat.data_ptr(), x_flat.numel(), out_scalar.data_ptr(), _stream()), "ix_sumsq_accum_f32")
+    wp, wn = _reduce_ws("scalar", 0, 0, 0, x_flat.device)
+    _chk(_L().ix_sumsq_accum_f32(x_flat.data_ptr(), x_flat.numel(), out_scalar.data_ptr(), wp, wn, _stream()), "ix_sumsq_accum_f32")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq=None, max_norm=0.0, zero_grad=False):

@@ -513,6 +513,51 @@ def test_bf16x6_contraction_is_fp32_grade(ops, akc, bkc):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_split_k_planes_are_deterministic(ops, akc, bkc):
+    """ix_gemm_f32_ws with a workspace: split-K partial sums go to per-split planes and are added in order -- the result is
+    bit-identical between runs (the atomics of the workspace-free entry point are not), for the bf16x6 kernel and both
+    exact-fp32 tile sizes, a strided / unaligned C (scalar reduction path), two batch levels, bias and alpha; and it agrees
+    with float64 like the unsplit product.  Too small a workspace is refused."""
+    from interactron_amd import _lib
+    import ctypes
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, bo, bi, split, hint, ldc_pad) in [(300, 260, 1805, 2, 1, 3, 1128, 0), (100, 20, 3000, 2, 2, 5, 64, 0),
+                                                   (256, 256, 3610, 1, 1, 0, 0, 0), (130, 77, 2048, 1, 3, 4, 128, 3),
+                                                   (512, 128, 7220, 2, 1, 0, 0, 0)]:
+        b = bo * bi
+        a = (rnd(b, M, K, seed=1) * rnd(b, M, 1, seed=2).exp()).cuda()
+        w = rnd(b, K, N, seed=3).cuda()
+        bias = rnd(bo, N, seed=4).cuda()
+        ref = 0.5 * (a.double() @ w.double()) + bias.double().repeat_interleave(bi, 0)[:, None, :]
+        scale = (a.double().abs() @ w.double().abs()) + 1e-30
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        lda, ldb, ldc = (K if akc else M), (K if bkc else N), N + ldc_pad
+        nws = ctypes.c_size_t(0)
+        assert lib.ix_workspace_bytes_gemm_f32(M, N, K, akc, bkc, lda, ldb, bo, bi, bi * M * K, bi * K * N, A.data_ptr(),
+                                               B.data_ptr(), hint, split, ctypes.byref(nws)) == 0
+        assert nws.value > 0, (M, N, K, "expected a split-K plan")
+        ws = torch.zeros(nws.value, dtype=torch.uint8, device="cuda")
+        outs = []
+        for rep in range(3):
+            C = torch.full((b, M, ldc), float("nan"), device="cuda")
+            args = (A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc, lda, ldb, ldc, bo, bi,
+                    bi * M * K, M * K, bi * K * N, K * N, bi * M * ldc, M * ldc, N, 0.5, hint, split)
+            rc = lib.ix_gemm_f32_ws(*args, ws.data_ptr(), nws.value, stream) if rep < 2 else lib.ix_gemm_f32(*args, stream)
+            assert rc == 0, lib.ix_last_error()
+            outs.append(C[:, :, :N].clone())
+            if ldc_pad:
+                assert bool(torch.isnan(C[:, :, N:]).all()), "the reduction wrote outside its rows"
+        assert torch.equal(outs[0], outs[1]), (M, N, K, "split-K planes are not deterministic")
+        err = float(((outs[0].double() - ref).abs() / scale).max())
+        assert err <= 6e-7, (M, N, K, err)
+        close(outs[2], outs[0], 2e-6, "atomics vs planes")
+    rc = lib.ix_gemm_f32_ws(*args, ws.data_ptr(), 64, stream)
+    assert rc != 0
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_f16x3_kernel_is_fp32_grade(ops, akc, bkc):
     """The fp16x3 form of the 12-wave contraction kernel (two fp16 planes with one exponent per 32 x 32 sub-block found by
     the producer waves, three fp16 MFMAs per k-slice, accumulators rescaled when a sub-block's exponent grows) against
@@ -587,6 +632,7 @@ def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
         lda, ldb = (K if akc else M), (K if bkc else N)
         sB = 0 if shareB else K * N
         nws = ctypes.c_size_t(0)
+        lib.ix_gemm_presplit_enable(1)   # (opt-in route; off again at the end of the test)
         rc = lib.ix_workspace_bytes_gemm_f32(M, N, K, akc, bkc, lda, ldb, b, 1, M * K, sB, A.data_ptr(), B.data_ptr(), 0, 0,
                                              ctypes.byref(nws))
         assert rc == 0 and nws.value > 0, (M, N, K, "expected the fp16x3 route")
@@ -607,13 +653,15 @@ def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     # too small a workspace is refused, not overrun
     rc = lib.ix_gemm_f32_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, akc, bkc, lda, ldb, N, b, 1, M * K, 0, sB, 0,
                             M * N, 0, 0, 1.0, 0, 0, ws.data_ptr(), 64, stream)
+    lib.ix_gemm_presplit_enable(0)
     assert rc != 0
 
 
 @pytest.mark.parametrize("bkc", [0, 1])
 def test_gemm_with_fused_rowsum(ops, bkc):
     """ix_gemm_rowsum_f32: the weight-gradient contraction dW = dy^T x with the bias gradient colsum(dy) produced by the
-    same launch (A-producer waves of the bf16x6 kernel), against float64 -- one split-K launch (atomic partial sums), a
+    same launch (A-producer waves of the bf16x6 kernel), against float64 -- one split-K launch (partial planes + ordered
+    reduction, bit-identical between runs; and the workspace-free atomic form), a
     per-episode batch, a ragged M (last row tile partly outside), and a small shape that falls back to the separate
     column-sum kernel."""
     from interactron_amd import _lib
@@ -625,9 +673,22 @@ def test_gemm_with_fused_rowsum(ops, bkc):
         B = x.transpose(1, 2).contiguous() if bkc else x
         C, C0 = torch.empty(b, M, N, device="cuda"), torch.empty(b, M, N, device="cuda")
         rs = torch.full((b, M), float("nan"), device="cuda")
-        rc = lib.ix_gemm_rowsum_f32(dy.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, 0, bkc, M, K if bkc else N, N, b,
-                                    K * M, K * N, M * N, 1.0, rs.data_ptr(), M, stream)
-        assert rc == 0, lib.ix_last_error()
+        import ctypes
+        nws = ctypes.c_size_t(0)
+        assert lib.ix_workspace_bytes_gemm_f32(M, N, K, 0, bkc, M, K if bkc else N, b, 1, K * M, K * N, dy.data_ptr(),
+                                               B.data_ptr(), 0, 0, ctypes.byref(nws)) == 0
+        ws = torch.zeros(max(nws.value, 16), dtype=torch.uint8, device="cuda")   # (ticket page zero on first use)
+        wp = ws.data_ptr() if nws.value else None
+        outs = []
+        for wsp, wsn in ((wp, nws.value), (wp, nws.value), (None, 0)):   # planes twice, then atomics
+            C.fill_(float("nan")); rs.fill_(float("nan"))
+            rc = lib.ix_gemm_rowsum_f32(dy.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, 0, bkc, M, K if bkc else N, N, b,
+                                        K * M, K * N, M * N, 1.0, rs.data_ptr(), M, wsp, wsn, stream)
+            assert rc == 0, lib.ix_last_error()
+            outs.append((C.clone(), rs.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "split-K planes: not deterministic"
+        close(outs[2][0], outs[0][0], 1e-6, "atomics vs planes")
+        assert float(((outs[2][1].double() - dy.double().sum(1)).abs() / dy.double().abs().sum(1)).max()) < 2e-6
         rc = lib.ix_gemm_f32(dy.data_ptr(), B.data_ptr(), C0.data_ptr(), None, M, N, K, 0, bkc, M, K if bkc else N, N, b, 1,
                              K * M, 0, K * N, 0, M * N, 0, 0, 1.0, 0, 0, stream)
         assert rc == 0, lib.ix_last_error()
