@@ -124,12 +124,20 @@ __global__ __launch_bounds__(256) void wce_fwd_kernel(const float* __restrict__ 
         if (threadIdx.x < 2) sums[threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
         return;
     }
-    if (threadIdx.x < 2) part[blockIdx.x * 2 + threadIdx.x] = (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]);
+    if (threadIdx.x < 2) ix_store_agent(part + blockIdx.x * 2 + threadIdx.x, (sw[0][threadIdx.x] + sw[1][threadIdx.x]) + (sw[2][threadIdx.x] + sw[3][threadIdx.x]));
     if (!ix_last_block(tickets, gridDim.x)) return;
-    if (threadIdx.x < 2) {
-        float t = 0.f;
-        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(part + b * 2 + threadIdx.x);
-        sums[threadIdx.x] = t;
+    // fixed order: thread t adds partials t, t + 256, ...; then the 256 thread sums through the block reduction
+    __shared__ float red[4];
+    float t0 = 0.f, t1 = 0.f;
+    for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256) {
+        t0 += ix_load_agent(part + b * 2);
+        t1 += ix_load_agent(part + b * 2 + 1);
+    }
+    t0 = ix_block_sum_256(t0, red);
+    t1 = ix_block_sum_256(t1, red);
+    if (threadIdx.x == 0) {
+        sums[0] = t0;
+        sums[1] = t1;
     }
 }
 

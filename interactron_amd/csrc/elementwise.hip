@@ -281,16 +281,18 @@ extern "C" int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C
 // Each block owns a band of rows and a 256-wide band of columns; lanes walk down rows (coalesced across columns).  With
 // several row bands the band sums go to `part[group][band][c]` and the last band to finish adds them in band order
 // (ix_last_block); part == nullptr: one atomic per column per block onto a zero-filled out (legacy, order-dependent).
-__device__ __forceinline__ void colsum_finish(float* __restrict__ out, float* __restrict__ part, unsigned int* tickets, int C,
-                                              int c0, int ncols) {
-    // this block's partial for columns [c0, c0 + ncols) is already stored in part[(z * gridDim.y + y) * C + c]
-    if (!ix_last_block(tickets + blockIdx.z * gridDim.x + blockIdx.x, gridDim.y)) return;
-    const float* base = part + (int64_t)blockIdx.z * gridDim.y * C;
-    for (int c = c0 + threadIdx.x; c < c0 + ncols && c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (unsigned int y = 0; y < gridDim.y; ++y) s += __builtin_nontemporal_load(base + (int64_t)y * C + c);
-        out[(int64_t)blockIdx.z * C + c] = s;
-    }
+// scratch of one (column band, group): [part1: gridDim.y x 256 | part2: cohorts x 256] floats
+__device__ __forceinline__ float* colsum_slot(float* part) {
+    const int ncoh = (gridDim.y + IX_COHORT - 1) / IX_COHORT;
+    return part + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * (gridDim.y + ncoh) * 256;
+}
+__device__ __forceinline__ void colsum_finish(float* __restrict__ out, float* slot, unsigned int* tickets, int C) {
+    const int ncoh = (gridDim.y + IX_COHORT - 1) / IX_COHORT;
+    const int c0 = blockIdx.x * 256;
+    float* og = out + (int64_t)blockIdx.z * C + c0;
+    const int ncols = min(256, C - c0);
+    ix_ordered_colsum(slot, slot + (int64_t)gridDim.y * 256, tickets + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * (ncoh + 1),
+                      blockIdx.y, gridDim.y, 256, [=](int c, float t) { if (c < ncols) og[c] = t; });
 }
 
 __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int C,
@@ -310,8 +312,9 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
         if (c < C) unsafeAtomicAdd(&out[(int64_t)blockIdx.z * C + c], s);
         return;
     }
-    if (c < C) part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c] = s;
-    colsum_finish(out, part, tickets, C, blockIdx.x * blockDim.x, blockDim.x);
+    float* slot = colsum_slot(part);
+    ix_store_agent(slot + (int64_t)blockIdx.y * 256 + threadIdx.x, s);
+    colsum_finish(out, slot, tickets, C);
 }
 
 // 16-byte form (C % 4 == 0, aligned rows): a thread owns 4 adjacent columns, the block's 4 waves take rows r, r+1, r+2,
@@ -360,8 +363,12 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
         }
         return;
     }
-    if (wave == 0 && c < C) *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c) = t;
-    colsum_finish(out, part, tickets, C, blockIdx.x * 256, 256);
+    float* slot = colsum_slot(part);
+    if (wave == 0) {
+        float* ps = slot + (int64_t)blockIdx.y * 256 + lane * 4;
+        ix_store_agent(ps + 0, t.x); ix_store_agent(ps + 1, t.y); ix_store_agent(ps + 2, t.z); ix_store_agent(ps + 3, t.w);
+    }
+    colsum_finish(out, slot, tickets, C);
 }
 
 __global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
@@ -369,6 +376,9 @@ __global__ void zero_f32_kernel(float* __restrict__ p, int64_t n) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += gs) p[k] = 0.f;
 }
 
+static size_t colsum_part_bytes(int nby, int C, int groups) {
+    return sizeof(float) * 256 * (size_t)(nby + ix_cohorts(nby)) * (size_t)ix_div_up(C, 256) * (size_t)groups;
+}
 static int colsum_bands(int64_t rows, int* rpb_out) {
     // few rows: one band (single pass, nothing to combine); else bands of >= 64 rows, at most 2048 of them
     int rpb = rows <= 256 ? 256 : 64;
@@ -381,7 +391,7 @@ extern "C" int ix_workspace_bytes_colsum_f32(int64_t rows, int C, int groups, si
     IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_colsum_f32: null out");
     int rpb;
     const int nby = rows > 0 ? colsum_bands(rows, &rpb) : 1;
-    *out = nby > 1 ? IX_TICKET_BYTES + sizeof(float) * (size_t)nby * (size_t)C * (size_t)(groups > 0 ? groups : 1) : 0;
+    *out = nby > 1 ? IX_TICKET_BYTES + colsum_part_bytes(nby, C, groups > 0 ? groups : 1) : 0;
     return IX_OK;
 }
 
@@ -402,8 +412,8 @@ extern "C" int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, in
     float* part = nullptr;
     unsigned int* tickets = nullptr;
     if (nby > 1 && workspace) {
-        const size_t need = IX_TICKET_BYTES + sizeof(float) * (size_t)nby * (size_t)C * (size_t)groups;
-        if (workspace_bytes < need || !ix_al16(workspace) || (int64_t)grid.x * groups > IX_MAX_TICKETS) {
+        const size_t need = IX_TICKET_BYTES + colsum_part_bytes(nby, C, groups);
+        if (workspace_bytes < need || !ix_al16(workspace) || (int64_t)grid.x * groups * (ix_cohorts(nby) + 1) > IX_MAX_TICKETS) {
             ix_set_error("ix_colsum_f32: workspace of %zu bytes (16-byte aligned) needed, %zu given", need, workspace_bytes);
             return IX_ERR_WORKSPACE;
         }
@@ -432,10 +442,10 @@ __global__ void dot_kernel(const float* __restrict__ a, const float* __restrict_
         if (threadIdx.x == 0) *out = s;
         return;
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    if (threadIdx.x == 0) ix_store_agent(part + blockIdx.x, s);
     if (!ix_last_block(tickets, gridDim.x)) return;
     float t = 0.f;
-    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(part + i);   // (gridDim.x <= 256)
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += ix_load_agent(part + i);   // (gridDim.x <= 256)
     t = ix_block_sum_256(t, red);
     if (threadIdx.x == 0) *out = t;
 }

@@ -163,10 +163,10 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
         if (threadIdx.x == 0) *out += s;
         return;
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = s;
-    if (!ix_last_block(tickets, gridDim.x)) return;   // the last workgroup adds the partials in index order
+    if (threadIdx.x == 0) ix_store_agent(part + blockIdx.x, s);
+    if (!ix_last_block(tickets, gridDim.x)) return;   // the last workgroup adds the partials in a fixed order
     float t = 0.f;
-    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += __builtin_nontemporal_load(part + i);
+    for (unsigned int i = threadIdx.x; i < gridDim.x; i += 256) t += ix_load_agent(part + i);
     t = ix_block_sum_256(t, red);
     if (threadIdx.x == 0) *out += t;
 }

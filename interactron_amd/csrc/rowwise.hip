@@ -593,18 +593,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         return;
     }
-    float* pg = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * D;
+    // part: [group][part1: gridDim.x x 2D | part2: cohorts x 2D]
+    const int ncoh = (gridDim.x + IX_COHORT - 1) / IX_COHORT;
+    float* p1 = part + (int64_t)blockIdx.y * (gridDim.x + ncoh) * 2 * D;
+    float* pg = p1 + (int64_t)blockIdx.x * 2 * D;
     for (int c = threadIdx.x; c < D; c += 256) {
-        pg[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
-        pg[D + c] = sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c];
+        ix_store_agent(pg + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+        ix_store_agent(pg + D + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
     }
-    if (!ix_last_block(tickets + blockIdx.y, gridDim.x)) return;
-    const float* base = part + (int64_t)blockIdx.y * gridDim.x * 2 * D;
-    for (int c = threadIdx.x; c < 2 * D; c += 256) {
-        float t = 0.f;
-        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(base + (int64_t)b * 2 * D + c);
-        if (c < D) dgamma[c] = t; else dbeta[c - D] = t;
-    }
+    ix_ordered_colsum(p1, p1 + (int64_t)gridDim.x * 2 * D, tickets + (int64_t)blockIdx.y * (ncoh + 1), blockIdx.x, gridDim.x, 2 * D,
+                      [=](int c, float t) { if (c < D) dgamma[c] = t; else dbeta[c - D] = t; });
 }
 
 static int ln_row_groups(int64_t rows) { return rows > 4096 ? 8 : (rows > 512 ? 2 : 1); }
@@ -617,7 +615,7 @@ static unsigned ln_grid_x(int64_t rows) {
 extern "C" int ix_workspace_bytes_layernorm_bwd(int64_t rows, int D, int groups, size_t* out) {
     IX_CHECK_ARG(out != nullptr, "ix_workspace_bytes_layernorm_bwd: null out");
     const unsigned gx = rows > 0 ? ln_grid_x(rows) : 1;
-    *out = gx > 1 ? IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)D * (size_t)gx * (size_t)(groups > 0 ? groups : 1) : 0;
+    *out = gx > 1 ? IX_TICKET_BYTES + sizeof(float) * 2 * (size_t)D * (size_t)(gx + ix_cohorts(gx)) * (size_t)(groups > 0 ? groups : 1) : 0;
     return IX_OK;
 }
 
@@ -626,8 +624,9 @@ static int ln_scratch(const char* who, int64_t rows, int D, int groups, int vecs
     *part = nullptr;
     *tickets = nullptr;
     if (rows <= 0 || ln_grid_x(rows) <= 1) return IX_OK;
-    const size_t need = IX_TICKET_BYTES + sizeof(float) * vecs * (size_t)D * (size_t)ln_grid_x(rows) * (size_t)groups;
-    if (!workspace || workspace_bytes < need || !ix_al16(workspace) || groups > IX_MAX_TICKETS) {
+    const unsigned gx = ln_grid_x(rows);
+    const size_t need = IX_TICKET_BYTES + sizeof(float) * vecs * (size_t)D * (size_t)(gx + ix_cohorts(gx)) * (size_t)groups;
+    if (!workspace || workspace_bytes < need || !ix_al16(workspace) || (int64_t)groups * (ix_cohorts(gx) + 1) > IX_MAX_TICKETS) {
         ix_set_error("%s: workspace of %zu bytes (16-byte aligned) needed, %zu given", who, need, workspace ? workspace_bytes : (size_t)0);
         return IX_ERR_WORKSPACE;
     }
@@ -764,15 +763,12 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
         for (int c = threadIdx.x; c < D; c += 256) grad_gamma[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
         return;
     }
-    float* pg = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * D;
-    for (int c = threadIdx.x; c < D; c += 256) pg[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
-    if (!ix_last_block(tickets + blockIdx.y, gridDim.x)) return;
-    const float* base = part + (int64_t)blockIdx.y * gridDim.x * D;
-    for (int c = threadIdx.x; c < D; c += 256) {
-        float t = 0.f;
-        for (unsigned int b = 0; b < gridDim.x; ++b) t += __builtin_nontemporal_load(base + (int64_t)b * D + c);
-        grad_gamma[c] = t;
-    }
+    const int ncoh = (gridDim.x + IX_COHORT - 1) / IX_COHORT;
+    float* p1 = part + (int64_t)blockIdx.y * (gridDim.x + ncoh) * D;
+    float* pg = p1 + (int64_t)blockIdx.x * D;
+    for (int c = threadIdx.x; c < D; c += 256) ix_store_agent(pg + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
+    ix_ordered_colsum(p1, p1 + (int64_t)gridDim.x * D, tickets + (int64_t)blockIdx.y * (ncoh + 1), blockIdx.x, gridDim.x, D,
+                      [=](int c, float t) { grad_gamma[c] = t; });
 }
 
 extern "C" int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const float* Gb, const float* dy,

@@ -94,6 +94,10 @@ def main():
     out = {"losses": {k: float(v) for k, v in l64.items()}}
     for grp, key in (("fusion", "fusion_grads"), ("detector", "detector_grads")):
         out[key] = {k: (None if g is None else float(g.norm())) for k, g in g64[grp].items()}
+        # the exact gradient at the fixture's 256 strided positions (golden_train.pt holds the reference's float32 values at
+        # the same positions): lets the GPU test ask "is HIP as close to the truth as the reference is?" element-wise
+        out[key + "_sample64"] = {k: (None if g is None else g.detach().reshape(-1)[T["g13"][key][k]["idx"]].double().clone())
+                                  for k, g in g64[grp].items()}
     out["configs"] = configs_f64()
     torch.save(out, os.path.join(HERE, "golden_train_f64.pt"))
     print("wrote golden_train_f64.pt")

@@ -57,20 +57,19 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
         # SGD step or a ReLU sitting on its kink flips with the summation order); there are no other elements to average
         # that out of the norm (tools/scalar_spread.py)
         rel = max(rel, 5e-2)
-    # Norm: 2 x rel.  Measured (IX_TEST_RECORD survey, 14 runs per test of the SAME binary, round 2): on the second-order
-    # configurations single backbone tensors move by up to 0.7 % of their norm from run to run (atomic split-K / row-sum
-    # orders decide which side of a ReLU kink or of the inner step's clip an element falls on -- discrete flips, heavy
-    # tails); the first-order configurations stay below 0.03 x the bound.
-    _judge("norm", what, abs(n - rec["norm"]), 2 * rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (n, rec["norm"], norm64))
+    # Norm within rel.  (Round 2 had to double this: split-K / row-sum atomics made two runs of one binary differ by up to
+    # 0.7 % on single tensors of the second-order configurations.  Every multi-workgroup sum is ordered now -- split-K
+    # planes, ticketed column sums -- and a step is bit-reproducible: tests/test_parity_gpu.py::test_step_is_bit_reproducible.)
+    _judge("norm", what, abs(n - rec["norm"]), rel * max(rec["norm"], 1e-9) + ref_noise + 1e-9, (n, rec["norm"], norm64))
     scale = max(rec["norm"] / max(g.numel(), 1) ** 0.5, 1e-12)
     err = (g.reshape(-1)[:8] - rec["head"]).abs().max().item()
     _judge("head", what, err, 20 * rel * scale + ref_noise + 1e-9, (err, scale))
     if "sample" in rec:
         # 256 values on an even stride over the whole tensor.  Float32 summation-order noise is relative to the tensor's
-        # RMS, not to each element, and in the second-order gradients single elements move discretely (an element of the
-        # clipped inner step or a ReLU on its kink flips -- run to run on the same binary, split-K atomics): so the
-        # sample must agree in L2 within 20 x rel, at most 2 % of its elements may be off by more than 20 x rel x RMS, and
-        # none by more than 100 x rel x RMS.  A slice routed to the wrong place is off by O(RMS) on EVERY element it covers.
+        # RMS, not to each element, and in the second-order gradients single elements sit on kinks (an element of the
+        # clipped inner step, a ReLU at zero) where the HIP and the reference summation orders may fall on different sides:
+        # the sample must agree in L2 within 4 x rel, at most 2 % of its elements may be off by more than 20 x rel x RMS,
+        # and none by more than 100 x rel x RMS.  A slice routed to the wrong place is off by O(RMS) on EVERY element it covers.
         got = g.reshape(-1)[rec["idx"]].double()
         ref = rec["sample"].double()
         diff = (got - ref).abs()
@@ -79,9 +78,7 @@ def check_grad(rec, g, rel=1e-3, what="", noise=1e-6, norm64=None):
         _judge("strided outliers", what, outliers, max(1, len(ref) // 50), (outliers, float(diff.max()), scale))
         _judge("strided worst element", what, float(diff.max()), 5 * bound, (float(diff.max()), scale))
         rn = float(ref.norm())
-        # (the same survey: up to 12 x rel on layer2 / layer3 convolution weights of the second-order configurations,
-        #  0.25 x 4 rel on the first-order ones; a mis-routed slice is off by ~100 x rel)
-        _judge("strided sample L2", what, float(diff.norm()), 20 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9,
+        _judge("strided sample L2", what, float(diff.norm()), 4 * rel * max(rn, scale * len(ref) ** 0.5) + ref_noise + 1e-9,
                (float(diff.norm()), rn))
 
 
@@ -107,10 +104,10 @@ class ReferenceMatching:
 
     # Share of images whose own optimum may differ from the recorded assignment (always by a tie, see above) before the
     # run is declared a failure: measured 0-3 % on the RNG-free weights over the large fixtures; a matcher or cost-kernel
-    # bug flips most images (and breaks the tie assertion first).  Small tests see 0-2 flips among their 6 images (config
-    # 3: 2 of 6 once in 30 runs), hence the additive slack of 3.
+    # bug flips most images (and breaks the tie assertion first).  The small tests (5-18 images) see 0 or 1 proven ties --
+    # a fixed number per test now that the step is deterministic, printed on exit -- hence an absolute slack of 1.
     MAX_FLIP_SHARE = 0.10
-    FLIP_SLACK = 3
+    FLIP_SLACK = 1
 
     def __init__(self, recorded, max_flip_share=None):
         self.recorded = recorded

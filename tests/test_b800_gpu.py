@@ -92,19 +92,22 @@ def test_full_800x800_meta_train_step_properties(golden):
     assert sum(float(first[k].double().norm()) > 0 for k in have) > 0.9 * len(have)
     random.seed(5)
     m(data)
-    tot1 = tot2 = 0.0
+    tot1 = tot2 = worst = 0.0
     for k in have:
         n1 = float(first[k].double().norm())
         n2 = float(m.get_parameter(k).grad.double().norm())
         tot1, tot2 = tot1 + n1 * n1, tot2 + n2 * n2
         if n1 < 1e-6:
             continue
-        # per tensor: within float32 run-to-run noise of the second-order path (a few % on the smallest gradients: split-K
-        # atomics, elements on the clip / ReLU kinks); a part dropped or written twice is off by 50 % or more
-        assert abs(n2 - 2 * n1) <= 0.1 * 2 * n1, (k, n1, n2)
-    assert abs(tot2 ** 0.5 - 2 * tot1 ** 0.5) <= 1e-2 * 2 * tot1 ** 0.5, (tot1 ** 0.5, tot2 ** 0.5)
+        # the second pass computes bit-identical contributions (ordered reductions), so .grad doubles up to the rounding of
+        # the accumulation itself; a part dropped or written twice is off by 50 % or more
+        worst = max(worst, abs(n2 - 2 * n1) / (2 * n1))
+        assert abs(n2 - 2 * n1) <= ACC_TENSOR * 2 * n1, (k, n1, n2)
+    print("800x800 accumulate twice: worst tensor %.2e, whole %.2e" % (worst, abs(tot2 ** 0.5 - 2 * tot1 ** 0.5) / (2 * tot1 ** 0.5)))
+    assert abs(tot2 ** 0.5 - 2 * tot1 ** 0.5) <= ACC_WHOLE * 2 * tot1 ** 0.5, (tot1 ** 0.5, tot2 ** 0.5)
 
 
+ACC_TENSOR, ACC_WHOLE = 1e-6, 1e-7   # measured (r3, deterministic reductions): 4.8e-9, 2.2e-11 (round 2, atomics: 0.1, 1e-2)
 FP8_LOGIT_MAX, FP8_LOGIT_L2, FP8_BOX_ABS = 0.08, 0.05, 0.03   # measured: 0.038, 0.030, 0.012
 
 

@@ -98,8 +98,8 @@ def test_two_ranks_equal_one_process():
     (g0, t0, d0, l0), (g1, t1, d1, l1) = out[0], out[1]
     assert l0 == l1 == ref_labels                      # every rank holds the single-process trie
     assert abs(t0 - t1) <= 1e-6 * t0 and abs(d0 - d1) <= 1e-6 * max(d0, 1e-12)   # replicas stay identical
-    assert abs(t0 - ref_total) <= 3e-2 * ref_total, (t0, ref_total)
-    assert abs(d0 - ref_delta) <= 5e-2 * ref_delta, (d0, ref_delta)
+    assert abs(t0 - ref_total) <= 2e-4 * ref_total, (t0, ref_total)
+    assert abs(d0 - ref_delta) <= 1e-4 * ref_delta, (d0, ref_delta)
     rel, num, den = {}, 0.0, 0.0
     for k, r in ref.items():
         a, b = g0[k], g1[k]
@@ -113,14 +113,16 @@ def test_two_ranks_equal_one_process():
         if max(n0, n1) < 1e-6:
             continue
         rel[k] = d / n0
-    # float32 summation-order noise between the episode-batched pass and two single-episode passes (see
-    # test_episode_batched_equals_sequential_schedule; split-K and row-sum atomics make it vary run to run, and single
-    # small second-order tensors move by tens of per cent when one clipped element or ReLU kink flips): a missing or
-    # doubled episode would put EVERY tensor off by ~50 % / 100 %.  So: the whole gradient within 3 %, the median tensor
-    # within 2 %, at most 2 % of the tensors beyond 15 %, none beyond 60 %.
+    # float32 summation-order differences between the episode-batched pass and two single-episode passes (other shapes pick
+    # other tiles / splits; then ~50 ReLU layers and the clipped inner step).  Every reduction is ordered, so this is a fixed
+    # number, not a scatter: measured (r3) total norm 3.6e-5, update 2.3e-7, whole gradient 2.0e-4, median tensor 1.1e-4,
+    # worst tensor 9.2e-3 (layer4.2.conv1).  Bounds ~3x above that (round 2, atomics: 3 % whole, 60 % worst); a missing or
+    # doubled episode would put EVERY tensor off by ~50 % / 100 %.
     vals = sorted(rel.values())
-    assert (num / den) ** 0.5 <= 3e-2, (num, den)
-    assert vals[len(vals) // 2] <= 2e-2, vals[len(vals) // 2]
+    print("two ranks vs one process: total norm %.2e, update %.2e, whole gradient %.2e, median tensor %.2e, worst %.2e (%s)"
+          % (abs(t0 - ref_total) / ref_total, abs(d0 - ref_delta) / ref_delta, (num / den) ** 0.5, vals[len(vals) // 2], vals[-1],
+             max(rel.items(), key=lambda kv: kv[1])[0]))
+    assert (num / den) ** 0.5 <= 1e-3, (num, den)
+    assert vals[len(vals) // 2] <= 5e-4, vals[len(vals) // 2]
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    assert sum(v > 1.5e-1 for v in vals) <= max(1, len(vals) // 50), worst
-    assert vals[-1] <= 6e-1, worst
+    assert vals[-1] <= 3e-2, worst

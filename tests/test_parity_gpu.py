@@ -218,6 +218,36 @@ def test_g13_g16_meta_train_step_and_outer_update(golden):
         assert abs(dn - rec["norm"]) <= 2e-2 * max(rec["norm"], 1e-9) + 1e-9, (k, dn, rec["norm"])
 
 
+def test_step_is_bit_reproducible():
+    """Two runs of one meta-train step (train mode: dropout on, same seeds; episode-batched; second-order backward; clip +
+    Adam) from the same state give BIT-identical losses, gradients and updated parameters.  Every sum that spans several
+    workgroups is ordered (split-K partial planes, ticketed column / scalar sums), the flash kernels own their outputs, and
+    autograd accumulates in graph order -- no fp32 atomics are left on the path.  (Round 2: up to 0.7 % per tensor.)"""
+    from interactron_amd import Config, build_model, hipops
+    from interactron_amd.trainer import FlatOuterStep
+    data = to_gpu(synthetic_episodes(2, height=128, width=160, tag="repro"))
+    runs = []
+    for rep in range(2):
+        m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", EPISODE_CHUNK=2)))
+        load_procedural(m.fusion, "fusion.")
+        m = m.cuda().train()
+        outer = FlatOuterStep(m)
+        random.seed(7)
+        hipops.manual_seed(1234)
+        _, losses = m(data)
+        grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+        outer.step()
+        torch.cuda.synchronize()
+        runs.append(({k: v.clone() for k, v in losses.items()}, grads, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    (l0, g0, p0), (l1, g1, p1) = runs
+    for k in l0:
+        assert torch.equal(l0[k], l1[k]), ("loss differs between two runs", k, float(l0[k]), float(l1[k]))
+    bad = [k for k in g0 if (g0[k] is None) != (g1[k] is None) or (g0[k] is not None and not torch.equal(g0[k], g1[k]))]
+    assert not bad, ("gradients differ between two runs of the same step", len(bad), bad[:5])
+    bad = [k for k in p0 if not torch.equal(p0[k], p1[k])]
+    assert not bad, ("updated parameters differ between two runs", len(bad), bad[:5])
+
+
 def test_skipped_gradients_change_nothing_but_the_launch_count():
     """hipops.skip_param_grads: the weight-gradient contractions nobody asked for (nn.Parameters in the MAML inner
     gradient, the per-episode copies in the supervisor backward) are not launched.  Same model, same episodes, with and
@@ -245,27 +275,14 @@ def test_skipped_gradients_change_nothing_but_the_launch_count():
             hipops.SKIP_UNUSED_GRADS = True
     (l1, g1, f1, n1), (l0, g0, f0, n0) = res
     assert n1 < n0 - 50 and f1 < 0.97 * f0, (n1, n0, f1, f0)
+    # The gradients that ARE computed come from the same launches in the same order either way, and every reduction is
+    # ordered: they must be bit-identical (round 2, with split-K atomics: whole gradient within 1 %, single tensors 30 %).
     for k in l0:
-        assert abs(float(l0[k]) - float(l1[k])) <= 1e-4 * max(abs(float(l0[k])), 1.0), k   # (two runs differ by this much)
-    rel, num, den = {}, 0.0, 0.0
+        assert torch.equal(l0[k], l1[k]), (k, float(l0[k]), float(l1[k]))
     for k in g0:
         assert (g0[k] is None) == (g1[k] is None), k
-        if g0[k] is None:
-            continue
-        d, n = float((g0[k] - g1[k]).double().norm()), float(g0[k].double().norm())
-        num, den = num + d * d, den + n * n
-        if n >= 1e-6:   # (else: mathematically zero gradient, rounding noise on both sides)
-            rel[k] = d / n
-    # Two runs of the SAME code differ on single tensors by 1e-3 .. 3e-2 (atomic split-K sums in another order, then ~50
-    # ReLU layers and the clipped inner step; worse on these small 8 x 10-token maps); a dropped term would put its tensor
-    # off by O(1).  So: the whole gradient within 1 %, the median tensor within 0.5 %, at most 2 % of the tensors beyond
-    # 5 %, none beyond 30 %.
-    vals = sorted(rel.values())
-    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    assert (num / den) ** 0.5 <= 1e-2, (num, den, worst)
-    assert vals[len(vals) // 2] <= 5e-3, vals[len(vals) // 2]
-    assert sum(v > 5e-2 for v in vals) <= max(1, len(vals) // 50), worst
-    assert vals[-1] <= 3e-1, worst
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), (k, float((g0[k] - g1[k]).abs().max()), float(g0[k].abs().max()))
 
 
 def test_episode_batched_equals_sequential_schedule():
@@ -304,6 +321,7 @@ def test_episode_batched_equals_sequential_schedule():
         torch.testing.assert_close(p1[k], p0[k], atol=1e-3 * float(p0[k].abs().max()) + 1e-4, rtol=1e-3)
     for k in l0:
         assert abs(float(l0[k]) - float(l1[k])) <= 1e-3 * max(abs(float(l0[k])), 1.0), k
+    rel = {}
     for k in g0:
         assert (g0[k] is None) == (g1[k] is None), k
         if g0[k] is None:
@@ -311,18 +329,26 @@ def test_episode_batched_equals_sequential_schedule():
         n0, n1 = float(g0[k].double().norm()), float(g1[k].double().norm())
         if max(n0, n1) < 1e-6:
             continue
-        # float32 rounding noise through ~50 ReLU layers + the adaptation step reaches ~2 % element-wise on the early
-        # backbone weights between ANY two summation orders (the reference's own float32 is 0.1-0.3 % off float64 on
-        # the norms of these tensors at 300x300, more on the 8x10-token maps used here); a mis-routed episode weight
-        # would show up as O(1) differences
-        # (per tensor 5 % / 15 %: two runs of one binary reach 3 % on single tensors of these small maps; the whole
-        #  gradient is compared below)
-        assert abs(n0 - n1) <= 5e-2 * n0 + 1e-7, (k, n0, n1)
-        assert float((g0[k] - g1[k]).double().norm()) <= 1.5e-1 * n0 + 1e-7, (k, n0, n1)
+        rel[k] = (abs(n0 - n1) / n0, float((g0[k] - g1[k]).double().norm()) / n0)
     have = [k for k in g0 if g0[k] is not None]
     num = sum(float((g0[k] - g1[k]).double().norm()) ** 2 for k in have)
     den = sum(float(g0[k].double().norm()) ** 2 for k in have)
-    assert (num / den) ** 0.5 <= 2e-2, (num, den)
+    worst_n = max(rel.items(), key=lambda kv: kv[1][0])
+    worst_d = max(rel.items(), key=lambda kv: kv[1][1])
+    vals = sorted(v[1] for v in rel.values())
+    print("batched vs sequential: whole gradient %.2e, median tensor %.2e, worst norm %.2e (%s), worst difference %.2e (%s)"
+          % ((num / den) ** 0.5, vals[len(vals) // 2], worst_n[1][0], worst_n[0], worst_d[1][1], worst_d[0]))
+    # Two different summation orders (batched vs per-episode shapes pick other tiles / splits) through ~50 ReLU layers and the
+    # clipped inner step: deterministic now, so the bounds sit 3x above what this comparison measures (printed above) instead
+    # of above the run-to-run scatter of the atomics (round 2: 5 % / 15 % per tensor).  A mis-routed episode weight is O(1).
+    assert (num / den) ** 0.5 <= BATCHED_WHOLE, (num, den)
+    assert vals[len(vals) // 2] <= BATCHED_MEDIAN, vals[len(vals) // 2]
+    assert worst_n[1][0] <= BATCHED_WORST_NORM, worst_n
+    assert worst_d[1][1] <= BATCHED_WORST_DIFF, worst_d
+
+
+# measured (r3, deterministic): whole 8.4e-4, median 3.8e-4, worst norm 3.1e-3, worst difference 4.3e-2 (layer4.1.conv1)
+BATCHED_WHOLE, BATCHED_MEDIAN, BATCHED_WORST_NORM, BATCHED_WORST_DIFF = 3e-3, 1.5e-3, 1e-2, 1.2e-1
 
 
 def test_batched_predict_equals_per_episode_predict():
