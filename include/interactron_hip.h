@@ -281,6 +281,36 @@ int ix_match_cost_f32(const float* logits, const float* boxes, const int64_t* tg
                       float* cost, int rows, int C, int T, float w_class, float w_bbox, float w_giou,
                       ix_stream_t stream);
 int ix_lsap_f32(const float* cost_host, int64_t nr, int64_t nc, int64_t* row_idx_host, int64_t* col_idx_host);
+
+/* Device-resident matcher + set criterion of a whole chunk of images (no host round trip, no per-image launches).
+ * Targets of all images as one CSR list: tgt_ids int64 [T], tgt_boxes [T, 4] cxcywh, off int32 [I + 1] (image i owns targets
+ * off[i] .. off[i + 1]).
+ *   ix_match_cost_csr_f32   cost [I, Q, ldn] = the matrices of matcher.py:54-73 for every image, column t = the image's t-th
+ *                           target (same arithmetic as ix_match_cost_f32)
+ *   ix_lsap_device_f32      scipy.optimize.linear_sum_assignment per image (matcher.py:76) on the GPU, one wavefront per image,
+ *                           the algorithm, double arithmetic and tie-breaking of ix_lsap_f32: identical assignments.
+ *                           tgt_of_q int32 [I, Q]: image-local target matched to query q or -1; q_of_tgt int32 [T]: query
+ *                           matched to target t or -1.  Sides (Q, targets per image, ldn) up to 256.
+ *   ix_set_loss_rows_f32    per prediction row: rowstat [I*Q, 4] = (w nll, w, L1, 1 - GIoU), lse [I*Q], flags int32 [I*Q]
+ *                           (detr.py:111-167; w = 1, w_noobj for the no-object class = `background_c` of interactron.py:103)
+ *   ix_set_loss_groups_f32  group g = images g*stride .. g*stride + len - 1: out[g] = (loss_ce, class_error, loss_bbox,
+ *                           loss_giou, cardinality_error) with the group's own normalisers norm[g] = (sum w, max(#targets, 1))
+ *                           (detr.py:220-265 evaluated once per group: the 5 frames of an episode, frame 0 alone for the policy
+ *                           reward, one frame for the detector loss -- interactron.py:101-108,128-131); ordered sums
+ *   ix_set_loss_bwd_f32     d(sum_g gout[g] . out[g]) / d(logits, boxes); images outside every group get zeros */
+int ix_match_cost_csr_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes, const int* off,
+                          float* cost, int I, int Q, int C, int ldn, float w_class, float w_bbox, float w_giou,
+                          ix_stream_t stream);
+int ix_lsap_device_f32(const float* cost, const int* off, int I, int Q, int ldn, int* tgt_of_q, int* q_of_tgt,
+                       ix_stream_t stream);
+int ix_set_loss_rows_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes, const int* off,
+                         const int* tgt_of_q, float* rowstat, float* lse, int* flags, int I, int Q, int C, float w_noobj,
+                         ix_stream_t stream);
+int ix_set_loss_groups_f32(const float* rowstat, const int* flags, const int* off, int stride, int len, int G, int Q, float* out,
+                           float* norm, ix_stream_t stream);
+int ix_set_loss_bwd_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes, const int* off,
+                        const int* tgt_of_q, const float* lse, const float* gout, const float* norm, int stride, int len, int I,
+                        int Q, int C, float w_noobj, float* dlogits, float* dboxes, ix_stream_t stream);
 int ix_weighted_ce_fwd_f32(const float* logits, const int64_t* target, const float* weight, float* lse,
                            int64_t* argmax, float* sums, int rows, int C, void* workspace, size_t workspace_bytes,
                            ix_stream_t stream);

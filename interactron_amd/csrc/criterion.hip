@@ -323,6 +323,389 @@ extern "C" int ix_box_loss_bwd_f32(const float* pred, const int64_t* src_idx, co
     return IX_OK;
 }
 
+// ======================================================================================================================
+// Device-resident set criterion: targets of all images as one CSR list, the Hungarian assignment solved on the GPU, the
+// losses of many (image-)groups from one pass.  The reference evaluates SetCriterion once per task and per frame subset
+// (models/interactron.py:101-108,128-131: the 5 supervised frames of an episode, frame 0 again for the policy reward, one
+// random frame for the detector loss) with a host LSAP in the middle (matcher.py:73-76); here one chunk of episodes is one
+// cost launch, one assignment launch and three loss launches, nothing leaves the device.
+//   tgt_ids int64 [T], tgt_boxes [T, 4], off int32 [I + 1]: image i owns targets off[i] .. off[i + 1]
+// ======================================================================================================================
+__global__ __launch_bounds__(256) void match_cost_csr_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                             const int64_t* __restrict__ tgt_ids,
+                                                             const float* __restrict__ tgt_boxes, const int* __restrict__ off,
+                                                             float* __restrict__ cost, int rows, int Q, int C, int ldn,
+                                                             float w_class, float w_bbox, float w_giou) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int img = row / Q, t0 = off[img], n = off[img + 1] - t0;
+    if (n <= 0) return;
+    const float* lr = logits + (int64_t)row * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lr[c]);
+    mx = ix_wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(lr[c] - mx);
+    s = ix_wave_sum(s);
+    const float* pb = boxes + (int64_t)row * 4;
+    const Box a = to_xyxy(pb);
+    for (int t = lane; t < n && t < ldn; t += 64) {
+        const float* tb = tgt_boxes + (int64_t)(t0 + t) * 4;
+        const float prob = __expf(lr[tgt_ids[t0 + t]] - mx) / s;
+        const float l1 = fabsf(pb[0] - tb[0]) + fabsf(pb[1] - tb[1]) + fabsf(pb[2] - tb[2]) + fabsf(pb[3] - tb[3]);
+        const Box b = to_xyxy(tb);
+        cost[(int64_t)row * ldn + t] = w_bbox * l1 + w_class * (-prob) + w_giou * (-giou_xyxy(a, b));
+    }
+}
+
+// cost [I, Q, ldn] (row (img, q), column = the image's t-th target); same arithmetic as ix_match_cost_f32
+extern "C" int ix_match_cost_csr_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes,
+                                     const int* off, float* cost, int I, int Q, int C, int ldn, float w_class, float w_bbox,
+                                     float w_giou, hipStream_t stream) {
+    const int rows = I * Q;
+    if (rows <= 0 || ldn <= 0) return IX_OK;
+    IX_CHECK_ARG(logits && boxes && tgt_ids && tgt_boxes && off && cost && C > 0, "ix_match_cost_csr_f32: bad args");
+    hipLaunchKernelGGL(match_cost_csr_kernel, dim3(ix_div_up(rows, 4)), dim3(256), 0, stream, logits, boxes, tgt_ids, tgt_boxes,
+                       off, cost, rows, Q, C, ldn, w_class, w_bbox, w_giou);
+    IX_CHECK_LAUNCH("ix_match_cost_csr_f32");
+    return IX_OK;
+}
+
+// ---- rectangular assignment on the device: one wavefront per image ---------------------------------------------------
+// The algorithm and its tie-breaking are those of csrc/lsap.cpp (Crouse's shortest augmenting path = scipy's
+// linear_sum_assignment, reference matcher.py:76), in the same double arithmetic, so the assignments are the host's bit for
+// bit: rows = the smaller side (transposed like scipy when there are fewer targets than queries), the Dijkstra scan over
+// the remaining columns runs across the lanes (position `it` of the `remaining` list per lane, 64 at a time) and the
+// scan-order rule "a strictly smaller path cost wins; among equal costs the LAST unassigned column, else the FIRST column"
+// is evaluated with wave reductions.  Sides up to LSAP_MAX.
+#define LSAP_MAX 256
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost, const int* __restrict__ off, int Q, int ldn,
+                                                  int* __restrict__ tgt_of_q, int* __restrict__ q_of_tgt) {
+    __shared__ double u[LSAP_MAX], v[LSAP_MAX], shortest[LSAP_MAX];
+    __shared__ int path[LSAP_MAX], col4row[LSAP_MAX], row4col[LSAP_MAX], remaining[LSAP_MAX];
+    __shared__ unsigned char SR[LSAP_MAX], SC[LSAP_MAX];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int t0 = off[img], n = off[img + 1] - t0;
+    int* toq = tgt_of_q + (int64_t)img * Q;
+    for (int q = lane; q < Q; q += 64) toq[q] = -1;
+    for (int t = lane; t < n; t += 64) q_of_tgt[t0 + t] = -1;
+    if (n <= 0) return;
+    const float* cm = cost + (int64_t)img * Q * ldn;
+    const bool tr = n < Q;                       // rows = targets, columns = queries
+    const int nr = tr ? n : Q, nc = tr ? Q : n;
+#define COST(i, j) ((double)(tr ? cm[(int64_t)(j) * ldn + (i)] : cm[(int64_t)(i) * ldn + (j)]))
+    for (int k = lane; k < nr; k += 64) { u[k] = 0.0; col4row[k] = -1; }
+    for (int k = lane; k < nc; k += 64) { v[k] = 0.0; row4col[k] = -1; path[k] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int k = lane; k < nc; k += 64) { remaining[k] = nc - k - 1; shortest[k] = INFINITY; SC[k] = 0; }
+        for (int k = lane; k < nr; k += 64) SR[k] = 0;
+        __syncthreads();
+        double min_val = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            double lowest = INFINITY;
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                const double r = min_val + COST(i, j) - ui - v[j];
+                if (r < shortest[j]) {
+                    path[j] = i;
+                    shortest[j] = r;
+                }
+                const double sj = shortest[j];
+                lowest = sj < lowest ? sj : lowest;
+            }
+            lowest = wave_min_f64(lowest);
+            // the sequential scan keeps the first position holding the minimum unless a later minimum-valued column is
+            // unassigned -- then the last such one
+            int p0 = 0x7fffffff, um = -1;
+            for (int it = lane; it < num_remaining; it += 64) {
+                const int j = remaining[it];
+                if (shortest[j] == lowest) {
+                    p0 = min(p0, it);
+                    if (row4col[j] == -1) um = max(um, it);
+                }
+            }
+            p0 = wave_min_i32(p0);
+            um = wave_max_i32(um);
+            if (p0 == 0x7fffffff) {   // no finite path cost (NaN / inf costs): leave this row unmatched instead of spinning
+                sink = -2;
+                break;
+            }
+            const int index = um > p0 ? um : p0;
+            min_val = lowest;
+            const int j = remaining[index];
+            const int r4c = row4col[j];
+            __syncthreads();
+            if (r4c == -1) sink = j; else i = r4c;
+            if (lane == 0) {
+                SC[j] = 1;
+                remaining[index] = remaining[num_remaining - 1];
+            }
+            --num_remaining;
+            __syncthreads();
+        }
+        if (sink < 0) {
+            __syncthreads();
+            continue;
+        }
+        // dual updates
+        for (int k = lane; k < nr; k += 64) {
+            if (k == cur) u[k] += min_val;
+            else if (SR[k]) u[k] += min_val - shortest[col4row[k]];
+        }
+        for (int k = lane; k < nc; k += 64)
+            if (SC[k]) v[k] -= min_val - shortest[k];
+        __syncthreads();
+        if (lane == 0) {   // augment along the path
+            int j = sink;
+            while (true) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int jn = col4row[ii];
+                col4row[ii] = j;
+                j = jn;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+#undef COST
+    if (tr) {   // rows = targets
+        for (int t = lane; t < n; t += 64) {
+            const int q = col4row[t];
+            q_of_tgt[t0 + t] = q;
+            if (q >= 0) toq[q] = t;
+        }
+    } else {    // rows = queries
+        for (int q = lane; q < Q; q += 64) {
+            const int t = col4row[q];
+            toq[q] = t;
+            if (t >= 0) q_of_tgt[t0 + t] = q;
+        }
+    }
+}
+
+// tgt_of_q int32 [I, Q]: the image-local target index matched to query q, or -1; q_of_tgt int32 [T]: the query matched to
+// target t (CSR position), or -1 (more targets than queries).  max(Q, targets per image) <= 256 -- the caller checks.
+extern "C" int ix_lsap_device_f32(const float* cost, const int* off, int I, int Q, int ldn, int* tgt_of_q, int* q_of_tgt,
+                                  hipStream_t stream) {
+    if (I <= 0) return IX_OK;
+    IX_CHECK_ARG(cost && off && tgt_of_q && q_of_tgt && Q > 0 && Q <= LSAP_MAX && ldn >= 0 && ldn <= LSAP_MAX,
+                 "ix_lsap_device_f32: bad args (sides up to %d)", LSAP_MAX);
+    hipLaunchKernelGGL(lsap_kernel, dim3(I), dim3(64), 0, stream, cost, off, Q, ldn, tgt_of_q, q_of_tgt);
+    IX_CHECK_LAUNCH("ix_lsap_device_f32");
+    return IX_OK;
+}
+
+// ---- losses ---------------------------------------------------------------------------------------------------------
+// Pass 1, one wave per prediction row (img, q): log-sum-exp, arg-max, target class (matched label or no-object), the weighted
+// NLL, and for matched rows the L1 / (1 - GIoU) terms.  rowstat [rows, 4] = (w * nll, w, l1, 1 - giou); flags: bit 0 matched,
+// bit 1 arg-max == label (matched rows), bit 2 arg-max != no-object.
+__global__ __launch_bounds__(256) void set_loss_rows_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                            const int64_t* __restrict__ tgt_ids,
+                                                            const float* __restrict__ tgt_boxes, const int* __restrict__ off,
+                                                            const int* __restrict__ tgt_of_q, float* __restrict__ rowstat,
+                                                            float* __restrict__ lse, int* __restrict__ flags, int rows, int Q,
+                                                            int C, float w_noobj) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* lr = logits + (int64_t)row * C;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = lane; c < C; c += 64) {
+        const float x = lr[c];
+        if (x > mx) {
+            mx = x;
+            am = c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(am, o, 64);
+        if (ov > mx || (ov == mx && oi < am)) {
+            mx = ov;
+            am = oi;
+        }
+    }
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += __expf(lr[c] - mx);
+    s = ix_wave_sum(s);
+    if (lane == 0) {
+        const int img = row / Q, t = tgt_of_q[row];
+        const float l = mx + __logf(s);
+        int64_t cls = C - 1;
+        float l1 = 0.f, gl = 0.f;
+        int f = (am != C - 1) ? 4 : 0;
+        if (t >= 0) {
+            const int g = off[img] + t;
+            cls = tgt_ids[g];
+            const float* p = boxes + (int64_t)row * 4;
+            const float* tb = tgt_boxes + (int64_t)g * 4;
+            l1 = fabsf(p[0] - tb[0]) + fabsf(p[1] - tb[1]) + fabsf(p[2] - tb[2]) + fabsf(p[3] - tb[3]);
+            gl = 1.f - giou_xyxy(to_xyxy(p), to_xyxy(tb));
+            f |= 1 | (am == cls ? 2 : 0);
+        }
+        const float w = cls == C - 1 ? w_noobj : 1.f;
+        float* rs = rowstat + (int64_t)row * 4;
+        rs[0] = w * (l - lr[cls]);
+        rs[1] = w;
+        rs[2] = l1;
+        rs[3] = gl;
+        lse[row] = l;
+        flags[row] = f;
+    }
+}
+
+// Pass 2, one workgroup per group g = images g * stride .. g * stride + len - 1: ordered sums over the group's rows ->
+// out[g] = (loss_ce, class_error, loss_bbox, loss_giou, cardinality_error), norm[g] = (sum of class weights, num_boxes)
+// (reference detr.py:111-167,238-242: weighted mean NLL; 100 - top-1 accuracy over the matched rows; L1 and (1 - GIoU)
+//  sums over matched pairs / max(number of targets, 1); mean over images of |#non-empty predictions - #targets|).
+__global__ __launch_bounds__(256) void set_loss_groups_kernel(const float* __restrict__ rowstat, const int* __restrict__ flags,
+                                                              const int* __restrict__ off, int stride, int len, int Q,
+                                                              float* __restrict__ out, float* __restrict__ norm) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, i0 = g * stride;
+    const int r0 = i0 * Q, nrows = len * Q;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    float matched = 0.f, correct = 0.f;
+    for (int r = threadIdx.x; r < nrows; r += 256) {
+        const float* rs = rowstat + (int64_t)(r0 + r) * 4;
+        a[0] += rs[0]; a[1] += rs[1]; a[2] += rs[2]; a[3] += rs[3];
+        const int f = flags[r0 + r];
+        matched += (f & 1) ? 1.f : 0.f;
+        correct += (f & 2) ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = ix_block_sum_256(a[k], red);
+    matched = ix_block_sum_256(matched, red);
+    correct = ix_block_sum_256(correct, red);
+    // cardinality: per image |#predictions that are not no-object - #targets|
+    float card = 0.f;
+    for (int im = 0; im < len; ++im) {
+        float c = 0.f;
+        for (int q = threadIdx.x; q < Q; q += 256) c += (flags[(i0 + im) * Q + q] & 4) ? 1.f : 0.f;
+        c = ix_block_sum_256(c, red);
+        card += fabsf(c - (float)(off[i0 + im + 1] - off[i0 + im]));
+    }
+    if (threadIdx.x == 0) {
+        const float nb = fmaxf((float)(off[i0 + len] - off[i0]), 1.f);
+        float* o = out + (int64_t)g * 5;
+        o[0] = a[0] / a[1];
+        o[1] = 100.f - (matched > 0.f ? correct * (100.f / matched) : 0.f);
+        o[2] = a[2] / nb;
+        o[3] = a[3] / nb;
+        o[4] = card / (float)len;
+        norm[g * 2] = a[1];
+        norm[g * 2 + 1] = nb;
+    }
+}
+
+extern "C" int ix_set_loss_rows_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes,
+                                    const int* off, const int* tgt_of_q, float* rowstat, float* lse, int* flags, int I, int Q,
+                                    int C, float w_noobj, hipStream_t stream) {
+    const int rows = I * Q;
+    if (rows <= 0) return IX_OK;
+    IX_CHECK_ARG(logits && boxes && off && tgt_of_q && rowstat && lse && flags && C > 1, "ix_set_loss_rows_f32: bad args");
+    hipLaunchKernelGGL(set_loss_rows_kernel, dim3(ix_div_up(rows, 4)), dim3(256), 0, stream, logits, boxes, tgt_ids, tgt_boxes, off,
+                       tgt_of_q, rowstat, lse, flags, rows, Q, C, w_noobj);
+    IX_CHECK_LAUNCH("ix_set_loss_rows_f32");
+    return IX_OK;
+}
+
+extern "C" int ix_set_loss_groups_f32(const float* rowstat, const int* flags, const int* off, int stride, int len, int G, int Q,
+                                      float* out, float* norm, hipStream_t stream) {
+    if (G <= 0) return IX_OK;
+    IX_CHECK_ARG(rowstat && flags && off && out && norm && stride >= 1 && len >= 1 && len <= stride && Q > 0,
+                 "ix_set_loss_groups_f32: bad args");
+    hipLaunchKernelGGL(set_loss_groups_kernel, dim3(G), dim3(256), 0, stream, rowstat, flags, off, stride, len, Q, out, norm);
+    IX_CHECK_LAUNCH("ix_set_loss_groups_f32");
+    return IX_OK;
+}
+
+// Backward of out[g, (0, 2, 3)] w.r.t. logits and boxes (class_error / cardinality carry no gradient):
+//   dlogits[r, c] = gout[g, 0] * w_r / W_g * (softmax(x_r)[c] - [c == cls_r])
+//   dboxes[r]     = gout[g, 2] / nb_g * sign(p - t) - gout[g, 3] / nb_g * dGIoU/dp      (matched rows; else 0)
+// rows of images outside every group (image index % stride >= len) get zeros.
+__global__ void set_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                    const int64_t* __restrict__ tgt_ids, const float* __restrict__ tgt_boxes,
+                                    const int* __restrict__ off, const int* __restrict__ tgt_of_q, const float* __restrict__ lse,
+                                    const float* __restrict__ gout, const float* __restrict__ norm, int stride, int len, int Q,
+                                    int C, float w_noobj, float* __restrict__ dlogits, float* __restrict__ dboxes, int64_t total) {
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += gs) {
+        const int row = (int)(k / C), c = (int)(k % C);
+        const int img = row / Q, g = img / stride;
+        const bool in = img - g * stride < len;
+        const int t = tgt_of_q[row];
+        int64_t cls = C - 1;
+        if (t >= 0) cls = tgt_ids[off[img] + t];
+        float d = 0.f;
+        if (in) {
+            const float w = cls == C - 1 ? w_noobj : 1.f;
+            const float p = __expf(logits[k] - lse[row]);
+            d = gout[g * 5] / norm[g * 2] * w * (p - (c == cls ? 1.f : 0.f));
+        }
+        dlogits[k] = d;
+        if (c == 0) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            if (in && t >= 0) {
+                const float* p = boxes + (int64_t)row * 4;
+                const float* tb = tgt_boxes + (int64_t)(off[img] + t) * 4;
+                const float g_l1 = gout[g * 5 + 2] / norm[g * 2 + 1], g_gi = gout[g * 5 + 3] / norm[g * 2 + 1];
+                float gg[4];
+                giou_grad(p, tb, gg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float df = p[j] - tb[j];
+                    const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                    o[j] = g_l1 * sg - g_gi * gg[j];
+                }
+            }
+            float* ob = dboxes + (int64_t)row * 4;
+            ob[0] = o[0]; ob[1] = o[1]; ob[2] = o[2]; ob[3] = o[3];
+        }
+    }
+}
+
+extern "C" int ix_set_loss_bwd_f32(const float* logits, const float* boxes, const int64_t* tgt_ids, const float* tgt_boxes,
+                                   const int* off, const int* tgt_of_q, const float* lse, const float* gout, const float* norm,
+                                   int stride, int len, int I, int Q, int C, float w_noobj, float* dlogits, float* dboxes,
+                                   hipStream_t stream) {
+    const int64_t total = (int64_t)I * Q * C;
+    if (total <= 0) return IX_OK;
+    IX_CHECK_ARG(logits && boxes && off && tgt_of_q && lse && gout && norm && dlogits && dboxes && stride >= 1 && len >= 1,
+                 "ix_set_loss_bwd_f32: bad args");
+    hipLaunchKernelGGL(set_loss_bwd_kernel, dim3(ix_grid_1d(total, 256)), dim3(256), 0, stream, logits, boxes, tgt_ids, tgt_boxes,
+                       off, tgt_of_q, lse, gout, norm, stride, len, Q, C, w_noobj, dlogits, dboxes, total);
+    IX_CHECK_LAUNCH("ix_set_loss_bwd_f32");
+    return IX_OK;
+}
+
 // ---- sine position embedding (position_encoding.py:28-48, num_pos_feats=128, normalize=True) ------------------
 // mask uint8 [n,h,w] (1 = padded) -> pos [n, h*w, 256] token-major (channel fastest): channels 0..127 from y, 128..255 from x
 __global__ void sine_pos_kernel(const uint8_t* __restrict__ mask, float* __restrict__ pos, int n, int h, int w,

@@ -69,6 +69,33 @@ def _weighted(l):
     return l["loss_ce"] + 5 * l["loss_giou"] + 2 * l["loss_bbox"]
 
 
+_const = {}
+
+
+def _loss_weights(E, device):
+    """[E, 5] constant that turns grouped criterion rows (loss_ce, class_error, loss_bbox, loss_giou, cardinality_error) into
+    sum_e loss_ce + 5 loss_giou + 2 loss_bbox (reference interactron.py:119: the weights of `_weighted`)"""
+    key = ("w", E, device.index)
+    if key not in _const:
+        _const[key] = torch.tensor([1.0, 0.0, 2.0, 5.0, 0.0], device=device).repeat(E, 1).contiguous()
+    return _const[key]
+
+
+def _ones(n, device):
+    key = ("1", n, device.index)
+    if key not in _const:
+        _const[key] = torch.ones(n, device=device)
+    return _const[key]
+
+
+def _weighted_rows(rows):
+    return rows[:, 0] + 5 * rows[:, 3] + 2 * rows[:, 2]
+
+
+def _named_means(criterion, row, tag):
+    return {k.replace("loss", tag): v for k, v in criterion.as_dict(row).items()}
+
+
 def _mean_losses(per_task, tag):
     return {k.replace("loss", tag): torch.mean(torch.stack([x[k] for x in per_task])) for k in per_task[0]}
 
@@ -218,7 +245,7 @@ class _Adaptive(_EpisodeModel):
             return self._forward_sequential(data)
         b, s, c, w, h = data["frames"].shape
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
-        det_losses, sup_losses, logits_out, boxes_out = [], [], [], []
+        det_out, sup_out, path_out, reward_out, logits_out, boxes_out = [], [], [], [], [], []
         self._theta = theta = self._real_parameters()
         targets2 = self._second_order_targets()
         lr = self.config.ADAPTIVE_LR
@@ -230,15 +257,17 @@ class _Adaptive(_EpisodeModel):
                 ep = range(e0, e0 + E)
                 labels = [_labels(data, t) for t in ep]
                 frames, masks = img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)
+                # the first-order branch's random frame per episode (reference :126) and both target lists: drawn, packed
+                # and uploaded before anything is queued
+                ridx = [random.randint(0, 4) for _ in ep]
+                tg = ops.pack_targets([lab for ep_labels in labels for lab in ep_labels])
+                tg1 = ops.pack_targets([labels[i][ridx[i]] for i in range(E)])
                 # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
                 dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
                 set_parameters(self.detector, dtheta)
                 # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
                 nt = NestedTensor(frames, masks)
                 nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
-                # the first-order branch's random frame per episode (reference :126): drawn and uploaded before anything
-                # is queued -- a blocking upload later would make the host sit out the whole queue
-                ridx = [random.randint(0, 4) for _ in ep]
                 sel = ops.h2d_async(torch.tensor([i * s + r for i, r in enumerate(ridx)]))
                 pre = self.detector(nt)
                 pt.mark("1 detector fwd (theta)")
@@ -252,16 +281,25 @@ class _Adaptive(_EpisodeModel):
                 set_parameters(self.detector, sgd_step(dtheta, grads, lr))
                 post = self.detector(nt)
                 pt.mark("4 inner SGD + detector fwd (theta')")
-                actions_out = fusion_out["actions"].reshape(E, 4, 4)
-                # ONE matcher pass for the whole chunk (matching is per image, so the assignments are exactly those of
-                # per-episode calls): one cost kernel + one asynchronous D2H instead of 2-3 host syncs per episode.
+                actions_out = fusion_out["actions"].reshape(E * 4, 4)
+                # Matcher + criterion of the whole chunk on the device (criterion.py): one cost launch and one assignment
+                # launch for all E * s images (matching is per image, so the assignments are exactly those of per-episode
+                # calls), then the losses of every episode's 5 frames AND of its frame 0 alone (the policy reward, reference
+                # :104-108) from one pass over the rows.
                 post_lb = {k: post[k] for k in ("pred_logits", "pred_boxes")}
-                match = self.criterion.matcher.begin(post_lb, [lab for ep_labels in labels for lab in ep_labels])
+                toq = self.criterion.matcher.match(post_lb, tg)
+                specs = ((s, s), (s, 1)) if self.use_policy else ((s, s),)
+                sup_rows = self.criterion.grouped(post_lb, tg, toq, specs, background_c=0.1)
+                if self.use_policy:   # frame-0 loss = the reward PathStorage ranks action sequences by: its D2H copy starts now
+                    gts = _weighted_rows(sup_rows[1])
+                    gts_host = torch.empty(E, dtype=torch.float32, pin_memory=True)
+                    gts_host.copy_(gts, non_blocking=True)
+                    gts_ready = torch.cuda.Event()
+                    gts_ready.record()
 
                 # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient,
-                # not on the criterion: its forward is queued NOW, so that the GPU works on it while the host runs the
-                # Hungarian assignment and builds the criterion.  The expansion of theta is differentiable; its backward
-                # sums the per-episode gradients into theta.grad.
+                # not on the criterion.  The expansion of theta is differentiable; its backward sums the per-episode
+                # gradients into theta.grad.
                 attached = list(ops.ExpandEpisodes.apply(E, *theta))
                 fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
                 set_parameters(self.detector, fast1)
@@ -269,65 +307,53 @@ class _Adaptive(_EpisodeModel):
                 nt1.stem = nt.stem[sel]
                 post1 = self.detector(nt1)
                 post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
-                match1 = self.criterion.matcher.begin(post1_lb, [labels[i][ridx[i]] for i in range(E)])
-                pt.mark("5 first-order SGD + 1-frame fwd (queued early)")
+                toq1 = self.criterion.matcher.match(post1_lb, tg1)
+                (det_rows,) = self.criterion.grouped(post1_lb, tg1, toq1, ((1, 1),), background_c=0.1)
+                pt.mark("5 criterion + first-order SGD + 1-frame fwd")
 
-                idx_all = self.criterion.matcher.finish(match)
-                sups, gts = [], []
-                for i, t in enumerate(ep):
-                    post_t = {k: v[i * s:(i + 1) * s] for k, v in post_lb.items()}
-                    idx = idx_all[i * s:(i + 1) * s]
-                    sups.append(self.criterion(post_t, labels[i], background_c=0.1, indices=idx))
-                    if self.use_policy:   # frame-0 loss = the reward PathStorage ranks action sequences by
-                        first = {k: v[[0]] for k, v in post_t.items()}
-                        gts.append(_weighted(self.criterion(first, [labels[i][0]], background_c=0.1, indices=idx[:1])))
-                rewards = torch.stack(gts).tolist() if self.use_policy else None   # one D2H for all episodes
-                total = None
-                if self.use_policy:   # PathStorage bookkeeping on the host, in episode order; ONE upload of the labels
+                total = ops.Dot.apply(sup_rows[0], _loss_weights(E, frames.device))
+                if self.use_policy:   # PathStorage bookkeeping on the host, in episode order: the step's ONE host round trip
+                    gts_ready.synchronize()   # (the GPU still has the first-order forward queued behind the copy)
+                    rewards = gts_host.tolist()
                     if "dp_index" in data:   # data parallel: replay the global batch's chunk (see _dp_chunk_labels)
                         best_host = self._dp_chunk_labels(data, e0 // chunk, chunk, list(ep), rewards)
                     else:
                         best_host = best_path_labels(self.path_storage, [data["initial_image_path"][t] for t in ep],
                                                      [actions_host[t][:4] for t in ep], rewards)
-                    best_all = ops.h2d_async(torch.tensor(best_host, dtype=torch.long))
-                    weight = torch.ones(4, device=frames.device)
-                for i, t in enumerate(ep):
-                    sup = sups[i]
-                    if self.use_policy:
-                        sup["loss_path"], _ = ops.WeightedCE.apply(actions_out[i], best_all[i], weight)
-                        sup["policy_reward"] = gts[i]
-                    sup_losses.append({k: v.detach() for k, v in sup.items()})
-                    tl = _weighted(sup) + (sup["loss_path"] if self.use_policy else 0)
-                    total = tl if total is None else total + tl
-                pt.mark("6 criterion + matcher + path storage")
+                    best_all = ops.h2d_async(torch.tensor(best_host, dtype=torch.long).reshape(E * 4))
+                    # sum over episodes of F.cross_entropy(actions[4, 4], best_path[4]) (reference :116-118) = E x the mean
+                    # over all E * 4 rows (equal rows per episode, unit class weights)
+                    path_ce, _ = ops.WeightedCE.apply(actions_out, best_all, _ones(4, frames.device))
+                    total = total + path_ce * float(E)
+                    path_out.append(path_ce.detach().reshape(1).expand(E))
+                    reward_out.append(gts)
+                sup_out.append(sup_rows[0].detach())
+                pt.mark("6 path storage (host) + policy loss")
                 # (the supervisor backward ends in the fusion parameters and the in_proj blocks; nothing keeps a gradient of
                 #  the per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
                 with ops.skip_param_grads(frozenset(id(t) for t in dtheta)):
                     torch.autograd.backward(total, inputs=targets2)
-                del grads, dtheta, fusion_out, pre, post, post_lb, sups, gts, sup, total, tl, loss_map, learned, actions_out
-
-                # criterion of the first-order branch: host work that overlaps the second-order backward on the GPU
-                idx1 = self.criterion.matcher.finish(match1)
-                total = None
-                for i, t in enumerate(ep):
-                    post_t = {k: v[i:i + 1] for k, v in post1_lb.items()}
-                    dl = self.criterion(post_t, labels[i][ridx[i]:ridx[i] + 1], background_c=0.1, indices=idx1[i:i + 1])
-                    det_losses.append({k: v.detach() for k, v in dl.items()})
-                    total = _weighted(dl) if total is None else total + _weighted(dl)
-                    logits_out.append(post_t["pred_logits"].detach())
-                    boxes_out.append(post_t["pred_boxes"].detach())
-                pt.mark("7 second-order backward (+ 1-frame criterion on the host)")
-                total.backward()
+                del grads, dtheta, fusion_out, pre, post, post_lb, sup_rows, total, loss_map, learned, actions_out
+                pt.mark("7 second-order backward")
+                det_out.append(det_rows.detach())
+                logits_out.append(post1_lb["pred_logits"].detach().unsqueeze(1))
+                boxes_out.append(post1_lb["pred_boxes"].detach().unsqueeze(1))
+                ops.Dot.apply(det_rows, _loss_weights(E, frames.device)).backward()
                 pt.mark("8 first-order backward")
-                del attached, fast1, post1, total
+                del attached, fast1, post1, det_rows
             if self.use_policy and "dp_index" in data:   # chunks this rank has no episodes in: still part of the exchange
                 for c in range((b + chunk - 1) // chunk, self._dp_chunks(data, chunk)):
                     self._dp_chunk_labels(data, c, chunk, [], [])
         finally:
             set_parameters(self.detector, theta)
-        predictions = {"pred_logits": torch.stack(logits_out, dim=0), "pred_boxes": torch.stack(boxes_out, dim=0)}
-        losses = _mean_losses(det_losses, "loss_detector")
-        losses.update(_mean_losses(sup_losses, "loss_supervisor"))
+        predictions = {"pred_logits": torch.cat(logits_out, dim=0), "pred_boxes": torch.cat(boxes_out, dim=0)}
+        # the reference's loss dict: per-task criterion dicts averaged over the tasks of the batch (:139-150)
+        losses = _named_means(self.criterion, torch.cat(det_out).mean(0), "loss_detector")
+        sup = _named_means(self.criterion, torch.cat(sup_out).mean(0), "loss_supervisor")
+        if self.use_policy:
+            sup["loss_supervisor_path"] = torch.cat(path_out).mean()
+            sup["policy_reward"] = torch.cat(reward_out).mean()
+        losses.update(sup)
         return predictions, losses
 
     # ---- PathStorage under data parallelism ----------------------------------------------------------------------
@@ -550,23 +576,23 @@ class detr_multiframe(_EpisodeModel):
                 losses.append({k: v.detach() for k, v in loss.items()})
                 lo.append(out["pred_logits"][0:1].detach())
                 bo.append(out["pred_boxes"][0:1].detach())
+        rows_out = []
         for e0 in range(0, b if chunk > 0 else 0, max(chunk, 1)):
             E = min(chunk, b - e0)
-            labels = [_labels(data, t) for t in range(e0, e0 + E)]
+            tg = ops.pack_targets([lab for t in range(e0, e0 + E) for lab in _labels(data, t)])
             det = self.detector(NestedTensor(img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)))
             out = self.fusion({k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in det.items()})
-            logits = out["pred_logits"].reshape(E * s, *out["pred_logits"].shape[-2:])
-            boxes = out["pred_boxes"].reshape(E * s, *out["pred_boxes"].shape[-2:])
-            idx = self.criterion.matcher({"pred_logits": logits, "pred_boxes": boxes}, [l for ep in labels for l in ep])
-            total = None
-            for i in range(E):
-                o = {"pred_logits": logits[i * s:(i + 1) * s], "pred_boxes": boxes[i * s:(i + 1) * s]}
-                loss = self.criterion(o, labels[i], background_c=0.1, indices=idx[i * s:(i + 1) * s])
-                total = _weighted(loss) if total is None else total + _weighted(loss)
-                losses.append({k: v.detach() for k, v in loss.items()})
-                lo.append(o["pred_logits"][0:1].detach())
-                bo.append(o["pred_boxes"][0:1].detach())
-            total.backward()
+            o = {"pred_logits": out["pred_logits"].reshape(E * s, *out["pred_logits"].shape[-2:]),
+                 "pred_boxes": out["pred_boxes"].reshape(E * s, *out["pred_boxes"].shape[-2:])}
+            # matcher + per-episode criteria of the chunk on the device, their weighted sum into one backward
+            (rows,) = self.criterion.grouped(o, tg, self.criterion.matcher.match(o, tg), ((s, s),), background_c=0.1)
+            ops.Dot.apply(rows, _loss_weights(E, rows.device)).backward()
+            rows_out.append(rows.detach())
+            lo.append(o["pred_logits"].detach()[0::s].unsqueeze(1))
+            bo.append(o["pred_boxes"].detach()[0::s].unsqueeze(1))
+        if chunk > 0:
+            return {"pred_logits": torch.cat(lo, dim=0), "pred_boxes": torch.cat(bo, dim=0)}, \
+                _named_means(self.criterion, torch.cat(rows_out).mean(0), "loss_detector")
         return {"pred_logits": torch.stack(lo, dim=0), "pred_boxes": torch.stack(bo, dim=0)}, \
             _mean_losses(losses, "loss_detector")
 

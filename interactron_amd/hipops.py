@@ -1644,6 +1644,110 @@ def lsap(cost_cpu):
     return r, c
 
 
+# ---- device-resident matcher + set criterion (csrc/criterion.hip, second half) --------------------------------------------
+class Targets:
+    """Ground truth of I images as one CSR list on the device: ids int64 [T], boxes [T, 4], off int32 [I + 1]; ``sizes`` is
+    the host copy of the per-image counts, ``ldn`` the column pitch of the cost matrices (max count, rounded up to 8)."""
+
+    def __init__(self, ids, boxes, off, sizes):
+        self.ids, self.boxes, self.off, self.sizes = ids, boxes, off, list(sizes)
+        self.I = len(self.sizes)
+        self.ldn = (max(self.sizes + [1]) + 7) // 8 * 8
+
+
+
+def pack_targets(targets):
+    """list of {"labels": int64 [n_i], "boxes": [n_i, 4]} (device tensors) -> Targets; one cat per field + one small upload"""
+    sizes = [int(t["labels"].shape[0]) for t in targets]
+    dev = targets[0]["boxes"].device if targets else torch.device("cuda")
+    if sum(sizes) == 0:
+        ids = torch.zeros(1, dtype=torch.int64, device=dev)
+        boxes = torch.full((1, 4), 0.5, dtype=torch.float32, device=dev)
+    else:
+        ids = torch.cat([t["labels"] for t in targets]).contiguous()
+        boxes = _req(torch.cat([t["boxes"] for t in targets]), "target boxes")
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    tg = Targets(ids, boxes, h2d_async(torch.tensor(off, dtype=torch.int32)), sizes)
+    tg.targets = targets   # (the per-image dicts: the host assignment route and the tests' pinning hook read them)
+    return tg
+
+
+LSAP_DEVICE_MAX = 256
+
+
+def match_cost_csr(logits, boxes, tg, w_class, w_bbox, w_giou):
+    """[I, Q, ldn] cost matrices of all images (columns beyond an image's target count are not written)"""
+    I, Q, C = logits.shape
+    logits, boxes = _req(logits.detach()), _req(boxes.detach())
+    cost = torch.empty(I, Q, tg.ldn, device=logits.device, dtype=torch.float32)
+    _chk(_L().ix_match_cost_csr_f32(logits.data_ptr(), boxes.data_ptr(), tg.ids.data_ptr(), tg.boxes.data_ptr(), tg.off.data_ptr(),
+                                    cost.data_ptr(), I, Q, C, tg.ldn, w_class, w_bbox, w_giou, _stream()), "ix_match_cost_csr_f32")
+    return cost
+
+
+def lsap_device(cost, tg):
+    """-> (tgt_of_q int32 [I, Q], q_of_tgt int32 [T]) -- scipy's assignment per image, computed on the GPU"""
+    I, Q, ldn = cost.shape
+    toq = torch.empty(I, Q, dtype=torch.int32, device=cost.device)
+    qot = torch.empty(max(int(tg.ids.shape[0]), 1), dtype=torch.int32, device=cost.device)
+    _chk(_L().ix_lsap_device_f32(cost.data_ptr(), tg.off.data_ptr(), I, Q, ldn, toq.data_ptr(), qot.data_ptr(), _stream()),
+         "ix_lsap_device_f32")
+    return toq, qot
+
+
+class SetLoss(Function):
+    """DETR set criterion of image groups: apply(logits [I, Q, C], boxes [I, Q, 4], tg, tgt_of_q, w_noobj, specs) with
+    specs = ((stride, len), ...) -> one [G, 5] tensor per spec, G = I // stride, columns (loss_ce, class_error, loss_bbox,
+    loss_giou, cardinality_error) of the group's images g * stride .. g * stride + len - 1, each with its own normalisers
+    (reference detr.py:220-265 called once per group).  Only the FIRST spec is differentiable (the others are bookkeeping:
+    the frame-0 reward of interactron.py:104-108)."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, tg, tgt_of_q, w_noobj, specs):
+        logits, boxes = _req(logits, "criterion logits"), _req(boxes, "criterion boxes")
+        I, Q, C = logits.shape
+        dev = logits.device
+        rowstat = torch.empty(I * Q, 4, dtype=torch.float32, device=dev)
+        lse = torch.empty(I * Q, dtype=torch.float32, device=dev)
+        flags = torch.empty(I * Q, dtype=torch.int32, device=dev)
+        L = _L()
+        _chk(L.ix_set_loss_rows_f32(logits.data_ptr(), boxes.data_ptr(), tg.ids.data_ptr(), tg.boxes.data_ptr(), tg.off.data_ptr(),
+                                    tgt_of_q.data_ptr(), rowstat.data_ptr(), lse.data_ptr(), flags.data_ptr(), I, Q, C, w_noobj,
+                                    _stream()), "ix_set_loss_rows_f32")
+        outs, norm0 = [], None
+        for k, (stride, ln) in enumerate(specs):
+            assert I % stride == 0 and 1 <= ln <= stride, (I, stride, ln)
+            G = I // stride
+            out = torch.empty(G, 5, dtype=torch.float32, device=dev)
+            norm = torch.empty(G, 2, dtype=torch.float32, device=dev)
+            _chk(L.ix_set_loss_groups_f32(rowstat.data_ptr(), flags.data_ptr(), tg.off.data_ptr(), stride, ln, G, Q, out.data_ptr(),
+                                          norm.data_ptr(), _stream()), "ix_set_loss_groups_f32")
+            outs.append(out)
+            if k == 0:
+                norm0 = norm
+        ctx.tg, ctx.w_noobj, ctx.spec0 = tg, w_noobj, specs[0]
+        ctx.save_for_backward(logits, boxes, tgt_of_q, lse, norm0)
+        for o in outs[1:]:
+            ctx.mark_non_differentiable(o)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g0, *_):
+        logits, boxes, tgt_of_q, lse, norm0 = ctx.saved_tensors
+        tg = ctx.tg
+        I, Q, C = logits.shape
+        stride, ln = ctx.spec0
+        g0 = _req(g0.contiguous())
+        dl, db = torch.empty_like(logits), torch.empty_like(boxes)
+        _chk(_L().ix_set_loss_bwd_f32(logits.data_ptr(), boxes.data_ptr(), tg.ids.data_ptr(), tg.boxes.data_ptr(), tg.off.data_ptr(),
+                                      tgt_of_q.data_ptr(), lse.data_ptr(), g0.data_ptr(), norm0.data_ptr(), stride, ln, I, Q, C,
+                                      ctx.w_noobj, dl.data_ptr(), db.data_ptr(), _stream()), "ix_set_loss_bwd_f32")
+        return dl, db, None, None, None, None
+
+
 class WeightedCE(Function):
     """F.cross_entropy(logits [R,C], target [R], weight [C]) with mean reduction; also returns per-row argmax."""
 
