@@ -156,6 +156,13 @@ int ix_sigmoid_bwd_f32(const float* dy, const float* y, float* dx, int64_t n, ix
 int ix_sigmoid_bwd_bwd_f32(const float* G, const float* dy, const float* y, float* grad_dy, float* grad_y, int64_t n,
                            ix_stream_t stream);
 int ix_dropout_f32(const float* x, float* out, int64_t n, float p, uint64_t seed, ix_stream_t stream);
+/* Dropout masks are pure functions of (seed, element index) and the seed is a launch argument: a captured HIP graph would
+ * replay the same masks for ever.  ix_set_dropout_salt(p): every dropout-carrying launch issued from now on (ix_dropout_f32,
+ * ix_relu_dropout_f32, ix_add_dropout_f32, ix_attn_prob_*, ix_flash_*) XORs the 64-bit word at DEVICE address p into its seed
+ * when the kernel runs; the caller changes that word between replays.  NULL (the default) switches it off.  Process-global,
+ * one host thread; the word must stay allocated while such launches (or graphs holding them) can run.
+ * (reference: nn.Dropout draws from torch's device RNG at run time -- models/gpt.py:33-34,52,56, transformer.py:143-146) */
+int ix_set_dropout_salt(const void* device_word);
 /* grouped forms: a/out [groups, rows, C], v [groups, C] (groups = episodes processed together; 1 = plain) */
 int ix_add_rowvec_f32(const float* a, const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);
 int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, int groups, ix_stream_t stream);

@@ -12,6 +12,9 @@
 
 void ix_set_error(const char* fmt, ...);
 
+// ix_set_dropout_salt: optional device word every dropout kernel XORs into its seed (see api.cpp)
+extern const uint64_t* ix_g_salt;
+
 #define IX_CHECK_ARG(cond, ...)                         \
     do {                                                \
         if (!(cond)) {                                  \

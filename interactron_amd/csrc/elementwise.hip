@@ -171,7 +171,8 @@ __device__ __forceinline__ uint32_t mix32(uint64_t z) {
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, uint32_t thresh,
-                               float scale, uint64_t seed) {
+                               float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
         const uint32_t r = mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull));
@@ -186,7 +187,7 @@ extern "C" int ix_dropout_f32(const float* x, float* out, int64_t n, float p, ui
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_dropout_f32: p=%f outside [0,1)", p);
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     hipLaunchKernelGGL(dropout_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, out, n, thresh,
-                       1.f / (1.f - p), seed);
+                       1.f / (1.f - p), seed, ix_g_salt);
     IX_CHECK_LAUNCH("ix_dropout_f32");
     return IX_OK;
 }
@@ -195,7 +196,8 @@ extern "C" int ix_dropout_f32(const float* x, float* out, int64_t n, float p, ui
 // its backward dx = dy * [y > 0] / keep: y = m relu(x) / keep is positive exactly where both the mask and the relu pass,
 // so the backward needs neither the mask hash nor x.
 __global__ void relu_dropout_kernel(const float* __restrict__ x, float* __restrict__ o, int64_t n, uint32_t thresh,
-                                    float scale, uint64_t seed) {
+                                    float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
         const uint32_t r = mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull));
@@ -209,14 +211,15 @@ extern "C" int ix_relu_dropout_f32(const float* x, float* out, int64_t n, float 
     IX_CHECK_ARG(x && out, "ix_relu_dropout_f32: null pointer");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_relu_dropout_f32: p=%f outside [0,1)", p);
     hipLaunchKernelGGL(relu_dropout_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, out, n,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed, ix_g_salt);
     IX_CHECK_LAUNCH("ix_relu_dropout_f32");
     return IX_OK;
 }
 
 // x + dropout(a): the residual adds of the transformer blocks (transformer.py:157-160,222-231, gpt.py:75-77) in one pass
 __global__ void add_dropout_kernel(const float* __restrict__ x, const float* __restrict__ a, float* __restrict__ o, int64_t n,
-                                   uint32_t thresh, float scale, uint64_t seed) {
+                                   uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += stride) {
         const uint32_t r = mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull));
@@ -230,7 +233,7 @@ extern "C" int ix_add_dropout_f32(const float* x, const float* a, float* out, in
     IX_CHECK_ARG(x && a && out, "ix_add_dropout_f32: null pointer");
     IX_CHECK_ARG(p >= 0.f && p < 1.f, "ix_add_dropout_f32: p=%f outside [0,1)", p);
     hipLaunchKernelGGL(add_dropout_kernel, dim3(ix_grid_1d(n, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, a, out, n,
-                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed);
+                       (uint32_t)((double)p * 4294967296.0), 1.f / (1.f - p), seed, ix_g_salt);
     IX_CHECK_LAUNCH("ix_add_dropout_f32");
     return IX_OK;
 }

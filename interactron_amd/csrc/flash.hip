@@ -312,6 +312,7 @@ struct FlashArgs {
     unsigned thr16;             // dropout threshold (0 = no dropout)
     float inv_keep;
     unsigned seed_lo, seed_hi;
+    const unsigned* salt;       // optional device word XORed into the seed when the kernel runs (ix_set_dropout_salt)
 };
 
 // dropout keep flags of the 16 accumulator registers of a tile whose lane holds ONE row id and whose registers walk the
@@ -342,6 +343,7 @@ struct FlashArgs {
 // the derivative kernels recompute.
 template <int HD, bool DROP, bool LSE_ONLY = false>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     constexpr int OFF_K = 0, OFF_VT = G::RBYTES, BYTES = LSE_ONLY ? G::RBYTES : G::RBYTES + G::TBYTES, NU = LSE_ONLY ? 2 : 5, NROW = 1;
@@ -491,6 +493,7 @@ extern "C" int ix_attn_rowdot_f32(const float* a, const float* b, float* t, int 
 // ---- query-owning workgroup: gQ (o1) ---------------------------------------------------------------------------------
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     constexpr int OFF_K = 0, OFF_V = G::RBYTES, OFF_KT = 2 * G::RBYTES, BYTES = 2 * G::RBYTES + G::TBYTES, NU = 7, NROW = 2;
@@ -581,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
 // output products while the next tile's tr operands are in flight.  49 KB of LDS and <= 256 registers: two workgroups per CU.
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     constexpr int OFF_Q = 0, OFF_D = G::RBYTES, OFF_QT = 2 * G::RBYTES, OFF_DT = 2 * G::RBYTES + G::TBYTES;
@@ -703,6 +707,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
 // barrier that ends its phase, from one shared set of staging registers.
 template <int HD, bool DROP, bool STATS>
 __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     // row segments k, hk, v, hv; then (pass 2) tr segments hk, k, hv, v
@@ -873,6 +878,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
 // pass 3 (key-owning): dk (o2), dv (o3).  Tiles [query, key]: lane = key, registers = queries.  Two-phase tile as in pass 2.
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
     // row segments q, hq, dO; tr segments hq, q, dO; statistics lse, delta, u, w [32] each (part of the TR phase)
@@ -1032,6 +1038,7 @@ static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, in
     a.thr16 = (unsigned)((double)p_drop * 65536.0 + 0.5);
     a.inv_keep = a.thr16 ? 65536.f / (float)(65536u - a.thr16) : 1.f;
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.salt = reinterpret_cast<const unsigned*>(ix_g_salt);
     return IX_OK;
 }
 #define FL_OUT_OK(LD, OFF) ((LD) % 4 == 0 && (OFF) % 4 == 0)
@@ -1170,7 +1177,8 @@ extern "C" int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out
 
 // The flash kernels' dropout mask as a tensor (tests only): m[bh][q][key] = 1/keep where kept, 0 where dropped.
 __global__ void flash_dropmask_kernel(float* __restrict__ m, int L, int S, unsigned thr16, float inv_keep, unsigned seed_lo,
-                                      unsigned seed_hi) {
+                                      unsigned seed_hi, const unsigned* __restrict__ salt) {
+    if (salt) { seed_lo ^= salt[0]; seed_hi ^= salt[1]; }
     const int bh = blockIdx.z, q = blockIdx.y;
     for (int key = blockIdx.x * blockDim.x + threadIdx.x; key < S; key += gridDim.x * blockDim.x) {
         const unsigned hsh = fl_hash(seed_lo, seed_hi, (unsigned)(bh * L + q), (unsigned)key >> 1);
@@ -1183,7 +1191,7 @@ extern "C" int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_dro
     const unsigned thr16 = (unsigned)((double)p_drop * 65536.0 + 0.5);
     const float inv_keep = thr16 ? 65536.f / (float)(65536u - thr16) : 1.f;
     hipLaunchKernelGGL(flash_dropmask_kernel, dim3(ix_div_up(S, 256), L, BH), dim3(256), 0, stream, m, L, S, thr16, inv_keep,
-                       (unsigned)seed, (unsigned)(seed >> 32));
+                       (unsigned)seed, (unsigned)(seed >> 32), reinterpret_cast<const unsigned*>(ix_g_salt));
     IX_CHECK_LAUNCH("ix_flash_dropmask_f32");
     return IX_OK;
 }
@@ -1278,10 +1286,12 @@ struct FlashFp8Args {
     unsigned thr16;
     float inv_keep;
     unsigned seed_lo, seed_hi;
+    const unsigned* salt;       // optional device word XORed into the seed when the kernel runs (ix_set_dropout_salt)
 };
 
 template <int HD, bool DROP>
 __global__ __launch_bounds__(256, 2) void flash_fwd_fp8_kernel(FlashFp8Args p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     constexpr int KROW = HD + 8, VROW = 32 + 8, OFF_VT = 32 * KROW, BYTES = OFF_VT + HD * VROW;   // 8-byte padded rows
     constexpr int NCH = 32 * HD / 8;   // 8-byte chunks of the K tile (= of the V tile): 256 at hd 64, 128 at hd 32
@@ -1430,6 +1440,7 @@ extern "C" int ix_flash_fwd_fp8_f32(const void* q_row8, const float* q_unscale, 
     a.thr16 = (unsigned)((double)p_drop * 65536.0 + 0.5);
     a.inv_keep = a.thr16 ? 65536.f / (float)(65536u - a.thr16) : 1.f;
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32);
+    a.salt = reinterpret_cast<const unsigned*>(ix_g_salt);
     dim3 grid((L + 127) / 128, n * H);
     ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, 2.0 * FL_PRODUCT_FLOPS, 1);
     FL_DISPATCH(flash_fwd_fp8_kernel, grid)

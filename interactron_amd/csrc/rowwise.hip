@@ -188,14 +188,15 @@ __device__ __forceinline__ float attn_keep(uint64_t seed, int64_t k, uint32_t th
     return attn_mix32(seed ^ ((uint64_t)k * 0xD6E8FEB86659FD93ull)) >= thresh ? scale : 0.f;
 }
 
-__global__ void attn_prob_fwd_stream_kernel(const float*, float*, float*, int64_t, int, int64_t, const uint8_t*, int, int64_t, uint32_t, float, uint64_t);
-__global__ void attn_prob_bwd_stream_kernel(const float*, const float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t);
-__global__ void attn_prob_bwd_bwd_stream_kernel(const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t);
+__global__ void attn_prob_fwd_stream_kernel(const float*, float*, float*, int64_t, int, int64_t, const uint8_t*, int, int64_t, uint32_t, float, uint64_t, const uint64_t*);
+__global__ void attn_prob_bwd_stream_kernel(const float*, const float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t, const uint64_t*);
+__global__ void attn_prob_bwd_bwd_stream_kernel(const float*, const float*, const float*, const float*, const float*, float*, float*, int64_t, int, int64_t, uint32_t, float, uint64_t, const uint64_t*);
 template <int NREG>
 __global__ __launch_bounds__(256) void attn_prob_fwd_kernel(const float* x, float* y, float* __restrict__ d, int64_t rows,
                                                             int len, int64_t ld, const uint8_t* __restrict__ mask,
                                                             int rows_per_mask, int64_t mask_ld, uint32_t thresh, float scale,
-                                                            uint64_t seed) {
+                                                            uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -244,13 +245,13 @@ extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t 
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const float scale = 1.f / (1.f - p);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define SM(N) hipLaunchKernelGGL(attn_prob_fwd_kernel<N>, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed)
+#define SM(N) hipLaunchKernelGGL(attn_prob_fwd_kernel<N>, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed, ix_g_salt)
     if (ld <= 64) SM(1);
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
     else if (ld <= 2304) SM(36);
-    else hipLaunchKernelGGL(attn_prob_fwd_stream_kernel, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed);
+    else hipLaunchKernelGGL(attn_prob_fwd_stream_kernel, grid, block, 0, stream, x, y, d, rows, len, ld, mask, rows_per_mask, mask_ld, thresh, scale, seed, ix_g_salt);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_fwd_f32");
     return IX_OK;
@@ -260,7 +261,8 @@ extern "C" int ix_attn_prob_fwd_f32(const float* x, float* y, float* d, int64_t 
 template <int NREG>
 __global__ __launch_bounds__(256) void attn_prob_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gd,
                                                             float* __restrict__ gs, int64_t rows, int len, int64_t ld,
-                                                            uint32_t thresh, float scale, uint64_t seed) {
+                                                            uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -299,13 +301,13 @@ extern "C" int ix_attn_prob_bwd_f32(const float* y, const float* gd, float* gs, 
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const float scale = 1.f / (1.f - p);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_kernel<N>, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed)
+#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_kernel<N>, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed, ix_g_salt)
     if (ld <= 64) SM(1);
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
     else if (ld <= 2304) SM(36);
-    else hipLaunchKernelGGL(attn_prob_bwd_stream_kernel, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed);
+    else hipLaunchKernelGGL(attn_prob_bwd_stream_kernel, grid, block, 0, stream, y, gd, gs, rows, len, ld, thresh, scale, seed, ix_g_salt);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_f32");
     return IX_OK;
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(256) void attn_prob_bwd_bwd_kernel(const float* __r
                                                                 const float* __restrict__ y, const float* __restrict__ gd,
                                                                 const float* __restrict__ HD, float* __restrict__ HgD,
                                                                 float* __restrict__ HS, int64_t rows, int len, int64_t ld,
-                                                                uint32_t thresh, float scale, uint64_t seed) {
+                                                                uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -378,13 +381,13 @@ extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const 
     const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
     const float scale = 1.f / (1.f - p);
     dim3 grid((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)), block(256);
-#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_bwd_kernel<N>, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed)
+#define SM(N) hipLaunchKernelGGL(attn_prob_bwd_bwd_kernel<N>, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed, ix_g_salt)
     if (ld <= 64) SM(1);
     else if (ld <= 256) SM(4);
     else if (ld <= 512) SM(8);
     else if (ld <= 1024) SM(16);
     else if (ld <= 2304) SM(36);
-    else hipLaunchKernelGGL(attn_prob_bwd_bwd_stream_kernel, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed);
+    else hipLaunchKernelGGL(attn_prob_bwd_bwd_stream_kernel, grid, block, 0, stream, G1, G2, y, gd, HD, HgD, HS, rows, len, ld, thresh, scale, seed, ix_g_salt);
 #undef SM
     IX_CHECK_LAUNCH("ix_attn_prob_bwd_bwd_f32");
     return IX_OK;
@@ -396,7 +399,8 @@ extern "C" int ix_attn_prob_bwd_bwd_f32(const float* G1, const float* G2, const 
 __global__ __launch_bounds__(256) void attn_prob_fwd_stream_kernel(const float* x, float* y, float* __restrict__ d,
                                                                    int64_t rows, int len, int64_t ld,
                                                                    const uint8_t* __restrict__ mask, int rows_per_mask,
-                                                                   int64_t mask_ld, uint32_t thresh, float scale, uint64_t seed) {
+                                                                   int64_t mask_ld, uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -418,7 +422,8 @@ __global__ __launch_bounds__(256) void attn_prob_fwd_stream_kernel(const float* 
 
 __global__ __launch_bounds__(256) void attn_prob_bwd_stream_kernel(const float* __restrict__ y, const float* __restrict__ gd,
                                                                    float* __restrict__ gs, int64_t rows, int len, int64_t ld,
-                                                                   uint32_t thresh, float scale, uint64_t seed) {
+                                                                   uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -434,7 +439,8 @@ __global__ __launch_bounds__(256) void attn_prob_bwd_bwd_stream_kernel(const flo
                                                                        const float* __restrict__ y, const float* __restrict__ gd,
                                                                        const float* __restrict__ HD, float* __restrict__ HgD,
                                                                        float* __restrict__ HS, int64_t rows, int len, int64_t ld,
-                                                                       uint32_t thresh, float scale, uint64_t seed) {
+                                                                       uint32_t thresh, float scale, uint64_t seed, const uint64_t* __restrict__ salt) {
+    if (salt) seed ^= *salt;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;

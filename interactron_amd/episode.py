@@ -92,6 +92,11 @@ def _weighted_rows(rows):
     return rows[:, 0] + 5 * rows[:, 3] + 2 * rows[:, 2]
 
 
+def _ldn(targets):
+    """column pitch of the cost matrices of these images: the largest target count, rounded up to 8"""
+    return (max([int(t["labels"].shape[0]) for t in targets] + [1]) + 7) // 8 * 8
+
+
 def _named_means(criterion, row, tag):
     return {k.replace("loss", tag): v for k, v in criterion.as_dict(row).items()}
 
@@ -150,6 +155,34 @@ class _Adaptive(_EpisodeModel):
 
     use_policy = False
 
+    def _graph_stamp(self):
+        """Addresses of everything a captured graph reads by pointer: all parameters (and their .grad), buffers of detector
+        and fusion plus the folded frozen-BN affines.  A re-homed parameter (FlatBuffers, .to()), a dropped .grad or a
+        rebuilt fold changes it."""
+        ptrs = [t.data_ptr() for t in self.detector.parameters()] + [t.data_ptr() for t in self.detector.buffers()]
+        ptrs += [t.data_ptr() for t in self.fusion.parameters()] + [t.data_ptr() for t in self.fusion.buffers()]
+        ptrs += [0 if t.grad is None else t.grad.data_ptr() for t in self.parameters()]
+        folds = [m._fold for m in self.detector.modules() if getattr(m, "_fold", None) is not None]
+        ptrs += [t.data_ptr() for f in folds for t in f[1]]
+        return hash(tuple(ptrs)), folds
+
+    def invalidate_graphs(self):
+        """Drop every captured graph (weights were reloaded / moved); the next call captures afresh."""
+        if self.__dict__.get("_graphs"):
+            self._graphs = {}
+        self.__dict__.pop("_chunk_graphs", None)
+        self.__dict__.pop("_predict_graphs", None)
+
+    def load_state_dict(self, *args, **kwargs):
+        # load_state_dict copies IN PLACE (addresses unchanged) but FrozenBatchNorm2d drops its folded scale/shift, which
+        # a captured graph reads by address: replaying it afterwards would read freed memory
+        self.invalidate_graphs()
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .float(): storage moves
+        self.invalidate_graphs()
+        return super()._apply(fn, *args, **kwargs)
+
     def _second_order_targets(self):
         """Leaves that keep a .grad from the supervisor backward: fusion parameters and the detector parameters that
         are real nn.Parameters during the episode (MultiheadAttention.in_proj_*)."""
@@ -187,7 +220,12 @@ class _Adaptive(_EpisodeModel):
         b, s, c, w, h = data["frames"].shape
         if b > 1:
             return self._predict_batched(data)
+        from . import graphs
         img, mask = data["frames"].view(s, c, w, h), data["masks"].view(s, w, h)
+        return graphs.predict_runner(self, img, mask)(img, mask)
+
+    def _predict_one(self, img, mask):
+        """reference interactron.py:31-59 for one episode: adapt on the s frames, detect frame 0 through theta'"""
         self._theta = self._real_parameters()
         try:
             with torch.enable_grad():
@@ -239,6 +277,90 @@ class _Adaptive(_EpisodeModel):
     # every Linear / conv / LayerNorm over them becomes ONE batched launch in which episode e's rows meet episode e's
     # weights, and theta's gradient is the sum over that dim -- the same numbers as the sequential loop, E x fewer
     # launches.  EPISODE_CHUNK (config key, default 16 = the reference BATCH_SIZE; 0 = the sequential reference loop) bounds E.
+    #
+    # A chunk is three sync-free SEGMENTS of launches with one host round trip (PathStorage, learned policy only):
+    #     A  expand theta, detector(5 frames), fusion, learned-loss gradient (create_graph), clipped SGD, detector again,
+    #        device matcher + criterion of the 5 frames and of frame 0 (the reward), reward -> pinned host memory
+    #     C  the first-order branch (reference :126-134): detector on one random frame through theta', criterion, backward
+    #     --  host: PathStorage bookkeeping on the rewards, policy labels up
+    #     B  policy cross-entropy, supervisor total, second-order backward
+    # Issued eagerly (default for large chunks: the step is GPU-bound) or replayed from three captured HIP graphs
+    # (graphs.ChunkGraphs; small chunks are bound by the host issuing ~6 000 launches, STEP_GRAPH: auto / true / false).
+    def _seg_a(self, st):
+        E, s, theta, lr = st.E, st.s, self._theta, self.config.ADAPTIVE_LR
+        # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
+        st.dtheta = dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
+        set_parameters(self.detector, dtheta)
+        # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
+        st.nt = nt = NestedTensor(st.frames, st.masks)
+        nt.stem = self.detector.backbone[0].body.frozen_stem(st.frames)
+        pre = self.detector(nt)
+        st.mark("1 detector fwd (theta)")
+        pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
+        fusion_out = self.fusion(pre)
+        st.mark("2 fusion fwd")
+        loss_map = fusion_out["loss"].reshape(E, -1)
+        learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
+        st.grads = grads = self._inner_grad(learned, dtheta, True)
+        st.mark("3 learned-loss grad (create_graph)")
+        set_parameters(self.detector, sgd_step(dtheta, grads, lr))
+        post = self.detector(nt)
+        st.mark("4 inner SGD + detector fwd (theta')")
+        st.actions_out = fusion_out["actions"].reshape(E * 4, 4)
+        # Matcher + criterion of the whole chunk on the device (criterion.py): one cost launch and one assignment launch
+        # for all E * s images (matching is per image, so the assignments are exactly those of per-episode calls), then
+        # the losses of every episode's 5 frames AND of its frame 0 alone (the policy reward, reference :104-108) from one
+        # pass over the rows.
+        post_lb = {k: post[k] for k in ("pred_logits", "pred_boxes")}
+        toq = self.criterion.matcher.match(post_lb, st.tg)
+        specs = ((s, s), (s, 1)) if self.use_policy else ((s, s),)
+        rows = self.criterion.grouped(post_lb, st.tg, toq, specs, background_c=0.1)
+        st.sup_rows = rows[0]
+        if self.use_policy:   # frame-0 loss = the reward PathStorage ranks action sequences by: its D2H copy starts now
+            st.gts = _weighted_rows(rows[1])
+            st.gts_host.copy_(st.gts, non_blocking=True)
+        st.mark("5 matcher + criterion")
+
+    def _seg_c(self, st):
+        # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient, not on the
+        # criterion.  The expansion of theta is differentiable; its backward sums the per-episode gradients into theta.grad.
+        E, theta = st.E, self._theta
+        attached = list(ops.ExpandEpisodes.apply(E, *theta))
+        fast1 = sgd_step(attached, [None if g is None else g.detach() for g in st.grads], self.config.ADAPTIVE_LR)
+        set_parameters(self.detector, fast1)
+        nt1 = NestedTensor(st.frames[st.sel], st.masks[st.sel])
+        nt1.stem = st.nt.stem[st.sel]
+        post1 = self.detector(nt1)
+        post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
+        toq1 = self.criterion.matcher.match(post1_lb, st.tg1)
+        (det_rows,) = self.criterion.grouped(post1_lb, st.tg1, toq1, ((1, 1),), background_c=0.1)
+        st.det_rows = det_rows.detach()
+        st.logits1, st.boxes1 = post1_lb["pred_logits"].detach(), post1_lb["pred_boxes"].detach()
+        st.mark("6 first-order SGD + 1-frame fwd + criterion")
+        ops.Dot.apply(det_rows, _loss_weights(E, st.frames.device)).backward()
+        st.mark("7 first-order backward")
+
+    def _seg_b(self, st):
+        E = st.E
+        total = ops.Dot.apply(st.sup_rows, _loss_weights(E, st.frames.device))
+        if self.use_policy:
+            # sum over episodes of F.cross_entropy(actions[4, 4], best_path[4]) (reference :116-118) = E x the mean over all
+            # E * 4 rows (equal rows per episode, unit class weights)
+            path_ce, _ = ops.WeightedCE.apply(st.actions_out, st.best_all, _ones(4, st.frames.device))
+            total = total + path_ce * float(E)
+            st.path_ce = path_ce.detach()
+        # (the supervisor backward ends in the fusion parameters and the in_proj blocks; nothing keeps a gradient of the
+        #  per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
+        with ops.skip_param_grads(frozenset(id(t) for t in st.dtheta)):
+            torch.autograd.backward(total, inputs=self._targets2)
+        st.sup_rows = st.sup_rows.detach()
+        st.mark("8 second-order backward")
+
+    def _chunk_runner(self, E, s, shape, ldn, ldn1):
+        """-> callable(inputs) -> results for chunks of this signature: eager segments, or graphs.ChunkGraphs replay"""
+        from . import graphs
+        return graphs.chunk_runner(self, E, s, shape, ldn, ldn1)
+
     def forward(self, data, train=True):
         chunk = int(getattr(self.config, "EPISODE_CHUNK", 16))
         if chunk <= 0:
@@ -247,100 +369,36 @@ class _Adaptive(_EpisodeModel):
         img, mask = data["frames"].view(b, s, c, w, h), data["masks"].view(b, s, w, h)
         det_out, sup_out, path_out, reward_out, logits_out, boxes_out = [], [], [], [], [], []
         self._theta = theta = self._real_parameters()
-        targets2 = self._second_order_targets()
-        lr = self.config.ADAPTIVE_LR
+        self._targets2 = self._second_order_targets()
         actions_host = data["actions"].tolist() if self.use_policy else None   # one D2H up front
         try:
             for e0 in range(0, b, chunk):
-                pt = _PhaseTimer(self.phase_times)
                 E = min(chunk, b - e0)
                 ep = range(e0, e0 + E)
                 labels = [_labels(data, t) for t in ep]
-                frames, masks = img[e0:e0 + E].reshape(E * s, c, w, h), mask[e0:e0 + E].reshape(E * s, w, h)
                 # the first-order branch's random frame per episode (reference :126) and both target lists: drawn, packed
                 # and uploaded before anything is queued
                 ridx = [random.randint(0, 4) for _ in ep]
-                tg = ops.pack_targets([lab for ep_labels in labels for lab in ep_labels])
-                tg1 = ops.pack_targets([labels[i][ridx[i]] for i in range(E)])
-                # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
-                dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
-                set_parameters(self.detector, dtheta)
-                # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
-                nt = NestedTensor(frames, masks)
-                nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
-                sel = ops.h2d_async(torch.tensor([i * s + r for i, r in enumerate(ridx)]))
-                pre = self.detector(nt)
-                pt.mark("1 detector fwd (theta)")
-                pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
-                fusion_out = self.fusion(pre)
-                pt.mark("2 fusion fwd")
-                loss_map = fusion_out["loss"].reshape(E, -1)
-                learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
-                grads = self._inner_grad(learned, dtheta, True)
-                pt.mark("3 learned-loss grad (create_graph)")
-                set_parameters(self.detector, sgd_step(dtheta, grads, lr))
-                post = self.detector(nt)
-                pt.mark("4 inner SGD + detector fwd (theta')")
-                actions_out = fusion_out["actions"].reshape(E * 4, 4)
-                # Matcher + criterion of the whole chunk on the device (criterion.py): one cost launch and one assignment
-                # launch for all E * s images (matching is per image, so the assignments are exactly those of per-episode
-                # calls), then the losses of every episode's 5 frames AND of its frame 0 alone (the policy reward, reference
-                # :104-108) from one pass over the rows.
-                post_lb = {k: post[k] for k in ("pred_logits", "pred_boxes")}
-                toq = self.criterion.matcher.match(post_lb, tg)
-                specs = ((s, s), (s, 1)) if self.use_policy else ((s, s),)
-                sup_rows = self.criterion.grouped(post_lb, tg, toq, specs, background_c=0.1)
-                if self.use_policy:   # frame-0 loss = the reward PathStorage ranks action sequences by: its D2H copy starts now
-                    gts = _weighted_rows(sup_rows[1])
-                    gts_host = torch.empty(E, dtype=torch.float32, pin_memory=True)
-                    gts_host.copy_(gts, non_blocking=True)
-                    gts_ready = torch.cuda.Event()
-                    gts_ready.record()
+                inputs = {"frames": img[e0:e0 + E].reshape(E * s, c, w, h), "masks": mask[e0:e0 + E].reshape(E * s, w, h),
+                          "targets": [lab for ep_labels in labels for lab in ep_labels],
+                          "targets1": [labels[i][ridx[i]] for i in range(E)],
+                          "sel": [i * s + r for i, r in enumerate(ridx)]}
 
-                # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient,
-                # not on the criterion.  The expansion of theta is differentiable; its backward sums the per-episode
-                # gradients into theta.grad.
-                attached = list(ops.ExpandEpisodes.apply(E, *theta))
-                fast1 = sgd_step(attached, [None if g is None else g.detach() for g in grads], lr)
-                set_parameters(self.detector, fast1)
-                nt1 = NestedTensor(frames[sel], masks[sel])
-                nt1.stem = nt.stem[sel]
-                post1 = self.detector(nt1)
-                post1_lb = {k: post1[k] for k in ("pred_logits", "pred_boxes")}
-                toq1 = self.criterion.matcher.match(post1_lb, tg1)
-                (det_rows,) = self.criterion.grouped(post1_lb, tg1, toq1, ((1, 1),), background_c=0.1)
-                pt.mark("5 criterion + first-order SGD + 1-frame fwd")
-
-                total = ops.Dot.apply(sup_rows[0], _loss_weights(E, frames.device))
-                if self.use_policy:   # PathStorage bookkeeping on the host, in episode order: the step's ONE host round trip
-                    gts_ready.synchronize()   # (the GPU still has the first-order forward queued behind the copy)
-                    rewards = gts_host.tolist()
+                def policy_labels(rewards, e0=e0, ep=ep):   # PathStorage bookkeeping on the host, in episode order
                     if "dp_index" in data:   # data parallel: replay the global batch's chunk (see _dp_chunk_labels)
-                        best_host = self._dp_chunk_labels(data, e0 // chunk, chunk, list(ep), rewards)
-                    else:
-                        best_host = best_path_labels(self.path_storage, [data["initial_image_path"][t] for t in ep],
-                                                     [actions_host[t][:4] for t in ep], rewards)
-                    best_all = ops.h2d_async(torch.tensor(best_host, dtype=torch.long).reshape(E * 4))
-                    # sum over episodes of F.cross_entropy(actions[4, 4], best_path[4]) (reference :116-118) = E x the mean
-                    # over all E * 4 rows (equal rows per episode, unit class weights)
-                    path_ce, _ = ops.WeightedCE.apply(actions_out, best_all, _ones(4, frames.device))
-                    total = total + path_ce * float(E)
-                    path_out.append(path_ce.detach().reshape(1).expand(E))
-                    reward_out.append(gts)
-                sup_out.append(sup_rows[0].detach())
-                pt.mark("6 path storage (host) + policy loss")
-                # (the supervisor backward ends in the fusion parameters and the in_proj blocks; nothing keeps a gradient of
-                #  the per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
-                with ops.skip_param_grads(frozenset(id(t) for t in dtheta)):
-                    torch.autograd.backward(total, inputs=targets2)
-                del grads, dtheta, fusion_out, pre, post, post_lb, sup_rows, total, loss_map, learned, actions_out
-                pt.mark("7 second-order backward")
-                det_out.append(det_rows.detach())
-                logits_out.append(post1_lb["pred_logits"].detach().unsqueeze(1))
-                boxes_out.append(post1_lb["pred_boxes"].detach().unsqueeze(1))
-                ops.Dot.apply(det_rows, _loss_weights(E, frames.device)).backward()
-                pt.mark("8 first-order backward")
-                del attached, fast1, post1, det_rows
+                        return self._dp_chunk_labels(data, e0 // chunk, chunk, list(ep), rewards)
+                    return best_path_labels(self.path_storage, [data["initial_image_path"][t] for t in ep],
+                                            [actions_host[t][:4] for t in ep], rewards)
+
+                run = self._chunk_runner(E, s, (c, w, h), _ldn(inputs["targets"]), _ldn(inputs["targets1"]))
+                res = run(inputs, policy_labels if self.use_policy else None)
+                sup_out.append(res["sup_rows"])
+                det_out.append(res["det_rows"])
+                logits_out.append(res["logits1"].unsqueeze(1))
+                boxes_out.append(res["boxes1"].unsqueeze(1))
+                if self.use_policy:
+                    path_out.append(res["path_ce"].reshape(1).expand(E))
+                    reward_out.append(res["gts"])
             if self.use_policy and "dp_index" in data:   # chunks this rank has no episodes in: still part of the exchange
                 for c in range((b + chunk - 1) // chunk, self._dp_chunks(data, chunk)):
                     self._dp_chunk_labels(data, c, chunk, [], [])
@@ -464,30 +522,6 @@ class interactron(_Adaptive):
     # episode it is bound by the host issuing them.  In eval mode the launch sequence of each frame count is captured
     # once into a HIP graph (static input buffers, weights by address) and replayed; any capture failure, training
     # mode or a weight re-allocation falls back to eager launches.  POLICY_GRAPH: false in the config turns it off.
-    def _graph_stamp(self):
-        """Addresses of everything a captured policy graph reads by pointer: all parameters and buffers of detector and
-        fusion plus the folded frozen-BN affines.  A re-homed parameter (FlatBuffers, .to()) or a rebuilt fold changes it."""
-        ptrs = [t.data_ptr() for t in self.detector.parameters()] + [t.data_ptr() for t in self.detector.buffers()]
-        ptrs += [t.data_ptr() for t in self.fusion.parameters()] + [t.data_ptr() for t in self.fusion.buffers()]
-        folds = [m._fold for m in self.detector.modules() if getattr(m, "_fold", None) is not None]
-        ptrs += [t.data_ptr() for f in folds for t in f[1]]
-        return hash(tuple(ptrs)), folds
-
-    def invalidate_graphs(self):
-        """Drop every captured policy graph (weights were reloaded / moved); the next eval call captures afresh."""
-        if self.__dict__.get("_graphs"):
-            self._graphs = {}
-
-    def load_state_dict(self, *args, **kwargs):
-        # load_state_dict copies IN PLACE (addresses unchanged) but FrozenBatchNorm2d drops its folded scale/shift, which
-        # a captured graph reads by address: replaying it afterwards would read freed memory
-        self.invalidate_graphs()
-        return super().load_state_dict(*args, **kwargs)
-
-    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .float(): storage moves
-        self.invalidate_graphs()
-        return super()._apply(fn, *args, **kwargs)
-
     def _policy_graph(self, frames, masks):
         key = (tuple(frames.shape), frames.device.index)
         if "_graphs" not in self.__dict__:

@@ -668,6 +668,21 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True):
 
 
 _bias_cache = {}
+_capture = [None]   # capture-local cache of additive key biases while a HIP-graph capture is running
+
+
+def capture_begin(salt):
+    """Called around a HIP-graph capture of launches from this module (graphs.ChunkGraphs).  `salt`: int64 device tensor every
+    dropout kernel of the capture XORs into its seed at run time (ix_set_dropout_salt), so that a replay draws fresh masks.
+    Tensors cached across calls must not be created inside a capture (their kernels only run at replay) nor evicted while a
+    graph reads them by address: the key-bias cache is replaced by a private one for the duration."""
+    _capture[0] = {}
+    _chk(_L().ix_set_dropout_salt(salt.data_ptr() if salt is not None else None), "ix_set_dropout_salt")
+
+
+def capture_end():
+    _capture[0] = None
+    _chk(_L().ix_set_dropout_salt(None), "ix_set_dropout_salt")
 
 
 def attn_bias(mask, n, S, device):
@@ -677,6 +692,14 @@ def attn_bias(mask, n, S, device):
     encoder and six decoder layers of one detector pass share one key_padding_mask."""
     Sb = _pad128(S)
     key = (device.index, n, S) if mask is None else (device.index, n, S, mask.data_ptr(), mask._version)
+    if _capture[0] is not None:   # inside a graph capture: a private cache that dies with the capture (see capture_begin)
+        hit = _capture[0].get(key)
+        if hit is None:
+            bias = torch.empty(n, Sb, dtype=torch.float32, device=device)
+            _chk(_L().ix_attn_bias_f32(mask.data_ptr() if mask is not None else None, bias.data_ptr(), n, S, Sb,
+                                       mask.shape[-1] if mask is not None else 0, _stream()), "ix_attn_bias_f32")
+            hit = _capture[0][key] = (bias, mask)
+        return hit[0]
     hit = _bias_cache.get(key)
     if hit is not None and (mask is None or hit[1] is mask):
         return hit[0]

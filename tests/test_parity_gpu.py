@@ -383,6 +383,98 @@ def test_step_is_bit_reproducible():
     assert not bad, ("updated parameters differ between two runs", len(bad), bad[:5])
 
 
+def _graph_vs_eager_models(model_type, **extra):
+    from interactron_amd import Config, build_model
+    from interactron_amd.trainer import FlatOuterStep
+    out = []
+    for graph in ("false", "true"):
+        m = build_model(Config(**dict(MODEL_CFG, TYPE=model_type, EPISODE_CHUNK=2, STEP_GRAPH=graph, PREDICT_GRAPH=(graph == "true"), **extra)))
+        load_procedural(m.fusion, "fusion.")
+        out.append((m.cuda(), None))
+    return [(m, FlatOuterStep(m)) for m, _ in out]
+
+
+@pytest.mark.parametrize("model_type", ["interactron", "interactron_random"])
+def test_chunk_graph_replay_equals_eager_launches(model_type):
+    """STEP_GRAPH: the three sync-free segments of a chunk replayed from captured HIP graphs (graphs.ChunkGraphs: static
+    input buffers, device matcher, one host round trip for PathStorage) against the same segments issued launch by launch:
+    four steps on alternating batches, each followed by clip + Adam -- losses, predictions, every gradient and every
+    updated parameter must be BIT-identical (eval mode: no dropout; step 1 is the eager warm-up of the graph model, step 2
+    captures, steps 3-4 replay with other inputs)."""
+    (me, oe), (mg, og) = _graph_vs_eager_models(model_type)
+    hw = (128, 160) if model_type == "interactron" else (300, 300)   # (the decoder fusion's position table is 19 x 19)
+    batches = [to_gpu(synthetic_episodes(2, height=hw[0], width=hw[1], tag="graph-%s" % t)) for t in ("a", "b")]
+    for m in (me, mg):
+        m.eval()
+    hist = []
+    for m, o in ((me, oe), (mg, og)):
+        random.seed(21)
+        steps = []
+        for k in range(4):
+            preds, losses = m(batches[k % 2])
+            grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in m.named_parameters()}
+            o.step()
+            steps.append((preds, losses, grads, {n: p.detach().clone() for n, p in m.named_parameters()}))
+        hist.append(steps)
+    kinds = [type(v).__name__ for v in mg.__dict__.get("_chunk_graphs", {}).values()]
+    assert kinds == ["ChunkGraphs"], ("the graph model did not capture", mg.__dict__.get("_chunk_graphs"))
+    assert not me.__dict__.get("_chunk_graphs")
+    for k, ((p0, l0, g0, w0), (p1, l1, g1, w1)) in enumerate(zip(*hist)):
+        for n in p0:
+            assert torch.equal(p0[n], p1[n]), (k, "prediction", n)
+        for n in l0:
+            assert torch.equal(l0[n], l1[n]), (k, "loss", n, float(l0[n]), float(l1[n]))
+        bad = [n for n in g0 if (g0[n] is None) != (g1[n] is None) or (g0[n] is not None and not torch.equal(g0[n], g1[n]))]
+        assert not bad, (k, "gradients", len(bad), bad[:4])
+        bad = [n for n in w0 if not torch.equal(w0[n], w1[n])]
+        assert not bad, (k, "parameters after clip + Adam", len(bad), bad[:4])
+    if model_type == "interactron":
+        assert {k: v.root.action for k, v in me.path_storage.items()} == {k: v.root.action for k, v in mg.path_storage.items()}
+
+
+def test_chunk_graph_replays_draw_fresh_dropout_masks():
+    """Train mode under graph replay: the dropout seeds are launch arguments frozen into the graph, the device salt
+    (ix_set_dropout_salt) is bumped before every replay -- two replays on the same batch from the same weights must differ
+    (and stay finite); the same salt reproduces the same step bit for bit."""
+    from interactron_amd import Config, build_model
+    m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", EPISODE_CHUNK=2, STEP_GRAPH="true")))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().train()
+    for p in m.parameters():
+        if p.requires_grad:
+            p.grad = torch.zeros_like(p)
+    data = to_gpu(synthetic_episodes(2, height=128, width=160, tag="graph-drop"))
+    vals = []
+    for k in range(5):
+        random.seed(3)
+        m.path_storage.clear()
+        m.zero_grad(set_to_none=False)
+        if k == 4:   # rewind the salt by one step: replay k = 3 again
+            g = next(iter(m._chunk_graphs.values()))
+            from interactron_amd.graphs import GOLDEN
+            g.salt.sub_(GOLDEN).sub_(GOLDEN)
+        _, losses = m(data)
+        vals.append((float(losses["loss_supervisor_ce"]), m.fusion.loss_decoder.layers[0].weight.grad.clone()))
+    assert all(v == v and abs(v) < 1e4 for v, _ in vals)
+    assert vals[2][0] != vals[3][0] and not torch.equal(vals[2][1], vals[3][1]), "two replays drew the same dropout masks"
+    assert vals[4][0] == vals[2][0] and torch.equal(vals[4][1], vals[2][1]), "same salt, different step"
+
+
+def test_predict_graph_replay_equals_eager():
+    """predict() of one episode from a captured graph (graphs.PredictGraph) == eager launches, bit for bit, on three calls with
+    two different episodes (call 1 warms, call 2 captures, call 3 replays other inputs)."""
+    (me, _), (mg, _) = _graph_vs_eager_models("interactron")
+    eps = [to_gpu(synthetic_episodes(1, height=128, width=160, tag="pg-%d" % i)) for i in range(2)]
+    for m in (me, mg):
+        m.eval()
+    for k in (0, 1, 0, 1):
+        a, b = me.predict(eps[k]), mg.predict(eps[k])
+        assert list(a) == list(b)
+        for n in a:
+            assert a[n].shape == b[n].shape and torch.equal(a[n], b[n]), (k, n)
+    assert [type(v).__name__ for v in mg._predict_graphs.values()] == ["PredictGraph"]
+
+
 def test_skipped_gradients_change_nothing_but_the_launch_count():
     """hipops.skip_param_grads: the weight-gradient contractions nobody asked for (nn.Parameters in the MAML inner
     gradient, the per-episode copies in the supervisor backward) are not launched.  Same model, same episodes, with and
