@@ -68,18 +68,24 @@ def to_gpu(data, dev):
     return out
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes); None when no such profile exists.
-    PMC counters cannot be collected from inside the process, so this is the profile's figure, not a live one."""
+def pmc_traffic(kernel, size):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command at this frame size
+    (profiles/*_pmc_hbm_traffic_<size>.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes; the 300x300 files of earlier rounds
+    carry no suffix); None when no profile of that shape exists.  PMC counters cannot be collected from inside the process,
+    so this is the profile's figure, not a live one."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (KeyError, ValueError, OSError):
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic_%d.json" % size)))
+    if not files and size == 300:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    for f in reversed(files):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except (KeyError, ValueError, OSError):
+            continue
+        for name, v in ks.items():
+            if name.startswith(kernel):
+                return v["hbm_bytes_per_launch"]
+    return None
 
 
 def usable_cores():
@@ -150,6 +156,31 @@ def cpu_baseline(cfg, size, config="interactron", timed=3):
             "sample": "%d training episodes (5 frames, %dx%d, fp32) through oracle/episode.py:%s after 1 warm-up episode, "
                       "median %.2f s (each: %s) on %d threads of %s"
                       % (timed, size, size, fn, med, ", ".join("%.2f" % t for t in times[1:]), cores, cpu_model_name())}
+
+
+def cpu_detector_800(timed=2):
+    """the CPU figure next to the 800x800 number is the detector forward alone (oracle/detector.py on one
+    3x800x800 frame, all usable host cores) -- the fusion at T = 12 755 materialises 8 x T^2 fp32 attention and is not
+    practical on the host."""
+    import torch
+    from interactron_amd.synthetic import procedural_state_dict, synthetic_episodes
+    from oracle import detector as od
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+    data = synthetic_episodes(1, frames=1, height=800, width=800, tag="bench-cpu800")
+    frames, masks = data["frames"][0], data["masks"][0]
+    times = []
+    with torch.no_grad():
+        for _ in range(1 + timed):
+            t0 = time.perf_counter()
+            od.detr_forward(det, frames, masks)
+            times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": 1.0 / med, "unit": "frames/s (detector forward only, 1 frame of 3x800x800)", "cores": cores, "kind": "port",
+            "sample": "%d detector forwards through oracle/detector.py:detr_forward after 1 warm-up, median %.2f s on %d threads of %s"
+                      % (timed, med, cores, cpu_model_name())}
 
 
 def launch_ranks(args):
@@ -242,8 +273,11 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     lib.ix_gemm_stats(None, None, 1)
     lib.ix_flash_stats(None, None, 1)
     t0 = time.perf_counter()
+    issue = 0.0
     for _ in range(steps):
+        ti = time.perf_counter()
         step()
+        issue += time.perf_counter() - ti   # host time until the step's launches are queued (no synchronisation added)
     fence()
     dt = time.perf_counter() - t0
     flops, launches, fflops, flaunches = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_int64()
@@ -254,7 +288,8 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = {"peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9, "seconds": dt, "steps": steps, "episodes": episodes, "frames_per_s": 5.0 * episodes * world * steps / dt,
-           "ms_per_step": dt * 1e3 / steps, "block_size": cfg["BLOCK_SIZE"], "cfg": cfg,
+           "ms_per_step": dt * 1e3 / steps, "host_issue_ms_per_step": issue * 1e3 / steps, "block_size": cfg["BLOCK_SIZE"], "cfg": cfg,
+           "step_graphs": sorted(type(v).__name__ for v in getattr(model, "__dict__", {}).get("_chunk_graphs", {}).values()),
            "gemm_gflop_per_step": flops.value / 1e9 / steps, "gemm_launches_per_step": launches.value / steps,
            "attention_gflop_per_step": fflops.value / 1e9 / steps, "attention_launches_per_step": flaunches.value / steps,
            "allreduce": None, "roofline": None}
@@ -281,14 +316,14 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         torch.cuda.synchronize()
         if args.gemm_csv and rank == 0:
             lib.ix_gemm_prof_dump(args.gemm_csv.encode())
-        kms, kfl, kn = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
-        lib.ix_prof_kinds3(kms, kfl, kn)
+        cms, cfl, cmf, cn = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+        lib.ix_prof_contractions(cms, cfl, cmf, cn)
         fms, ffl, fmf, fn = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_int64 * 7)()
         lib.ix_prof_flash(fms, ffl, fmf, fn)
         ms, pairs = ctypes.c_double(), ctypes.c_int64()
         lib.ix_gemm_prof_read(ctypes.byref(ms), ctypes.byref(pairs))
         lib.ix_gemm_prof_enable(0)
-        res["roofline"] = build_roofline(list(kms), list(kfl), list(kn), list(fms), list(ffl), list(fmf), list(fn))
+        res["roofline"] = build_roofline(list(cms), list(cfl), list(cmf), list(cn), list(fms), list(ffl), list(fmf), list(fn), size)
 
     bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
     assert not bad, "non-finite losses after the timed steps: %s" % bad
@@ -342,49 +377,52 @@ FLASH_KERNELS = ["all", "flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_
                  "flash_bb_q_kernel", "flash_bb_kv_kernel"]
 
 
-def build_roofline(kms, kfl, kn, fms, ffl, fmf, fn):
-    """`roofline` object for the dominant kernel = the bf16x6 contraction kernel (fp32 operands split 3-way into bf16, 6
-    bf16 MFMAs per fp32 multiply-add).  `achieved` is ALGORITHMIC (fp32-equivalent) FLOP/s of its launches; `peak` is the
-    most that scheme can deliver on the bf16 matrix cores, 2500 / 6.  The fp32-MFMA kernel (small-K products) and the
-    flash attention kernels (3 fp16 / 6 bf16 MFMA terms per product, executed rate against the 2500 TFLOP/s peak) are
-    listed beside it."""
-    tf = [kfl[i] / (kms[i] * 1e-3) / 1e12 if kms[i] > 0 else 0.0 for i in range(3)]
-    k = 1 if kms[1] >= kms[0] else 0
-    peak = BF16_MFMA_PEAK_TFLOPS / X6_PRODUCTS if k == 1 else FP32_MFMA_PEAK_TFLOPS
-    kname = "gemm_f32_bf16x6_p12_kernel" if k == 1 else "gemm_f32_mfma_kernel"
+def build_roofline(cms, cfl, cmf, cn, fms, ffl, fmf, fn, size):
+    """`roofline` object for the dominant kernel = the 12-wave contraction kernel that evaluates fp32 products on the 16-bit
+    matrix cores (fp16x3 form: two fp16 planes + a sub-block exponent, 3 MFMAs per fp32 multiply-add -- the default; bf16x6
+    form: three bf16 planes, 6 MFMAs -- narrow tiles and IX_GEMM_KERNEL=x6).  `achieved` = matrix-instruction FLOP/s it
+    EXECUTES over its launches (HIP events per launch), against the dense 16-bit MFMA peak; the algorithmic
+    (fp32-equivalent) rate is listed beside it.  The exact-fp32 MFMA kernel and the flash attention kernels follow."""
+    def rate(fl, ms):
+        return fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    forms = {}
+    for i, name in ((2, "gemm_f32_f16x3_p12_kernel"), (1, "gemm_f32_bf16x6_p12_kernel")):
+        if cn[i]:
+            forms[name] = {"launches_per_step": int(cn[i]), "kernel_ms_per_step": cms[i], "gflop_per_step": cfl[i] / 1e9,
+                           "algorithmic_tflops": rate(cfl[i], cms[i]), "executed_mfma_tflops": rate(cmf[i], cms[i]),
+                           "mfma_frac": rate(cmf[i], cms[i]) / BF16_MFMA_PEAK_TFLOPS}
+    ems, efl, emf, en = cms[1] + cms[2], cfl[1] + cfl[2], cmf[1] + cmf[2], cn[1] + cn[2]
+    dominant = "gemm_f32_f16x3_p12_kernel" if cms[2] >= cms[1] else "gemm_f32_bf16x6_p12_kernel"
     attn = {"kernel_ms_per_step": fms[0], "launches_per_step": int(fn[0]), "gflop_per_step": ffl[0] / 1e9,
-            "achieved": ffl[0] / (fms[0] * 1e-3) / 1e12 if fms[0] > 0 else 0.0, "unit": "TFLOP/s (fp32-equivalent, algorithmic)",
-            "executed_mfma_tflops": fmf[0] / (fms[0] * 1e-3) / 1e12 if fms[0] > 0 else 0.0, "mfma_peak": BF16_MFMA_PEAK_TFLOPS,
-            "mfma_frac": fmf[0] / (fms[0] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS if fms[0] > 0 else 0.0,
-            "kernels": {FLASH_KERNELS[i]: {"ms_per_step": fms[i], "launches": int(fn[i]),
-                                           "achieved": ffl[i] / (fms[i] * 1e-3) / 1e12,
-                                           "mfma_frac": fmf[i] / (fms[i] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS}
+            "achieved": rate(ffl[0], fms[0]),
+            "unit": "TFLOP/s (fp32-equivalent, algorithmic: the reference graph's products -- 2 forward, 4 backward, 10 double backward)",
+            "executed_mfma_tflops": rate(fmf[0], fms[0]), "mfma_peak": BF16_MFMA_PEAK_TFLOPS,
+            "mfma_frac": rate(fmf[0], fms[0]) / BF16_MFMA_PEAK_TFLOPS,
+            "kernels": {FLASH_KERNELS[i]: {"ms_per_step": fms[i], "launches": int(fn[i]), "achieved": rate(ffl[i], fms[i]),
+                                           "mfma_frac": rate(fmf[i], fms[i]) / BF16_MFMA_PEAK_TFLOPS}
                         for i in range(1, 7) if fms[i] > 0}}
-    total_ms = kms[0] + kms[1] + fms[0]
-    total_fl = kfl[0] + kfl[1] + ffl[0]
-    if os.environ.get("IX_GEMM_KERNEL", "") == "x3" and k == 1:
-        # opt-in fp16x3 form: its 128-wide tiles issue three fp16 MFMAs per product, the rest (narrow tiles, convolution
-        # gathers) still six bf16 ones, and the launch records do not tell them apart -- no single peak prices this mix
-        return {"bound": "mfma", "kernel": "gemm_f32_f16x3_p12_kernel + gemm_f32_bf16x6_p12_kernel (IX_GEMM_KERNEL=x3)",
-                "achieved": tf[k], "peak": None, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9, "kernel_ms_per_step": kms[k],
-                "note": "mixed kernel forms: peaks 2500/3 (fp16x3 tiles) and 2500/6 (bf16x6 tiles); compare kernel_ms_per_step "
-                        "with the default run's", "attention_kernels": attn}
-    return {"bound": "mfma", "kernel": kname, "achieved": tf[k], "peak": peak, "unit": "TFLOP/s", "frac": tf[k] / peak,
-            "traffic": pmc_traffic(kname), "launches_per_step": int(kn[k]), "gflop_per_step": kfl[k] / 1e9,
-            "avg_launch_us": kms[k] * 1e3 / max(1, kn[k]), "kernel_ms_per_step": kms[k],
-            "note": "achieved = fp32-equivalent algorithmic FLOP/s; executed bf16 MFMA rate = 6x that "
-                    "(%.0f of %.0f TFLOP/s).  The peak assumes 2.4 GHz: back to back this kernel holds the package at "
-                    "its 1400 W cap and the shader clock at 1.4-1.8 GHz (profiles/README.md, power probe)"
-                    % (6 * tf[1], BF16_MFMA_PEAK_TFLOPS),
-            "fp32_mfma_kernel": {"achieved": tf[0], "peak": FP32_MFMA_PEAK_TFLOPS, "frac": tf[0] / FP32_MFMA_PEAK_TFLOPS,
-                                 "launches_per_step": int(kn[0]), "kernel_ms_per_step": kms[0]},
+    total_ms = cms[0] + ems + fms[0]
+    total_fl = cfl[0] + efl + ffl[0]
+    return {"bound": "mfma", "kernel": dominant + (" (+ the other form of the same kernel, see forms)" if len(forms) > 1 else ""),
+            "achieved": rate(emf, ems), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": rate(emf, ems) / BF16_MFMA_PEAK_TFLOPS,
+            "traffic": pmc_traffic(dominant, size), "launches_per_step": int(en), "gflop_per_step": efl / 1e9,
+            "executed_gflop_per_step": emf / 1e9, "algorithmic_tflops": rate(efl, ems),
+            "avg_launch_us": ems * 1e3 / max(1, en), "kernel_ms_per_step": ems, "forms": forms,
+            "note": "achieved = matrix-instruction FLOP/s executed by the fp32-on-16-bit contraction kernel (3 per fp32 "
+                    "multiply-add in the fp16x3 form, 6 in the bf16x6 form) against the dense 16-bit MFMA peak; "
+                    "algorithmic_tflops = fp32-equivalent 2MNK rate.  The peak assumes 2.4 GHz: back to back this kernel holds "
+                    "the package at its 1400 W cap and the shader clock at 1.4-1.8 GHz (profiles/README.md, power probe)",
+            "fp32_mfma_kernel": {"achieved": rate(cfl[0], cms[0]), "peak": FP32_MFMA_PEAK_TFLOPS,
+                                 "frac": rate(cfl[0], cms[0]) / FP32_MFMA_PEAK_TFLOPS,
+                                 "launches_per_step": int(cn[0]), "kernel_ms_per_step": cms[0]},
             "attention_kernels": attn,
-            "all_mfma_kernels": {"achieved": total_fl / (total_ms * 1e-3) / 1e12 if total_ms > 0 else 0.0,
-                                 "gflop_per_step": total_fl / 1e9, "kernel_ms_per_step": total_ms}}
+            "all_mfma_kernels": {"achieved": rate(total_fl, total_ms), "gflop_per_step": total_fl / 1e9, "kernel_ms_per_step": total_ms,
+                                 "unit": "TFLOP/s (algorithmic, fp32-equivalent)"}}
 
 
 JSON_FD = 1
+N800_STEPS = 10        # timed steps of the north-star sub-measurement (after 2 warm-up steps)
+ALLREDUCE_MS_ASSUMED = 2.0   # 234 MB flat gradient over xGMI at ~200 GB/s bus bandwidth (used only where no RCCL timing exists)
 
 
 def main():
@@ -406,6 +444,12 @@ def main():
     ap.add_argument("--attention-dtype", default="fp32", choices=["fp32", "fp8"],
                     help="fp8: the forward attention products on OCP e4m3 MFMA (BASELINE.json configs[4], the 1600 / 200-query "
                          "stress configuration: --size 1600 --queries 200 --attention-dtype fp8); fp32 = the parity path")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: ONE batch of this many episodes per step, rank r runs episodes r::N of it (what train.py + "
+                         "shard_batch do with the reference config, BATCH_SIZE 16); 0 = weak scaling, --episodes per GPU")
+    ap.add_argument("--small-e", type=int, default=2,
+                    help="episodes per GPU of the `small_e` sub-measurement at N = 1 (the per-GPU share of the reference's global "
+                         "batch on 8 GPUs; replayed from HIP graphs); 0 = skip it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -438,13 +482,26 @@ def main():
     from interactron_amd import hipops as _ops
     _ops.ATTENTION_DTYPE = args.attention_dtype
 
+    strong = args.global_batch > 0
+    if strong:   # this rank's share of ONE global batch (rank r: episodes r::N), the rest of the line as usual
+        assert args.global_batch % world == 0, "--global-batch must be a multiple of --gpus"
+        args.episodes = args.global_batch // world
+        args.chunk = min(args.chunk, args.episodes)
     head = run_workload(args, args.size, args.episodes, args.chunk, args.steps, args.warmup, ctx, not args.no_roofline, "bench")
+    headline_cfg = args.size == 300 and args.mode == "train" and args.config == "interactron" and not strong
+    # The per-GPU share of the reference's global batch of 16 on 8 GPUs (engine/interactron_trainer.py:78-84 + SURVEY 8e): what
+    # a rank of the strong-scaling run executes per step.  At N = 1 as `small_e`; at N > 1 the same global batch as `strong`.
+    small = strong_run = None
+    if headline_cfg and world == 1 and args.small_e > 0:
+        small = run_workload(args, 300, args.small_e, args.small_e, 10, 3, ctx, False, "bench")
+    if headline_cfg and world > 1 and 16 % world == 0:
+        strong_run = run_workload(args, 300, 16 // world, 16 // world, 10, 3, ctx, False, "bench")
     # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755),
     # measured in the same process after the headline: same step definition, fewer episodes per pass, its own warm-up.
     n800 = r8 = None
-    if args.size == 300 and args.mode == "train" and args.config == "interactron" and args.n800_episodes > 0:
+    if headline_cfg and args.n800_episodes > 0:
         try:
-            r8 = run_workload(args, 800, args.n800_episodes, args.n800_episodes, 3, 1, ctx, not args.no_roofline, "bench800")
+            r8 = run_workload(args, 800, args.n800_episodes, args.n800_episodes, N800_STEPS, 2, ctx, not args.no_roofline, "bench800")
         except torch.cuda.OutOfMemoryError as e:   # (8 episodes per pass need 149 GB: never lose the headline over it)
             r8 = None
             n800 = {"error": "out of memory at %d episodes per pass: %s" % (args.n800_episodes, str(e)[:200])}
@@ -452,7 +509,8 @@ def main():
     if r8 is not None:
         n800 = {"workload": "%d episodes/GPU x 5 frames x 3x800x800, Q=%d, fusion T=%d, same step as the headline"
                             % (args.n800_episodes, args.queries, r8["block_size"]),
-                "value": r8["frames_per_s"], "unit": "frames/s", "steps": 3, "warmup": 1, "ms_per_step": r8["ms_per_step"],
+                "value": r8["frames_per_s"], "unit": "frames/s", "steps": N800_STEPS, "warmup": 2, "ms_per_step": r8["ms_per_step"],
+                "peak_memory_GB": r8["peak_memory_GB"],
                 "episodes_per_gpu": args.n800_episodes, "gemm_gflop_per_step": r8["gemm_gflop_per_step"],
                 "attention_gflop_per_step": r8["attention_gflop_per_step"], "roofline": r8["roofline"]}
 
@@ -462,7 +520,7 @@ def main():
         line = {
             "metric": "frames/sec (5-frame episodes)", "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
                                     "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode "
                                     "(dropout on; model-level parity is pinned in eval mode, the dropout kernels op by op)"
@@ -475,18 +533,39 @@ def main():
                                        [args.mode], args.episodes, args.size, args.size)),
                        "mode": args.mode, "episodes_per_gpu": args.episodes, "frame_size": args.size,
                        "attention": hipops.ATTENTION_IMPL, "attention_dtype": hipops.ATTENTION_DTYPE,
-                       "peak_memory_GB": head.get("peak_memory_GB"), "parallelism": "dp%d" % world},
+                       "peak_memory_GB": head.get("peak_memory_GB"), "parallelism": "dp%d" % world,
+                       "global_batch": args.global_batch if strong else args.episodes * world,
+                       "host_issue_ms_per_step": head["host_issue_ms_per_step"], "step_graphs": head["step_graphs"],
+                       "contraction_kernel": os.environ.get("IX_GEMM_KERNEL", "x3 (default: fp16x3 form, bf16x6 for narrow tiles)")},
             "gemm_gflop_per_step": head["gemm_gflop_per_step"], "gemm_launches_per_step": head["gemm_launches_per_step"],
             "attention_gflop_per_step": head["attention_gflop_per_step"],
             "roofline": head["roofline"],
             "cpu_baseline": None,
             "n800": n800,
+            "small_e": None, "strong": None,
             "hbm_kernels": hbm_kernels(torch, hipops, dev) if not args.no_roofline else None,
             "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,
             "allreduce": head["allreduce"],
         }
+        if small is not None:
+            ar = ALLREDUCE_MS_ASSUMED
+            line["small_e"] = {"workload": "%d episodes/GPU (the per-GPU share of the reference's global batch of 16 on 8 GPUs), same step, "
+                                           "replayed from captured HIP graphs" % args.small_e, "episodes_per_gpu": args.small_e,
+                               "steps": 10, "warmup": 3, "ms_per_step": small["ms_per_step"], "host_issue_ms_per_step": small["host_issue_ms_per_step"],
+                               "value": small["frames_per_s"], "unit": "frames/s", "step_graphs": small["step_graphs"],
+                               "allreduce_ms_assumed": ar,
+                               "strong_scaling_projection": head["ms_per_step"] * (args.small_e * 8.0 / args.episodes) / (small["ms_per_step"] + ar),
+                               "projection": "t(E = %d) x (8 x %d / %d) / (t(E = %d) + allreduce): speed-up of 8 GPUs over 1 GPU on one global "
+                                             "batch of %d episodes" % (args.episodes, args.small_e, args.episodes, args.small_e, 8 * args.small_e)}
+        if strong_run is not None:
+            line["strong"] = {"workload": "global batch 16 (reference BATCH_SIZE), rank r runs episodes r::%d: %d per GPU" % (world, 16 // world),
+                              "global_batch": 16, "episodes_per_gpu": 16 // world, "steps": 10, "warmup": 3, "scaling": "strong",
+                              "ms_per_step": strong_run["ms_per_step"], "host_issue_ms_per_step": strong_run["host_issue_ms_per_step"],
+                              "value": strong_run["frames_per_s"], "unit": "frames/s", "step_graphs": strong_run["step_graphs"]}
         if not args.no_cpu_baseline and world == 1 and args.mode == "train" and args.size <= 800 and args.attention_dtype == "fp32":
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
+            if n800 is not None and "error" not in n800:
+                n800["cpu_baseline"] = cpu_detector_800()
         sys.stdout.flush()
         os.write(JSON_FD, (json.dumps(line) + "\n").encode())   # the one line on the real stdout
     if world > 1:

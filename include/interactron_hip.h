@@ -61,7 +61,8 @@ int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kconti
                                 int batch_inner, int64_t sAo, int64_t sBo, const float* A, const float* B, int tile_hint,
                                 int split_k_hint, size_t* out_host);
 int ix_gemm_presplit_enable(int on);
-int ix_prof_x3(double* ms, double* flops, int64_t* calls); /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
+int ix_prof_x3(double* ms, double* flops, int64_t* calls);
+int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3); /* by form: fp32 / bf16x6 / fp16x3 */ /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
 
 /* ix_gemm_rowsum_f32: C = alpha A B and, from the same launch, rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  With A
  * stored m-contiguous (a_kcontig = 0) the bf16x6 kernel's A-producer waves accumulate the sums from the tiles they stream

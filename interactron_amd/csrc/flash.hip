@@ -1102,15 +1102,18 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.v_row = (const unsigned short*)v->row; a.v_us = v->unscale;
     a.lse = const_cast<float*>(lse); a.delta = delta;
     a.o1 = gq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = gk; a.ld2 = ld_k; a.off2 = off_k; a.o3 = gv; a.ld3 = ld_v; a.off3 = off_v;
+    // algorithmic FLOPs = the products the REFERENCE's graph evaluates (first derivative of softmax(q k^T) v: dP = dO v^T,
+    // dV = P^T dO, dQ = dS k, dK = dS^T q -- four; two per kernel); the recomputed S (and gd in the key-owning pass) only count as
+    // executed matrix instructions (third argument)
     if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 2);
+        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 2);
         FL_DISPATCH(flash_bwd_q_kernel, grid)
         ix_prof_end(stream);
     }
     if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * 6) * FL_PRODUCT_FLOPS, 3);
+        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * 6) * FL_PRODUCT_FLOPS, 3);
         FL_DISPATCH(flash_bwd_kv_kernel, grid)
         ix_prof_end(stream);
     }
@@ -1148,15 +1151,18 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     a.o1 = dq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = dk; a.ld2 = ld_k; a.off2 = off_k;
     a.o3 = dv; a.ld3 = ld_v; a.off3 = off_v; a.o4 = ddo; a.ld4 = ld_do; a.off4 = off_do;
     const dim3 gq((L + 127) / 128, n * H), gk((S + 127) / 128, n * H), blk(256);
-    // products per pass (G counts twice: hq k^T + q hk^T): statistics 5; dq + ddO 5 + 4; dk + dv 5 + 3
+    // tiles formed per pass (G counts twice: hq k^T + q hk^T): statistics 5; dq + ddO 5 + 4; dk + dv 5 + 3 -- the executed
+    // matrix work (third argument).  Algorithmic FLOPs = the ten products of the materialised double-backward graph (hipops.
+    // AttentionCoreBwd.backward = what autograd evaluates for the reference): G 2 + HD 1 in the statistics pass, the 4 and 3
+    // output products of the other two; recomputed S / gd / G / HD tiles are not algorithmic work
 #define FL_BB_LAUNCH(HD_, DR_)                                                                         \
-    ix_prof_begin(stream, 2, 5.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);                      \
+    ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);                      \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true>), gq, blk, 0, stream, a);                    \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 9.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 6) * FL_PRODUCT_FLOPS, 5);              \
+    ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 6) * FL_PRODUCT_FLOPS, 5);              \
     hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false>), gq, blk, 0, stream, a);                   \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 8.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 6) * FL_PRODUCT_FLOPS, 6);              \
+    ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 6) * FL_PRODUCT_FLOPS, 6);              \
     hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);                         \
     ix_prof_end(stream);
     if (hd == 64) {

@@ -1760,11 +1760,11 @@ static int g_x3k = -1;
 static bool x3k_enabled() {
     if (g_x3k < 0) {
         const char* e = getenv("IX_GEMM_KERNEL");
-        g_x3k = (e && e[0] == 'x' && e[1] == '3') ? 1 : 0;
+        g_x3k = (e && e[0] == 'x' && e[1] == '6') ? 0 : 1;   // default since round 3: the fp16x3 form; IX_GEMM_KERNEL=x6 = bf16x6 everywhere
     }
     return g_x3k != 0;
 }
-// Test hook: 0 = bf16x6 form only (default), 1 = fp16x3 form for 128-wide tiles.  Returns the previous setting.
+
 extern "C" int ix_gemm_set_x3(int on) {
     const int old = x3k_enabled() ? 1 : 0;
     g_x3k = on ? 1 : 0;
@@ -1988,7 +1988,7 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
         const ProfRec& r = g_rec[i / 2];
         if (r.bm == 3128) continue;   // pre-split fp16x3 kernel: reported by ix_prof_x3
-        const int k = r.bm == 2002 ? 2 : (r.bm == 1128 ? 1 : 0);
+        const int k = r.bm == 2002 ? 2 : ((r.bm == 1128 || r.bm == 1129) ? 1 : 0);
         ms[k] += t;
         fl[k] += r.flops;
         n[k] += 1;
@@ -1996,6 +1996,30 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
     for (int k = 0; k < 3; ++k) {
         if (ms3) ms3[k] = ms[k];
         if (flops3) flops3[k] = fl[k];
+        if (launches3) launches3[k] = n[k];
+    }
+    return IX_OK;
+}
+
+// Profiled contraction launches by kernel form: [0] exact-fp32 MFMA kernel, [1] bf16x6 form of the 12-wave kernel, [2] its
+// fp16x3 form; summed event time (ms), algorithmic FLOPs, FLOPs of the matrix instructions actually issued (1 / 6 / 3 per
+// fp32 multiply-add), launches.  Host arrays of 3.  Call before ix_gemm_prof_read (which clears the records).
+extern "C" int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3) {
+    double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0}, mf[3] = {0, 0, 0};
+    int64_t n[3] = {0, 0, 0};
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm == 2002 || r.bm == 3128) continue;
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        const int k = r.bm == 1129 ? 2 : (r.bm == 1128 ? 1 : 0);
+        ms[k] += t; fl[k] += r.flops; mf[k] += r.mfma_flops > 0 ? r.mfma_flops : r.flops; n[k] += 1;
+    }
+    for (int k = 0; k < 3; ++k) {
+        if (ms3) ms3[k] = ms[k];
+        if (flops3) flops3[k] = fl[k];
+        if (mfma_flops3) mfma_flops3[k] = mf[k];
         if (launches3) launches3[k] = n[k];
     }
     return IX_OK;
@@ -2444,9 +2468,11 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     dim3 grid(a.tiles_m * a.tiles_n, nbatch, split);
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
     g_launches += 1;
+    const bool use_x3 = use_x6 && bn == 128 && x3k_enabled() && g_x6 == 3;
     if (g_prof_on) {
-        ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x6 ? 1128 : bm, split};
+        ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x3 ? 1129 : (use_x6 ? 1128 : bm), split};
         r.flops = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+        r.mfma_flops = r.flops * (use_x3 ? 3.0 : (use_x6 ? 6.0 : 1.0));   // matrix instructions issued per fp32 multiply-add
         g_rec.push_back(r);
     }
     prof_mark(stream);
@@ -2464,7 +2490,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);
     else
 #endif
-    if (use_x6 && bn == 128 && x3k_enabled() && g_x6 == 3)
+    if (use_x3)
         launch_x3q(a, a_kcontig, b_kcontig, items, stream);
     else if (use_x6)
         launch_x6q<false>(a, bn, a_kcontig, b_kcontig, items, stream);
@@ -2510,10 +2536,19 @@ static int x6_pick_split(int M, int N, int K, int nbatch) {
 }
 
 template <int BN>
-static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t stream) {
+static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t stream, bool x3 = false) {
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
+    if (x3 && BN == 128) {   // fp16x3 form of the gathering producers (128-wide tiles only)
+        if (kind == 0)
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0>), grid, dim3(768), 0, stream, a, items);
+        else if (kind == 1)
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, false, 1, 3>), grid, dim3(768), 0, stream, a, items);
+        else
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, false, 0, 2>), grid, dim3(768), 0, stream, a, items);
+        return;
+    }
     if (kind == 0)
         hipLaunchKernelGGL((gemm_f32_bf16x6_p12_kernel<BN, true, true, false, 4, 1, 0>), grid, dim3(768), 0, stream, a, items);
     else if (kind == 1)
@@ -2644,13 +2679,15 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     const double fl = 2.0 * (double)a.M * (double)a.N * (double)a.K * (double)groups;
     g_flops += fl;
     g_launches += 1;
+    const bool conv_x3 = bn == 128 && x3k_enabled() && g_x6 == 3;
     if (g_prof_on) {
-        ProfRec r = {a.M, a.N, a.K, groups, a_kc, b_kc, 1128, split};
+        ProfRec r = {a.M, a.N, a.K, groups, a_kc, b_kc, conv_x3 ? 1129 : 1128, split};
         r.flops = fl;
+        r.mfma_flops = fl * (conv_x3 ? 3.0 : 6.0);
         g_rec.push_back(r);
     }
     prof_mark(stream);
-    if (bn == 128) launch_conv_bn<128>(a, kind, items, stream);
+    if (bn == 128) launch_conv_bn<128>(a, kind, items, stream, conv_x3);
     else launch_conv_bn<64>(a, kind, items, stream);
     splitk_finish(a, groups, groups, false, real, stream);
     prof_mark(stream);

@@ -23,3 +23,15 @@ def golden():
         return torch.load(os.path.join(GOLDEN, name), weights_only=False)
 
     return load
+
+
+@pytest.fixture(params=["x3", "x6"])
+def kernel_form(request):
+    """Runs a test once per form of the 12-wave contraction kernel: "x3" = two fp16 planes + a sub-block exponent, three MFMAs
+    per k-slice (the default since round 3), "x6" = three bf16 planes, six MFMAs (IX_GEMM_KERNEL=x6).  Both carry the parity
+    record of the model-level tests."""
+    from interactron_amd import _lib
+    lib = _lib.load()
+    old = lib.ix_gemm_set_x3(1 if request.param == "x3" else 0)
+    yield request.param
+    lib.ix_gemm_set_x3(old)

@@ -115,14 +115,14 @@ def test_two_ranks_equal_one_process():
         rel[k] = d / n0
     # float32 summation-order differences between the episode-batched pass and two single-episode passes (other shapes pick
     # other tiles / splits; then ~50 ReLU layers and the clipped inner step).  Every reduction is ordered, so this is a fixed
-    # number, not a scatter: measured (r3) total norm 3.6e-5, update 2.3e-7, whole gradient 2.0e-4, median tensor 1.1e-4,
-    # worst tensor 9.2e-3 (layer4.2.conv1).  Bounds ~3x above that (round 2, atomics: 3 % whole, 60 % worst); a missing or
+    # number, not a scatter: measured (r3, fp16x3 contraction form) total norm 7.6e-5, update 1.2e-6, whole gradient 7.4e-4,
+    # median tensor 5.6e-4, worst tensor 2.5e-2 (layer3.1.conv1; bf16x6 form: 2.0e-4 / 1.1e-4 / 9.2e-3).  Bounds ~3x above that (round 2, atomics: 3 % whole, 60 % worst); a missing or
     # doubled episode would put EVERY tensor off by ~50 % / 100 %.
     vals = sorted(rel.values())
     print("two ranks vs one process: total norm %.2e, update %.2e, whole gradient %.2e, median tensor %.2e, worst %.2e (%s)"
           % (abs(t0 - ref_total) / ref_total, abs(d0 - ref_delta) / ref_delta, (num / den) ** 0.5, vals[len(vals) // 2], vals[-1],
              max(rel.items(), key=lambda kv: kv[1])[0]))
-    assert (num / den) ** 0.5 <= 1e-3, (num, den)
-    assert vals[len(vals) // 2] <= 5e-4, vals[len(vals) // 2]
+    assert (num / den) ** 0.5 <= 2e-3, (num, den)
+    assert vals[len(vals) // 2] <= 1.5e-3, vals[len(vals) // 2]
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    assert vals[-1] <= 3e-2, worst
+    assert vals[-1] <= 6e-2, worst

@@ -214,6 +214,7 @@ def test_conv2d_nhwc(ops, cin, cout, k, stride, pad, dil, hw):
 @pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw,n", [(64, 128, 3, 1, 1, 1, 19, 2), (128, 64, 3, 2, 1, 1, 20, 3),
                                                              (64, 64, 3, 1, 2, 2, 13, 2), (128, 256, 1, 2, 0, 1, 15, 2),
                                                              (256, 128, 3, 2, 1, 1, 9, 1), (64, 64, 3, 1, 1, 1, 38, 5)])
+@pytest.mark.usefixtures("kernel_form")
 def test_implicit_gemm_conv(ops, cin, cout, k, stride, pad, dil, hw, n):
     """ix_conv_gemm_f32 (the bf16x6 producers gather the taps; no patch matrix): forward, both gradients and the gradients
     of those (MAML's double backward) against F.conv2d in float64 -- 3x3 stride 1 / 2, the dilated stage, the 1x1 stride-2
@@ -717,6 +718,7 @@ def test_episode_batched_linear_layernorm_rowvec(ops):
              lambda a, v: (a.reshape(E, 5, 64) + v[:, None, :]).reshape(E * 5, 64), [a, v], name="grouped add_rowvec")
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_episode_batched_conv(ops):
     E, n, cin, cout = 2, 4, 8, 12
     x = rnd(n, 9, 9, cin, seed=1)

@@ -235,6 +235,7 @@ def test_g10_clipped_sgd_bit_exact(golden):
         assert torch.equal(a.cpu(), b)
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_g7_detector_forward(golden, interactron_model, episode1):
     from interactron_amd import NestedTensor
     M = golden("golden_model.pt")
@@ -244,6 +245,7 @@ def test_g7_detector_forward(golden, interactron_model, episode1):
         check_record(rec, out[k], atol=rec_tol(rec), rtol=1e-3, what="g7/" + k)
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_g8_g9_fusion_and_learned_loss_gradient(golden, interactron_model, episode1):
     from interactron_amd import NestedTensor, hipops
     from interactron_amd.meta import get_parameters, set_parameters
@@ -267,6 +269,7 @@ def test_g8_g9_fusion_and_learned_loss_gradient(golden, interactron_model, episo
         check_grad(M["g9"]["grads"][name], gi, rel=5e-3, what="g9/" + name)
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_g11_g12_predict_and_next_action(golden, interactron_model, episode1):
     M = golden("golden_model.pt")
     pred = interactron_model.predict(episode1)
@@ -281,13 +284,14 @@ def test_g11_g12_predict_and_next_action(golden, interactron_model, episode1):
         torch.testing.assert_close(got.cpu(), ref, atol=1e-3 * float(ref.abs().max()) + 1e-4, rtol=1e-3)
 
 
-# measured (r3): the MEDIAN tensor is closer to float64 than the reference's own float32 is (norm 3.1e-5 vs 1.0e-4, strided
-# sample 2.6e-4 vs 6.6e-4 of the tensor); worst excess over twice the reference's error: norm 1.05e-3 (layer3.3.conv1, every
-# other tensor below 1e-3), strided sample 3.3e-5
-F64_SLACK_NORM, F64_SLACK_SAMPLE = 2e-3, 1e-3
+# measured (r3): the MEDIAN tensor is closer to float64 than the reference's own float32 is, with either form of the contraction
+# kernel (norm 2.0e-5 (x3) / 3.1e-5 (x6) vs 1.0e-4; strided sample 1.9e-4 / 2.6e-4 vs 6.6e-4 of the tensor).  Worst excess over
+# twice the reference's error -- tensors with elements on ReLU / clip kinks, where the reference itself is up to 0.7 % off:
+# x6: norm 1.05e-3 (layer3.3.conv1), sample 3.3e-5;  x3: norm 3.0e-3 (layer3.3.conv1), sample 3.3e-3 (layer3.0.conv2).
+F64_SLACK = {"x6": (2e-3, 1e-3), "x3": (6e-3, 6e-3)}
 
 
-def test_g13_g16_meta_train_step_and_outer_update(golden):
+def test_g13_g16_meta_train_step_and_outer_update(golden, kernel_form):
     T = golden("golden_train.pt")
     F64 = golden("golden_train_f64.pt")   # exact (float64 oracle) norms: bounds the reference's own float32 noise
     m = make("interactron")
@@ -333,8 +337,8 @@ def test_g13_g16_meta_train_step_and_outer_update(golden):
     for name, ex in (("norm", ex_norm), ("strided sample", ex_samp)):
         print("g13 vs float64, %s: worst excess %.2e (HIP %.2e, reference fp32 %.2e) on %s; median HIP error %.2e, median "
               "reference error %.2e" % ((name,) + ex[0] + (sorted(e[1] for e in ex)[len(ex) // 2], sorted(e[2] for e in ex)[len(ex) // 2])))
-    assert ex_norm[0][0] <= F64_SLACK_NORM, ex_norm[:3]
-    assert ex_samp[0][0] <= F64_SLACK_SAMPLE, ex_samp[:3]
+    assert ex_norm[0][0] <= F64_SLACK[kernel_form][0], ex_norm[:3]
+    assert ex_samp[0][0] <= F64_SLACK[kernel_form][1], ex_samp[:3]
     labels = {k: v.get_label(data["actions"][0][:4].tolist()) for k, v in m.path_storage.items()}
     assert labels == T["g13"]["path_labels"]
     # G16: clip_grad_norm_(all, 1.0) + Adam(detector, 1e-5) + Adam(fusion, 1e-4) as one fused flat-buffer step
@@ -609,6 +613,7 @@ def test_policy_step_graph_replay_equals_eager():
     assert picks[True][0] == picks[False][0] == picks[True][1]
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_config1_detr(golden, episode1):
     O = golden("golden_configs.pt")
     m = make("detr")
@@ -625,6 +630,7 @@ def test_config1_detr(golden, episode1):
         check_grad(O["detr_forward"]["grads"][k], p.grad, rel=5e-3, what="detr/" + k, norm64=F64.get(k))
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_config2_multiframe(golden, episode1):
     O = golden("golden_configs.pt")
     m = make("detr_multiframe")
@@ -647,6 +653,7 @@ def test_config2_multiframe(golden, episode1):
                    norm64=F64["fusion_grads"].get(k))
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_config3_interactron_random(golden, episode1):
     O = golden("golden_configs.pt")
     m = make("interactron_random")
@@ -668,6 +675,7 @@ def test_config3_interactron_random(golden, episode1):
                    norm64=F64["fusion_grads"].get(k))
 
 
+@pytest.mark.usefixtures("kernel_form")
 def test_oracle_parity_fresh_inputs_small_resolution():
     """HIP vs CPU oracle on inputs no fixture covers (different seed, 160x128 frames, padded masks)."""
     from interactron_amd import NestedTensor
