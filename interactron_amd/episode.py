@@ -284,6 +284,7 @@ class _Adaptive(_EpisodeModel):
     #     C  the first-order branch (reference :126-134): detector on one random frame through theta', criterion, backward
     #     --  host: PathStorage bookkeeping on the rewards, policy labels up
     #     B  policy cross-entropy, supervisor total, second-order backward
+    #     D  .grad += C's gradients (C and B share no state, so a replay runs them concurrently on two streams)
     # Issued eagerly (default for large chunks: the step is GPU-bound) or replayed from three captured HIP graphs
     # (graphs.ChunkGraphs; small chunks are bound by the host issuing ~6 000 launches, STEP_GRAPH: auto / true / false).
     def _seg_a(self, st):
@@ -337,8 +338,24 @@ class _Adaptive(_EpisodeModel):
         st.det_rows = det_rows.detach()
         st.logits1, st.boxes1 = post1_lb["pred_logits"].detach(), post1_lb["pred_boxes"].detach()
         st.mark("6 first-order SGD + 1-frame fwd + criterion")
-        ops.Dot.apply(det_rows, _loss_weights(E, st.frames.device)).backward()
+        # the gradients come back as tensors and are added into .grad by segment D: this segment then touches no state the
+        # supervisor backward (segment B) touches, and a graph replay runs the two on different streams at the same time
+        st.c_params = [p for p in list(theta) + self._in_proj if p.requires_grad]
+        st.c_grads = torch.autograd.grad(ops.Dot.apply(det_rows, _loss_weights(E, st.frames.device)), st.c_params, allow_unused=True)
         st.mark("7 first-order backward")
+
+    def _seg_d(self, st):
+        """.grad += the first-order branch's gradients (one multi-tensor launch; a parameter without a .grad gets the tensor)"""
+        dst, src = [], []
+        for p, g in zip(st.c_params, st.c_grads):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                dst.append(p.grad)
+                src.append(g)
+        ops.accumulate_multi(dst, src)
 
     def _seg_b(self, st):
         E = st.E
@@ -370,6 +387,8 @@ class _Adaptive(_EpisodeModel):
         det_out, sup_out, path_out, reward_out, logits_out, boxes_out = [], [], [], [], [], []
         self._theta = theta = self._real_parameters()
         self._targets2 = self._second_order_targets()
+        theta_ids = {id(p) for p in theta}
+        self._in_proj = [p for p in self.detector.parameters() if p.requires_grad and id(p) not in theta_ids]
         actions_host = data["actions"].tolist() if self.use_policy else None   # one D2H up front
         try:
             for e0 in range(0, b, chunk):

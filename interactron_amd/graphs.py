@@ -37,7 +37,7 @@ class ChunkState:
             self.timer.mark(name)
 
     def drop_tape(self):
-        for k in ("dtheta", "grads", "nt", "actions_out", "sup_rows", "gts", "det_rows", "logits1", "boxes1", "path_ce"):
+        for k in ("dtheta", "grads", "nt", "actions_out", "sup_rows", "gts", "det_rows", "logits1", "boxes1", "path_ce", "c_grads", "c_params"):
             self.__dict__.pop(k, None)
 
 
@@ -69,6 +69,7 @@ def run_eager(model, E, s, inputs, policy_labels):
         labels = policy_labels(st.gts_host.tolist())
         st.best_all = ops.h2d_async(torch.tensor(labels, dtype=torch.long).reshape(E * 4))
     model._seg_b(st)
+    model._seg_d(st)
     res = _results(st, policy, clone=False)
     st.drop_tape()
     return res
@@ -117,8 +118,8 @@ class ChunkGraphs:
             st.best_all = torch.zeros(E * 4, dtype=torch.int64, device=dev)
             self.best_stage = torch.zeros(E * 4, dtype=torch.int64, pin_memory=True)
         self.salt = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.stream = torch.cuda.Stream(device=dev)
-        self.graphs, self.stamp, self.keep, self.loaded = None, None, None, None
+        self.stream, self.side = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.graphs, self.stamp, self.keep, self.loaded, self.alive = None, None, None, None, None
 
     def load(self, inputs):
         st = self.st
@@ -136,19 +137,24 @@ class ChunkGraphs:
         self.loaded.record()
 
     def capture(self):
+        """Capture order A, C, B, D.  A, B and D share one memory pool (B's backward releases A's tape); C -- the first-order
+        branch, which a replay runs on a second stream WHILE B runs -- allocates from its own pool and its own scratch slot, and
+        reads of A only what this object keeps alive (the learned-loss gradients, the stem features, the static inputs)."""
         model, st = self.model, self.st
         theta = model._theta
-        pool = torch.cuda.graph_pool_handle()
+        pool, pool_c = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         graphs = []
         ops.capture_begin(self.salt)
         try:
-            for seg in (model._seg_a, model._seg_c, model._seg_b):
+            for seg, pl, slot in ((model._seg_a, pool, 0), (model._seg_c, pool_c, 1), (model._seg_b, pool, 0), (model._seg_d, pool, 0)):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool, stream=self.stream):
+                with ops.scratch_slot(slot), torch.cuda.graph(g, pool=pl, stream=self.stream):
                     seg(st)
                 graphs.append(g)
-            # small results live in the pool: keep them (replays rewrite them in place), drop the autograd tape
+            # small results live in the pools: keep them (replays rewrite them in place), drop the autograd tape -- but keep
+            # what C and D read of the other segments alive for as long as the graphs exist
             self.keep = _results(st, self.policy, clone=False)
+            self.alive = (st.grads, st.nt, st.c_grads)
             if self.policy:
                 self.keep["gts_host"] = st.gts_host
         finally:
@@ -160,18 +166,23 @@ class ChunkGraphs:
     def __call__(self, inputs, policy_labels):
         self.load(inputs)
         self.salt.add_(GOLDEN)
-        gA, gC, gB = self.graphs
+        gA, gC, gB, gD = self.graphs
+        main = torch.cuda.current_stream()
         gA.replay()
+        self.side.wait_stream(main)
         if self.policy:
             ready = torch.cuda.Event()
             ready.record()
-        gC.replay()
+        with torch.cuda.stream(self.side):   # the first-order branch runs beside the supervisor backward
+            gC.replay()
         if self.policy:
             ready.synchronize()
             labels = policy_labels(self.keep["gts_host"].tolist())
             self.best_stage.copy_(torch.tensor(labels, dtype=torch.long).reshape(-1))
             self.st.best_all.copy_(self.best_stage, non_blocking=True)
         gB.replay()
+        main.wait_stream(self.side)
+        gD.replay()
         return {k: v.clone() for k, v in self.keep.items() if k != "gts_host"}
 
 

@@ -138,6 +138,28 @@ _ws_bytes = {}   # contraction signature -> scratch bytes (split-K planes; fp16x
 # alive because captured HIP graphs hold their addresses.
 _scratch = [None]
 _scratch_retired = []
+_scratch_slots = {0: None}   # slot -> scratch tensor; slot 0 is the default.  Launch sequences that may run CONCURRENTLY with the
+_scratch_slot = [0]          # main one (graphs.ChunkGraphs replays the first-order branch on a second stream) take their own slot
+
+
+class scratch_slot:
+    """with scratch_slot(k): contractions / reductions issued inside use scratch buffer k (own split-K planes, own tickets)"""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        _scratch_slots[_scratch_slot[0]] = _scratch[0]
+        self.prev = _scratch_slot[0]
+        _scratch_slot[0] = self.slot
+        _scratch[0] = _scratch_slots.get(self.slot)
+        return self
+
+    def __exit__(self, *exc):
+        _scratch_slots[self.slot] = _scratch[0]
+        _scratch_slot[0] = self.prev
+        _scratch[0] = _scratch_slots.get(self.prev)
+        return False
 
 
 TICKET_BYTES = 65536   # IX_TICKET_BYTES of csrc/common.h: the head of the scratch holds the reduction tickets
@@ -1963,6 +1985,15 @@ class _ClippedSGDBwd(Function):
         n = ctx.n
         res = _ClippedSGDBwd.call(ctx.lr, ctx.clip, n, *(list(GG) + list(gs)))
         return (None, None, None) + tuple(res) + (None,) * n
+
+
+def accumulate_multi(dst, src):
+    """dst_i += src_i for two lists of tensors in ONE multi-tensor launch (the clipped-SGD kernel with lr = -1 and no clip:
+    p - clamp(-g) = p + g)."""
+    dst, src = [_req(d) for d in dst], [_req(s) for s in src]
+    if dst:
+        _chk(_L().ix_sgd_clip_multi_f32(_ptr_array(dst), _ptr_array(src), _ptr_array(dst), _size_array(dst), len(dst), -1.0, 3.0e38,
+                                        _stream()), "ix_sgd_clip_multi_f32")
 
 
 def sumsq_accum(x_flat, out_scalar):

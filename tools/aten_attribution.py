@@ -16,7 +16,8 @@ from interactron_amd.synthetic import load_procedural, synthetic_episodes
 from interactron_amd.trainer import FlatOuterStep
 
 size, episodes, chunk = int(os.environ.get("SIZE", 300)), int(os.environ.get("EPISODES", 16)), int(os.environ.get("CHUNK", 8))
-cfg, _ = bench.model_cfg(size, 100, chunk, "interactron")
+cfg, _ = bench.model_cfg(size, 50, chunk, "interactron")
+cfg["STEP_GRAPH"] = "false"   # (attribute the eager launches: a graph replay has no Python stacks)
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 model = build_model(Config(**cfg))
