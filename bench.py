@@ -332,12 +332,13 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     return res
 
 
-def hbm_kernels(torch, hipops, dev):
+def hbm_kernels(torch, hipops, dev, rows=32960, seq=(16, 2060)):
     """The HBM-bound kernels of the path, timed alone on step-sized buffers (HIP events on the current stream, 5 launches
     after a warm-up): achieved GB/s = ALGORITHMIC bytes per launch / average launch time, against the 8 TB/s HBM3E peak
     (/opt/skills/guides/MI355X_MICROARCH.md; a float4 copy reaches 6.3).  Sizes: the 58.4 M-element flat parameter buffer
-    (Adam, clip norm), theta's 38.0 M elements (clipped SGD), a [32960, 512] fusion activation (LayerNorm) and a
-    [16, 2060, 512] projection (operand split)."""
+    (Adam, clip norm), theta's 38.0 M elements (clipped SGD), and at THIS run's shape the fusion activation [episodes x T, 512]
+    (LayerNorm) and projection [episodes, T, 512] (operand split): [32960, 512] at the headline, [51005, 512] for the stress
+    configuration (--size 1600 --queries 200 --episodes 1)."""
     import math
     def timed(fn, it=5):
         fn()
@@ -361,12 +362,12 @@ def hbm_kernels(torch, hipops, dev):
     ps, gs = [torch.randn(n2, device=dev)], [torch.randn(n2, device=dev) * 10]
     t = timed(lambda: hipops.ClippedSGD.forward(hipops._NullCtx(), 1e-3, 0.01, 1, *(ps + gs)))
     out["multi_map2_kernel<sgd_clip>"] = {"bytes": 12 * n2, "GBps": 12 * n2 / t / 1e9}
-    x = torch.randn(32960, 512, device=dev)
+    x = torch.randn(rows, 512, device=dev)   # the fusion activation of this run: (episodes per chunk x T) rows of 512
     w, b = torch.ones(512, device=dev), torch.zeros(512, device=dev)
     t = timed(lambda: hipops.LayerNorm.forward(hipops._NullCtx(), x, w, b, 1e-5))
     out["ln_fwd_kernel"] = {"bytes": 8 * x.numel(), "GBps": 8 * x.numel() / t / 1e9}
-    y = torch.randn(16, 2060, 512, device=dev)
-    t = timed(lambda: hipops.attn_split(y, 16, 2060, 512, 0, 8, 64))
+    y = torch.randn(seq[0], seq[1], 512, device=dev)
+    t = timed(lambda: hipops.attn_split(y, seq[0], seq[1], 512, 0, 8, 64))
     out["attn_split_kernel"] = {"bytes": 14 * y.numel(), "GBps": 14 * y.numel() / t / 1e9}   # 4 B read, 4 B fp16 + 6 B bf16 planes written
     for k in out:
         out[k]["frac_of_8TBps"] = out[k]["GBps"] / 8000.0
@@ -543,7 +544,8 @@ def main():
             "cpu_baseline": None,
             "n800": n800,
             "small_e": None, "strong": None,
-            "hbm_kernels": hbm_kernels(torch, hipops, dev) if not args.no_roofline else None,
+            "hbm_kernels": hbm_kernels(torch, hipops, dev, min(args.chunk, args.episodes) * cfg["BLOCK_SIZE"],
+                                       (min(args.chunk, args.episodes), cfg["BLOCK_SIZE"])) if not args.no_roofline else None,
             "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,
             "allreduce": head["allreduce"],
         }

@@ -221,3 +221,85 @@ class InteractiveDataset(_RolloutBase):
 
 
 InteractiveDaatset = InteractiveDataset   # the reference's spelling (datasets/interactive_dataset.py:10)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# data-parallel batches: every rank agrees on the global batch, decodes only its own episodes
+# ------------------------------------------------------------------------------------------------------------
+class _RankItems(Dataset):
+    """dataset[(idx, actions)] -> one decoded rollout along `actions` (what a DataLoader worker of this rank produces)"""
+
+    def __init__(self, base):
+        self.base = base
+
+    def __len__(self):
+        return len(self.base)
+
+    def __getitem__(self, item):
+        idx, actions = item
+        return self.base.__getitem__(idx, actions=list(actions) if actions is not None else None)
+
+
+class EpisodeBatchLoader:
+    """The batches ``DataLoader(SequenceDataset, batch_size=B, shuffle=...)`` of the reference trainer
+    (engine/interactron_trainer.py:78-90) under one-process-per-GPU data parallelism.
+
+    Every rank derives the SAME global batches from one seeded generator -- the permutation of an epoch from
+    ``seed + epoch``, each training rollout's five random actions (sequence_dataset.py:42-43) from ``(seed, epoch, idx)`` --
+    but its DataLoader workers open and transform only the episodes ``rank::world`` of each batch (1 / world of the JPEG
+    decodes).  What the others contribute to this rank's PathStorage replay (models/interactron.py:109-115) is their root
+    image path and their actions, both read off the annotation table without touching an image.  Yields
+    ``(local batch with dp_roots / dp_actions / dp_index / dp_world, global batch size)``; a rank whose shard of a short last
+    batch is empty gets a batch with zero episodes."""
+
+    def __init__(self, dataset, batch_size, shuffle, rank=0, world=1, seed=42, num_workers=0, pin_memory=True, collate=None):
+        from torch.utils.data.dataloader import DataLoader
+        self.dataset, self.batch_size, self.shuffle, self.rank, self.world, self.seed = dataset, batch_size, shuffle, rank, world, seed
+        self.num_workers, self.pin_memory, self.collate, self._DataLoader = num_workers, pin_memory, collate, DataLoader
+        self.epoch = 0
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def _plan(self, epoch):
+        """global batches of one epoch: [[(idx, actions | None), ...], ...] -- identical on every rank"""
+        n = len(self.dataset)
+        if self.shuffle:
+            order = torch.randperm(n, generator=torch.Generator().manual_seed(self.seed + epoch)).tolist()
+        else:
+            order = list(range(n))
+        names = self.dataset.annotations["metadata"]["actions"]
+        plan = []
+        for b0 in range(0, n, self.batch_size):
+            batch = []
+            for idx in order[b0:b0 + self.batch_size]:
+                if self.dataset.mode == "test":
+                    acts = list(TEST_ACTIONS)
+                else:
+                    rng = random.Random((self.seed * 1000003 + epoch) * 1000003 + idx)
+                    acts = [rng.choice(names) for _ in range(5)]
+                batch.append((idx, acts))
+            plan.append(batch)
+        return plan
+
+    def __iter__(self):
+        plan = self._plan(self.epoch)
+        self.epoch += 1
+        mine = [[item for item in batch[self.rank::self.world]] for batch in plan]
+        loader = self._DataLoader(_RankItems(self.dataset), batch_sampler=[b for b in mine if b], num_workers=self.num_workers,
+                                  pin_memory=self.pin_memory, collate_fn=self.collate)
+        it = iter(loader)
+        for batch, local in zip(plan, mine):
+            data = next(it) if local else _empty_batch()
+            data["dp_roots"] = [self.dataset._path(self.dataset.annotations["data"][idx], self.dataset.annotations["data"][idx]["root"])
+                                for idx, _ in batch]
+            data["dp_actions"] = [[ACTIONS.index(a) for a in acts[:4]] for _, acts in batch]
+            data["dp_index"] = list(range(self.rank, len(batch), self.world))
+            data["dp_world"] = self.world
+            yield data, len(batch)
+
+
+def _empty_batch():
+    return {"frames": torch.zeros(0, 5, 3, 1, 1), "masks": torch.zeros(0, 5, 1, 1, dtype=torch.long),
+            "actions": torch.zeros(0, 5, dtype=torch.long), "object_ids": [], "category_ids": [], "boxes": [],
+            "episode_ids": torch.zeros(0, dtype=torch.long), "initial_image_path": []}

@@ -14,11 +14,10 @@ from datetime import datetime
 
 import numpy as np
 import torch
-from torch.utils.data.dataloader import DataLoader
 
-from ..datasets import SequenceDataset, train_transform, transform
+from ..datasets import EpisodeBatchLoader, SequenceDataset, train_transform, transform
 from ..storage import collate_fn
-from ..trainer import FlatOuterStep, init_distributed, shard_batch
+from ..trainer import FlatOuterStep, init_distributed
 from .logging import TBLogger
 
 
@@ -32,7 +31,9 @@ def _to_device(data, device):
 
 class _TrainerBase:
     fixed_lrs = None          # InteractronRandomTrainer hard-codes 1e-5 / 1e-4 (interactron_random_trainer.py:70-71)
-    shard_by_root = True      # multi-GPU: an episode goes to rank hash(initial_image_path) % world (see shard_batch)
+    shard_by_root = True      # multi-GPU: rank r takes episodes r::world of every batch; the batch's roots + actions travel
+                              # with it so that every rank replays the whole batch's PathStorage updates (EpisodeBatchLoader)
+    replica_check_every = 100 # outer steps between two replica-equality checks (flat parameter checksum over the ranks)
     pass_train_flag = False   # ... and calls model(data, train=is_train) (:91)
 
     def __init__(self, model, config, evaluator=None, train_dataset=None, test_dataset=None):
@@ -81,8 +82,30 @@ class _TrainerBase:
     def _base_lr(self, cfg):
         return self.fixed_lrs[1] if self.fixed_lrs else cfg.SUPERVISOR_LR
 
-    def _tokens_per_batch(self, data):
-        return data["frames"].shape[0] * data["frames"].shape[1]
+    def _tokens_of(self, global_episodes, data):
+        """LR-schedule tokens of one GLOBAL batch (reference interactron_trainer.py:116: episodes x frames)"""
+        return global_episodes * 5
+
+    # ---- replica hygiene under data parallelism ------------------------------------------------------------------
+    def _sync_replicas(self, outer):
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_initialized():
+            dist.broadcast(outer.flat.params, src=0)
+            for b in self.model.buffers():
+                dist.broadcast(b.data, src=0)
+            self._check_replicas(outer)
+
+    def _check_replicas(self, outer):
+        """Every rank must hold the same parameters: (sum, sum of squares) of the flat buffer, MIN and MAX over the ranks."""
+        import torch.distributed as dist
+        p = outer.flat.params.double()
+        stat = torch.stack([p.sum(), (p * p).sum()])
+        lo, hi = stat.clone(), stat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("data-parallel replicas have drifted apart: parameter checksums differ between ranks "
+                               "(min %s, max %s)" % (lo.tolist(), hi.tolist()))
 
     def _decay_lr(self, cfg, outer, global_tokens):
         """Cosine schedule of the reference (interactron_trainer.py:113-127), counted in tokens of the GLOBAL batch so that
@@ -106,15 +129,25 @@ class _TrainerBase:
         model.train()
         state = {"epoch": 0}
 
+        # replicas start from rank 0's weights (every rank built the same model, but a checkpoint path or an RNG-dependent
+        # initialiser may differ between hosts) and are checked against each other every `replica_check_every` steps
+        self._sync_replicas(outer)
+        loaders = {}
+
         def run_epoch(split):
             is_train = split == "train"
-            loader = DataLoader(self.train_dataset if is_train else self.test_dataset, shuffle=is_train, pin_memory=True,
-                                batch_size=cfg.BATCH_SIZE, num_workers=cfg.NUM_WORKERS, collate_fn=collate_fn)
+            if split not in loaders:   # (kept across epochs: the loader's epoch counter drives the shared permutation)
+                loaders[split] = EpisodeBatchLoader(self.train_dataset if is_train else self.test_dataset, cfg.BATCH_SIZE,
+                                                    shuffle=is_train, rank=self.rank, world=self.world, seed=42,
+                                                    num_workers=cfg.NUM_WORKERS, pin_memory=True, collate=collate_fn)
             tag = "Train" if is_train else "Test"
             loss_list = []
-            for it, data in enumerate(loader):
-                global_tokens = self._tokens_per_batch(data)   # of the GLOBAL batch: identical on every rank
-                data = _to_device(shard_batch(data, self.rank, self.world, by_root=self.shard_by_root), self.device)
+            for it, (data, global_episodes) in enumerate(loaders[split]):
+                global_tokens = self._tokens_of(global_episodes, data)   # of the GLOBAL batch: identical on every rank
+                if self.world == 1 or not self.shard_by_root:
+                    for k in ("dp_roots", "dp_actions", "dp_index", "dp_world"):
+                        data.pop(k, None)
+                data = _to_device(data, self.device)
                 if data["frames"].shape[0] == 0:    # a short last batch can leave a rank without episodes: it still
                     if hasattr(model, "dp_idle_step"):   # has to take part in the reward exchange, the gradient
                         model.dp_idle_step(data)         # all-reduce and the LR schedule
@@ -132,6 +165,9 @@ class _TrainerBase:
                     outer.step()   # all-reduce(SUM) of the flat grads + clip_grad_norm_ + Adam x2, grads zeroed
                     lr = self._decay_lr(cfg, outer, global_tokens)
                     self.logger.add_value("{}/LR".format(tag), lr)
+                    self.steps += 1
+                    if self.world > 1 and self.steps % self.replica_check_every == 0:
+                        self._check_replicas(outer)
                     if self.rank == 0 and it % 10 == 0:
                         print("epoch %d iter %d: train loss %.5f. lr %e" % (state["epoch"], it, float(np.mean(loss_list)), lr))
             if not is_train:
@@ -147,7 +183,7 @@ class _TrainerBase:
                 self.logger.add_value("Test/" + k, float(v))
             return m
 
-        self.tokens = 0
+        self.tokens, self.steps = 0, 0
         run_evaluation()
         self.logger.log_values()
         for epoch in range(1, cfg.MAX_EPOCHS):
@@ -188,5 +224,5 @@ class DirectSupervisionTrainer(_TrainerBase):
     def _base_lr(self, cfg):
         return cfg.LEARNING_RATE
 
-    def _tokens_per_batch(self, data):
-        return data["frames"].shape[0]
+    def _tokens_of(self, global_episodes, data):
+        return global_episodes

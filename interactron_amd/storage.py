@@ -59,13 +59,18 @@ def exchange_rewards(local_rewards, slots, total):
     run of ``total`` episodes; returns all ``total`` rewards (list of float).  One tiny all-reduce (SUM of disjoint
     one-hot placements) -- every rank of the group must call it the same number of times."""
     import torch.distributed as dist
-    buf = torch.zeros(total, dtype=torch.float64)
+    on_gpu = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == "nccl"
+    buf = torch.zeros(total, dtype=torch.float64, pin_memory=on_gpu)
     for s, r in zip(slots, local_rewards):
         buf[s] = r
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "nccl":
-            buf = buf.cuda()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if on_gpu:   # RCCL reduces device memory: pinned staging both ways, no pageable (host-blocking, stream-draining) copy
+            dev = buf.to("cuda", non_blocking=True)
+            dist.all_reduce(dev, op=dist.ReduceOp.SUM)
+            buf.copy_(dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf.tolist()
 
 

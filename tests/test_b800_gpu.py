@@ -160,3 +160,40 @@ def test_stress_config_200_queries_fp32_and_fp8_attention():
         print("fp8 attention, %s: logits max err / max|logit| = %.4f, relative L2 = %.4f; boxes max abs err = %.4f" % (name, worst, l2, box))
         assert worst <= FP8_LOGIT_MAX and l2 <= FP8_LOGIT_L2 and box <= FP8_BOX_ABS, (name, worst, l2, box)
     assert float((d8["pred_logits"] - d["pred_logits"]).abs().max()) > 0   # (the fp8 path really ran)
+
+
+def test_stress_config_full_size_predict_properties():
+    """BASELINE.json configs[4] at FULL size: one 5-frame episode of 3x1600x1600 frames (100 x 100 = 10 000 tokens per frame),
+    200 queries, fusion T = 5 (10 000 + 200) + 5 = 51 005 (reference shapes: models/gpt.py:39-57,191, detr.py:331), forward
+    attention products on e4m3 MFMA -- ``predict()`` (adapt on the 5 frames through the learned loss, detect frame 0 through
+    theta').  The oracle cannot run this size; checked are the size-independent properties: shapes, finiteness, box range,
+    that the adaptation moved the prediction (theta' != theta) and that a second call reproduces the first bit for bit."""
+    from interactron_amd import Config, build_model, hipops
+    Q, size = 200, 1600
+    cfg = dict(MODEL_CFG, TYPE="interactron", NUM_QUERIES=Q, BLOCK_SIZE=5 * (100 * 100 + Q) + 5, PREDICT_GRAPH=False)
+    m = build_model(Config(**cfg))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().eval()
+    assert m.fusion.model.block_size == 51005
+    data = synthetic_episodes(1, height=size, width=size, tag="stress-full")
+    ep = {"frames": data["frames"].cuda(), "masks": data["masks"].cuda()}
+    torch.cuda.reset_peak_memory_stats()
+    hipops.ATTENTION_DTYPE = "fp8"
+    try:
+        out = m.predict(ep)
+        again = m.predict(ep)
+        with torch.no_grad():
+            from interactron_amd import NestedTensor
+            plain = m.detector(NestedTensor(ep["frames"][0, :1], ep["masks"][0, :1]))
+    finally:
+        hipops.ATTENTION_DTYPE = "fp32"
+    torch.cuda.synchronize()
+    print("1600x1600 / Q = 200 / T = 51005 predict: peak memory %.1f GB" % (torch.cuda.max_memory_allocated() / 1e9))
+    assert out["pred_logits"].shape == (1, 1, Q, 1236) and out["pred_boxes"].shape == (1, 1, Q, 4)
+    assert out["embedded_memory_features"].shape == (1, 1, 256, 100, 100)
+    for k, v in out.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert torch.equal(v, again[k]), (k, "predict is not reproducible")
+    assert float(out["pred_boxes"].min()) >= 0.0 and float(out["pred_boxes"].max()) <= 1.0
+    moved = float((out["pred_logits"][0] - plain["pred_logits"]).abs().max())
+    assert 0.0 < moved < 1e3, moved   # one clipped inner SGD step (|delta theta| <= 0.01 per element) changes the prediction

@@ -194,3 +194,44 @@ def test_g17_sequence_dataset_collate_and_interactive_match_reference(golden):
             for a, b in zip(d["boxes"][0], rec["boxes"]):
                 torch.testing.assert_close(a, b, atol=1e-7, rtol=1e-6)
             assert all(torch.equal(a, b) for a, b in zip(d["category_ids"][0], rec["category_ids"]))
+
+
+def test_episode_batch_loader_shards_the_decode_not_the_batch():
+    """EpisodeBatchLoader under world size 2 (plain objects, no process group needed): both ranks derive the same global
+    batches (permutation and per-episode action scripts from one seed), each decodes only its episodes r::2 -- together they
+    are exactly the single-process batch, frame for frame -- and both carry the whole batch's roots / actions for the
+    PathStorage replay.  A second epoch draws another permutation; a rank whose shard of the short last batch is empty gets
+    an empty batch and the same global size."""
+    from interactron_amd.datasets import EpisodeBatchLoader, SequenceDataset, transform
+    from interactron_amd.storage import collate_fn
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    imgs, ann = os.path.join(root, "imgs"), os.path.join(root, "annotations.json")
+
+    def loaders(world, mode, shuffle):   # (the deterministic eval transform: the shards must be comparable pixel for pixel)
+        ds = SequenceDataset(imgs + "/", ann, mode, transform=transform)
+        return [EpisodeBatchLoader(ds, 2, shuffle, rank=r, world=world, seed=7, num_workers=0, pin_memory=False, collate=collate_fn)
+                for r in range(world)]
+
+    for mode, shuffle in (("train", True), ("test", False)):
+        (one,), (r0, r1) = loaders(1, mode, shuffle), loaders(2, mode, shuffle)
+        for epoch in range(2):
+            full, parts = list(one), [list(r0), list(r1)]
+            assert len(full) == len(parts[0]) == len(parts[1]) == 2   # 3 scenes, batches of 2
+            for b, (whole, n) in enumerate(full):
+                for r in range(2):
+                    part, n_r = parts[r][b]
+                    assert n_r == n and part["dp_world"] == 2 and part["dp_index"] == list(range(r, n, 2))
+                    assert part["dp_roots"] == whole["initial_image_path"] == whole["dp_roots"]
+                    assert part["dp_actions"] == whole["actions"][:, :4].tolist() == whole["dp_actions"]
+                    idx = list(range(r, n, 2))
+                    assert part["frames"].shape[0] == len(idx)
+                    if idx:
+                        assert torch.equal(part["frames"], whole["frames"][idx]) and torch.equal(part["actions"], whole["actions"][idx])
+                        assert part["initial_image_path"] == [whole["initial_image_path"][i] for i in idx]
+                        for i, ep in zip(idx, part["boxes"]):
+                            assert all(torch.equal(a, b) for a, b in zip(ep, whole["boxes"][i]))
+            if epoch == 0:
+                first = [w["episode_ids"].tolist() for w, _ in full]
+            elif shuffle:
+                assert sorted(sum(first, [])) == sorted(sum([w["episode_ids"].tolist() for w, _ in full], []))
+        assert full[-1][1] == 1 and parts[1][-1][0]["frames"].shape[0] == 0   # short last batch: rank 1 idles
