@@ -252,7 +252,7 @@ class _Adaptive(_EpisodeModel):
                 frames = data["frames"][e0:e0 + E].reshape(E * s, c, w, h)
                 masks = data["masks"][e0:e0 + E].reshape(E * s, w, h)
                 with torch.enable_grad():
-                    dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
+                    dtheta = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
                     set_parameters(self.detector, dtheta)
                     nt = NestedTensor(frames, masks)
                     nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
@@ -290,7 +290,7 @@ class _Adaptive(_EpisodeModel):
     def _seg_a(self, st):
         E, s, theta, lr = st.E, st.s, self._theta, self.config.ADAPTIVE_LR
         # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
-        st.dtheta = dtheta = [t.requires_grad_(True) for t in ops.ExpandEpisodes.apply(E, *[p.detach() for p in theta])]
+        st.dtheta = dtheta = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
         set_parameters(self.detector, dtheta)
         # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
         st.nt = nt = NestedTensor(st.frames, st.masks)
@@ -326,7 +326,7 @@ class _Adaptive(_EpisodeModel):
         # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient, not on the
         # criterion.  The expansion of theta is differentiable; its backward sums the per-episode gradients into theta.grad.
         E, theta = st.E, self._theta
-        attached = list(ops.ExpandEpisodes.apply(E, *theta))
+        attached = ops.expand_episodes(E, theta)
         fast1 = sgd_step(attached, [None if g is None else g.detach() for g in st.grads], self.config.ADAPTIVE_LR)
         set_parameters(self.detector, fast1)
         nt1 = NestedTensor(st.frames[st.sel], st.masks[st.sel])

@@ -799,10 +799,17 @@ class FlashAttention(Function):
         q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
         out, lse, pl = flash_forward(q, k, v, g, mask, p, seed, need_backward=not isinstance(ctx, _NullCtx))
         ctx.g, ctx.p, ctx.seed, ctx.pl = g, p, seed, pl
-        # packed projection buffers: [q | k] (nn.MultiheadAttention self-attention) or [k | q | v] (fusion blocks) in one tensor
-        same_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape
-        same_qv = q.data_ptr() == v.data_ptr() and q.shape == v.shape
-        ctx.same_qk = (same_qk, same_qv)
+        # packed projection buffers: [q | k] (nn.MultiheadAttention self-attention) or [k | q | v] (fusion blocks) in one tensor.
+        # ONE gradient buffer serves the operands of a shared tensor only when their column ranges are disjoint and cover the
+        # rows (the two packed layouts); the same tensor passed with overlapping columns (attention(x, x, x) with equal
+        # offsets) gets separate buffers, which autograd then sums.
+        E_ = g.heads * g.hd
+        alias_qk = q.data_ptr() == k.data_ptr() and q.shape == k.shape
+        alias_qv = q.data_ptr() == v.data_ptr() and q.shape == v.shape
+        packed3 = alias_qk and alias_qv and g.q_ld == 3 * E_ and g.k_ld == 3 * E_ and g.v_ld == 3 * E_ \
+            and sorted((g.q_off, g.k_off, g.v_off)) == [0, E_, 2 * E_]
+        packed2 = alias_qk and not alias_qv and g.q_ld == 2 * E_ and g.k_ld == 2 * E_ and sorted((g.q_off, g.k_off)) == [0, E_]
+        ctx.same_qk = (packed2 or packed3, packed3)
         ctx.save_for_backward(q, k, v, out, lse)
         return out
 
@@ -1903,6 +1910,19 @@ class ExpandEpisodes(Function):
             for i, r in zip(idx, ReduceEpisodes.call(ctx.E, *[gs[i] for i in idx])):
                 res[i] = r
         return (None,) + tuple(res)
+
+
+def expand_episodes(E, tensors, groups=8):
+    """ExpandEpisodes over consecutive groups of the parameter list (the detector's stages in module order) instead of one
+    node for all ~200 tensors: a group's per-episode gradients are reduced and RELEASED as soon as the backward has passed
+    its stage, instead of all E-copy gradients staying alive until the end of the backward (E x |theta| x 4 bytes of peak
+    memory at 800x800)."""
+    tensors = list(tensors)
+    n = max(1, (len(tensors) + groups - 1) // groups)
+    out = []
+    for i in range(0, len(tensors), n):
+        out.extend(ExpandEpisodes.apply(E, *tensors[i:i + n]))
+    return out
 
 
 class ReduceEpisodes(Function):

@@ -830,6 +830,29 @@ def test_flash_attention_packed_qk_buffer(ops):
     close(gh[1], gr[1], 3e-5, "packed grad v")
 
 
+def test_flash_attention_same_tensor_for_q_k_v(ops):
+    """attention(x, x, x) -- ONE unpacked tensor as query, key and value (equal offsets, overlapping columns): the operands'
+    gradients must be SUMMED into x.grad, first and second order (a shared gradient buffer is only legal for the packed
+    [q | k] / [k | q | v] layouts, whose columns are disjoint)."""
+    n, H, L, hd = 2, 4, 70, 32
+    E = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, L, hd, E, E, 0, 0, E, 0, scale)
+    x = rnd(n, L, E, seed=1)
+    xh, xr = x.cuda().requires_grad_(True), x.double().requires_grad_(True)
+    out = ops.FlashAttention.apply(xh, xh, xh, g, None, 0.0, 0)
+    ref = _ref_attention_drop(xr, xr, xr, H, scale, None, None)
+    close(out, ref, 2e-5, "x-x-x forward")
+    gy = rnd(n, L, E, seed=2)
+    (gh,) = torch.autograd.grad(out, [xh], gy.cuda(), create_graph=True)
+    (gr,) = torch.autograd.grad(ref, [xr], gy.double(), create_graph=True)
+    close(gh, gr, 3e-5, "x-x-x grad")
+    w = rnd(n, L, E, seed=3)
+    (hh,) = torch.autograd.grad((gh * w.cuda()).sum(), [xh])
+    (hr,) = torch.autograd.grad((gr * w.double()).sum(), [xr])
+    close(hh, hr, 6e-5, "x-x-x second order")
+
+
 @pytest.mark.parametrize("n,H,L,S,hd,masked,pdrop", [(2, 4, 50, 90, 32, True, 0.0), (1, 2, 150, 150, 64, False, 0.0),
                                                       (2, 2, 70, 130, 32, True, 0.1), (1, 2, 130, 200, 64, False, 0.1)])
 def test_flash_attention_second_order_against_float64(ops, n, H, L, S, hd, masked, pdrop):
