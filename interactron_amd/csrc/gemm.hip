@@ -2130,6 +2130,19 @@ void ix_prof_end(hipStream_t stream) { prof_mark(stream); }
 struct TilePlan {
     int bm, split, kps;
 };
+// cycles of one 128 x 128 x 32 step of the 12-wave kernel on one CU, as the cost model prices it: bf16x6 form 1900 (measured);
+// fp16x3 form 950 (half the matrix instructions; swept 200 .. 2600 on the headline step and on the 2-episode step, round 3:
+// 285.0 / 67.7 ms at 900 against 288.1 / 70.7 at 1900 and 290.4 / 75.2 at 200).  IX_X6_STEP_CYCLES overrides it (tuning runs).
+static bool x3k_enabled();
+static double x6_step_cycles() {
+    static double forced = -1.0;
+    if (forced < 0) {
+        const char* e = getenv("IX_X6_STEP_CYCLES");
+        forced = e ? atof(e) : 0.0;
+    }
+    if (forced >= 100.0) return forced;
+    return x3k_enabled() ? 950.0 : 1900.0;
+}
 static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int tile_hint, int split_k_hint) {
     int bm = 64, split = 1;
     double best = 1e300;
@@ -2140,7 +2153,7 @@ static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int ti
         if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
         const int bk = t == 128 ? 32 : 64;
         // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
-        const double step_cycles = t == 128 ? (want_x6 ? 1900.0 : 4096.0) : 2048.0 * 1.15;
+        const double step_cycles = t == 128 ? (want_x6 ? x6_step_cycles() : 4096.0) : 2048.0 * 1.15;
         const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
         for (int si = 0; si < 14; ++si) {
             int sp = cand_split[si];
