@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
 // products out of the TR region while the next tile's tr operands are in flight; each region is refilled right after the
 // barrier that ends its phase, from one shared set of staging registers.
 template <int HD, bool DROP, bool STATS>
-__global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256, 1) void flash_bb_q_kernel(FlashArgs p) {
 
 // pass 3 (key-owning): dk (o2), dv (o3).  Tiles [query, key]: lane = key, registers = queries.  Two-phase tile as in pass 2.
 template <int HD, bool DROP>
-__global__ __launch_bounds__(256, 1) void flash_bb_kv_kernel(FlashArgs p) {
+__global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
     typedef FlSeg<HD> G;
