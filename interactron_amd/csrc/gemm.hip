@@ -1199,6 +1199,10 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
     static_assert(G == 0 || (G == 1 && KC && !IS_B) || ((G == 2 || G == 3) && !KC && IS_B), "gather mode vs operand layout");
     SplitLoader<BT, KC, SWZ, X3> s0, s1, s2;
+#ifdef X6_DIAG_TIMING
+    const int lane = pt & 63, wave = IS_B ? 100 : 4 + (pt >> 6);   // (stamps: the first A-producer wave)
+    int dbgn = 0;
+#endif
     typename SplitLoader<BT, KC, SWZ, X3>::PixRows pr;   // (mode 1 only; dead otherwise)
     int erun = -1000;                                    // fp16x3 form: running sub-block exponent of the item (store_x3)
     int* const expo = expo0 + (IS_B ? 4 : 0) + (pt >> 6);   // this wave's word in image 0 (image 1: + 8)
@@ -1262,14 +1266,17 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);                                                       \
     }
 #define X6Q_STEP(S)                                                                                         \
+    X6_STAMP(1, 0)                                                                                          \
     X6Q_WAIT_STAGE(S)                                                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
+    X6_STAMP(1, 1)                                                                                          \
     if (X3)                                                                                                 \
         S.store_x3(lds0 + buf * buf_bytes + plane_off, pt, itS.kbeg + tS * BK, itS.kend, erun, expo + buf * 8); \
     else                                                                                                    \
         S.store(lds0 + buf * buf_bytes + plane_off, pt, itS.kbeg + tS * BK, itS.kend);                      \
     X6Q_RSUM_ACC(S)                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
+    X6_STAMP(1, 2)                                                                                          \
     buf ^= 1;                                                                                               \
     if (++tS >= itS.nk) {                                                                                   \
         X6Q_RSUM_FLUSH                                                                                      \
@@ -1280,7 +1287,9 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         if (moreS) itS = x6_item<BN>(p, wS);                                                                \
     }                                                                                                       \
     X6Q_LD(S)                                                                                               \
-    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */
+    X6_STAMP(1, 3)                                                                                          \
+    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */           \
+    X6_STAMP(1, 4)
     X6Q_LD(s0)
     X6Q_LD(s1)
     X6Q_LD(s2)
@@ -1634,7 +1643,10 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     X3Q_EXPO(0)
     X3Q_LDA(ahx, 0, lds[0], 0) X3Q_LDA(al, 1, lds[0], 0)
     X3Q_LDB(bhx, 0, lds[0], 0) X3Q_LDB(bl, 1, lds[0], 0)
+    int dbgn = 0;
+    (void)dbgn;
     for (; w < last; w += stride) {
+        X6_STAMP(0, 10)
         const X6Item it = x6_item<BN>(p, w);
         f32x16 acc[TM][TN];
         int U[TM][TN];
@@ -1663,14 +1675,18 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
             X3Q_SB
             X3Q_SLICE(ahx, bhx, ahy, bhy, lds[buf], 1)
             const bool more = kt + 1 < it.nk || w + stride < last;
+            X6_STAMP(0, 12)
             if (more) x6_lds_barrier();
+            X6_STAMP(0, 13)
             const int nbuf = more ? buf ^ 1 : buf;
             const unsigned char* nb = lds[nbuf];
             X3Q_EXPO(nbuf)
             X3Q_SB
             X3Q_SLICE(ahy, bhy, ahx, bhx, nb, 0)
+            X6_STAMP(0, 15)
             buf ^= 1;
         }
+        X6_STAMP(0, 14)
         const bool add_bias = it.bias != nullptr && it.ks == 0;
         if (staged) {
             float* ct = cstrip[wave];
