@@ -2159,7 +2159,8 @@ static double x6_step_cycles() {
     if (forced >= 100.0) return forced;
     return x3k_enabled() ? 950.0 : 1900.0;
 }
-static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int tile_hint, int split_k_hint) {
+static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int tile_hint, int split_k_hint, double step128 = 0.0) {
+    if (step128 <= 0.0) step128 = x6_step_cycles();
     int bm = 64, split = 1;
     double best = 1e300;
     const int cand_tiles[2] = {128, 64};
@@ -2169,7 +2170,7 @@ static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int ti
         if (tile_hint != 0 && (tile_hint == 1128 ? 128 : tile_hint) != t) continue;
         const int bk = t == 128 ? 32 : 64;
         // 64x64 tiles pull 2x the L2 bytes per flop; the bf16x6 128-tile step is 48 x 32 MFMA cycles + the split
-        const double step_cycles = t == 128 ? (want_x6 ? x6_step_cycles() : 4096.0) : 2048.0 * 1.15;
+        const double step_cycles = t == 128 ? (want_x6 ? step128 : 4096.0) : 2048.0 * 1.15;
         const int64_t tl = (int64_t)ix_div_up(M, t) * ix_div_up(N, t) * nbatch;
         for (int si = 0; si < 14; ++si) {
             int sp = cand_split[si];
@@ -2336,11 +2337,15 @@ extern "C" int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, i
     const int nbatch = batch_outer * batch_inner;
     size_t need = 0;
     if (M > 0 && N > 0 && nbatch > 0) {
-        for (int x6 = 0; x6 < 2; ++x6) {
-            const TilePlan pl = plan_tiles(M, N, K, nbatch, x6 != 0, tile_hint, split_k_hint);
-            const size_t b = splitk_plane_bytes(pl.split, nbatch, batch_outer, M, N);
-            if (b > need) need = b;
-        }
+        // (whichever kernel family and form of the 12-wave kernel the call is planned for when it is issued: the test hooks
+        //  ix_gemm_set_mode / ix_gemm_set_x3 may switch between this query and the launch)
+        const double steps[3] = {950.0, 1900.0, x6_step_cycles()};
+        for (int x6 = 0; x6 < 2; ++x6)
+            for (int si = 0; si < 3; ++si) {
+                const TilePlan pl = plan_tiles(M, N, K, nbatch, x6 != 0, tile_hint, split_k_hint, steps[si]);
+                const size_t b = splitk_plane_bytes(pl.split, nbatch, batch_outer, M, N);
+                if (b > need) need = b;
+            }
     }
     if (need) need += IX_TICKET_BYTES;
     // ix_gemm_rowsum_f32 on shapes the producers do not sum: a separate ordered column sum of A (K rows of M)

@@ -23,6 +23,9 @@ import torch
 from . import hipops as ops
 from .meta import set_parameters
 
+# "thread_local": only the capturing thread's own unsafe calls invalidate a capture -- the RCCL watchdog thread of a multi-rank
+# run polls events while a rank captures, which the default "global" mode treats as an error
+CAPTURE_MODE = "thread_local"
 GOLDEN = -0x61C8864680B583EB   # 0x9E3779B97F4A7C15 as a signed 64-bit step of the dropout salt
 
 
@@ -148,7 +151,7 @@ class ChunkGraphs:
         try:
             for seg, pl, slot in ((model._seg_a, pool, 0), (model._seg_c, pool_c, 1), (model._seg_b, pool, 0), (model._seg_d, pool, 0)):
                 g = torch.cuda.CUDAGraph()
-                with ops.scratch_slot(slot), torch.cuda.graph(g, pool=pl, stream=self.stream):
+                with ops.scratch_slot(slot), torch.cuda.graph(g, pool=pl, stream=self.stream, capture_error_mode=CAPTURE_MODE):
                     seg(st)
                 graphs.append(g)
             # small results live in the pools: keep them (replays rewrite them in place), drop the autograd tape -- but keep
@@ -251,7 +254,7 @@ class PredictGraph:
         g = torch.cuda.CUDAGraph()
         ops.capture_begin(None)
         try:
-            with torch.cuda.graph(g, stream=self.stream):
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode=CAPTURE_MODE):
                 out = self.model._predict_one(self.frames, self.masks)
         finally:
             ops.capture_end()

@@ -116,13 +116,54 @@ def test_two_ranks_equal_one_process():
     # float32 summation-order differences between the episode-batched pass and two single-episode passes (other shapes pick
     # other tiles / splits; then ~50 ReLU layers and the clipped inner step).  Every reduction is ordered, so this is a fixed
     # number, not a scatter: measured (r3, fp16x3 contraction form) total norm 7.6e-5, update 1.2e-6, whole gradient 7.4e-4,
-    # median tensor 5.6e-4, worst tensor 2.5e-2 (layer3.1.conv1; bf16x6 form: 2.0e-4 / 1.1e-4 / 9.2e-3).  Bounds ~3x above that (round 2, atomics: 3 % whole, 60 % worst); a missing or
+    # median tensor 5.6e-4, worst tensor 2.5e-2 (layer3.1.conv1; bf16x6 form: 2.0e-4 / 1.1e-4 / 9.2e-3; after the cost-model retune of the
+    # tile / split plan: median 2.3e-3).  The numbers move with the contraction plans (other tiles = other summation orders),
+    # so the bounds leave room for that: whole 5e-3, median 5e-3, worst tensor 1e-1.  (Round 2, atomics: 3 % whole, 60 % worst.)  A missing or
     # doubled episode would put EVERY tensor off by ~50 % / 100 %.
     vals = sorted(rel.values())
     print("two ranks vs one process: total norm %.2e, update %.2e, whole gradient %.2e, median tensor %.2e, worst %.2e (%s)"
           % (abs(t0 - ref_total) / ref_total, abs(d0 - ref_delta) / ref_delta, (num / den) ** 0.5, vals[len(vals) // 2], vals[-1],
              max(rel.items(), key=lambda kv: kv[1])[0]))
-    assert (num / den) ** 0.5 <= 2e-3, (num, den)
-    assert vals[len(vals) // 2] <= 1.5e-3, vals[len(vals) // 2]
+    assert (num / den) ** 0.5 <= 5e-3, (num, den)
+    assert vals[len(vals) // 2] <= 5e-3, vals[len(vals) // 2]
     worst = sorted(rel.items(), key=lambda kv: -kv[1])[:5]
-    assert vals[-1] <= 6e-2, worst
+    assert vals[-1] <= 1e-1, worst
+
+
+def _rank_graph(rank, world, port, out):
+    import torch.distributed as dist
+    from interactron_amd import Config, build_model
+    from interactron_amd.trainer import FlatOuterStep, init_distributed, shard_batch
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      IX_DIST_BACKEND="gloo")
+    init_distributed()
+    m = build_model(Config(**dict(MODEL_CFG, TYPE="interactron", STEP_GRAPH="true")))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().train()
+    outer = FlatOuterStep(m, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0)
+    data = to_gpu(shard_batch(_batch(), rank, world, by_root=True))
+    random.seed(5)
+    for _ in range(4):   # eager warm-up, capture, two replays -- each with the reward exchange between segments A and B
+        m(data)
+        outer.step()
+    p = outer.flat.params.double()
+    out[rank] = ([float(p.sum()), float((p * p).sum())], {k: v.get_label(data["dp_actions"][1]) for k, v in m.path_storage.items()},
+                 sorted(type(v).__name__ for v in m.__dict__.get("_chunk_graphs", {}).values()))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_under_graph_replay_stay_identical():
+    """Data parallelism with the chunk replayed from HIP graphs (train mode, 4 steps, one episode per rank): the PathStorage
+    reward exchange runs on the host between the captured segments, the flat-gradient all-reduce between the replays and the
+    update -- afterwards both ranks must hold bit-identical parameters and identical tries, and both must have captured."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = mp.Manager().dict()
+    mp.spawn(_rank_graph, args=(2, port, out), nprocs=2, join=True)
+    (c0, l0, g0), (c1, l1, g1) = out[0], out[1]
+    assert g0 == g1 == ["ChunkGraphs"], (g0, g1)
+    assert c0 == c1, ("replicas drifted apart under graph replay", c0, c1)
+    assert l0 == l1 and len(l0) == 1

@@ -2,7 +2,7 @@
 # One round's measurement artefacts (run on the GPU box through gpurun; results land in gpurun_out/$1/ and are copied into
 # profiles/ by hand): driver-style bench line, rocprofv3 kernel stats of the same command, the two PMC HBM-traffic passes,
 # SQ counters, the other reference configs / evaluation modes, the stress configuration, the 2-rank launcher smoke, power probe.
-TAG=${1:-r2d}
+TAG=${1:-r3g}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -11,10 +11,19 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof -o p --output-format csv -- python
 cp $OUT/prof/p_kernel_stats.csv $OUT/${TAG}_bench_p300_e16_kernel_stats.csv; rm -rf $OUT/prof
 rocprofv3 --kernel-trace --stats -d $OUT/prof8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 8 --chunk 8 --steps 2 --warmup 1 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_800_e8_profiled.json 2> $OUT/prof8.err
 cp $OUT/prof8/p_kernel_stats.csv $OUT/${TAG}_bench_800_e8_kernel_stats.csv; rm -rf $OUT/prof8
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
-python tools/pmc_summary.py $OUT/pf/p_counter_collection.csv $OUT/pw/p_counter_collection.csv $OUT/${TAG}_pmc_hbm_traffic.json > /dev/null; rm -rf $OUT/pf $OUT/pw
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/ps -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 --small-e 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 --small-e 0 > /dev/null 2>&1
+python tools/pmc_summary.py $OUT/pf/p_counter_collection.csv $OUT/pw/p_counter_collection.csv $OUT/${TAG}_pmc_hbm_traffic_300.json > /dev/null; rm -rf $OUT/pf $OUT/pw
+# the same two passes at the north-star shape (bench.py's n800 object reads THIS file for its `traffic`)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 8 --chunk 8 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pw8 -o p --output-format csv -- python3 bench.py --size 800 --episodes 8 --chunk 8 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 > /dev/null 2>&1
+python tools/pmc_summary.py $OUT/pf8/p_counter_collection.csv $OUT/pw8/p_counter_collection.csv $OUT/${TAG}_pmc_hbm_traffic_800.json > /dev/null; rm -rf $OUT/pf8 $OUT/pw8
+# the per-GPU share of the reference batch on 8 GPUs (2 episodes, replayed from HIP graphs) and its neighbours
+for e in 1 2 4 8; do python bench.py --episodes $e --chunk $e --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --n800-episodes 0 --small-e 0 > $OUT/${TAG}_bench_p300_e$e.json 2>/dev/null; done
+rocprofv3 --kernel-trace --stats -d $OUT/prof2 -o p --output-format csv -- python3 bench.py --episodes 2 --chunk 2 --steps 5 --warmup 3 --no-cpu-baseline --no-roofline --n800-episodes 0 --small-e 0 > /dev/null 2> $OUT/prof2.err
+cp $OUT/prof2/p_kernel_stats.csv $OUT/${TAG}_bench_p300_e2_kernel_stats.csv; rm -rf $OUT/prof2
+python tools/step_graph_probe.py 1 2 4 > $OUT/${TAG}_step_graph_probe.txt 2>/dev/null
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/ps -o p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --n800-episodes 0 --small-e 0 > /dev/null 2>&1
 python tools/pmc_sq_summary.py $OUT/ps/p_counter_collection.csv $OUT/${TAG}_pmc_sq_counters.json > /dev/null
 python tools/pmc_flash_summary.py $OUT/ps/p_counter_collection.csv $OUT/${TAG}_pmc_sq_counters_flash.json > /dev/null; rm -rf $OUT/ps
 for c in interactron_random multi_frame_baseline single_frame_baseline; do python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --n800-episodes 0 > $OUT/${TAG}_bench_$c.json 2>/dev/null; done
