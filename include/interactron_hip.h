@@ -221,10 +221,17 @@ int ix_workspace_bytes_layernorm_bwd(int64_t rows, int D, int groups, size_t* ou
  *
  * ix_attn_split_f32: fp32 activations x [n][R][ld] (head h = columns off + h*hd .. + hd) ->
  *   row_planes  [2][n*H][Rp][hd] fp16 (h, l of x * 2^e) + row_unscale [n*H][Rp/32] f32 (2^-e per block of 32 rows), and/or
- *   tr_planes   [3][n*H][hd][Rp] bf16 (h, m, l; rows permuted within 16-groups to the MFMA accumulator order).
- *   Rp = R rounded up to 128, padded rows are zero.  row_planes + row_unscale, or tr_planes, may be null.
- * struct ix_attn_planes: the three pointers of one operand, as the entry points below take them (members an entry
- *   point does not read may be null: forward reads q.row, k.row, v.tr).
+ *   tr_planes   tr_form 0: [3][n*H][hd][Rp] bf16 (h, m, l of x; rows permuted within 16-groups to the MFMA accumulator
+ *               order) -- the products that contract over tokens then take six matrix instructions per k-slice;
+ *               tr_form 1: [2][n*H][hd][Rp] fp16, the row planes' scaled (h, l) transposed and permuted likewise (reads
+ *               row_unscale too) -- three matrix instructions per k-slice, the [L, S] intermediates are brought into fp16
+ *               range in registers by a running power-of-two factor per output row (csrc/flash.hip).  The caller may
+ *               always allocate 3 planes.
+ *   Rp = R rounded up to 128, padded rows are zero.  row_planes or tr_planes may be null; row_unscale is needed with
+ *   row_planes and with tr_planes of form 1.
+ * struct ix_attn_planes: the pointers of one operand and the tr form they were split with, as the entry points below take
+ *   them (members an entry point does not read may be null: forward reads q.row, k.row, v.tr); all tr operands of one
+ *   call must share one form.
  * ix_attn_bias_f32: key_padding_mask uint8 [n][mask_ld] (nonzero = ignore; null = none) -> additive bias [n][Sb],
  *   Sb >= S (the kernels want S rounded up to 128): 0 for valid keys, -inf for masked keys and the tail.
  * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; rows
@@ -244,9 +251,10 @@ struct ix_attn_planes {
     const void* row;
     const float* unscale;
     const void* tr;
+    int tr_form;
 };
-int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int n, int R, int Rp, int64_t ld,
-                      int off, int H, int hd, ix_stream_t stream);
+int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R, int Rp,
+                      int64_t ld, int off, int H, int hd, ix_stream_t stream);
 int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, int Sb, int64_t mask_ld, ix_stream_t stream);
 int ix_flash_fwd_f32(const struct ix_attn_planes* q, const struct ix_attn_planes* k, const struct ix_attn_planes* v,
                      const float* bias, float* out, float* lse, int n, int H, int L, int Lp, int S, int Sp, int hd,

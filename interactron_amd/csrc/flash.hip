@@ -16,6 +16,13 @@
 //     2^-22 relative; fp16 subnormals are honoured by the MFMA, tools/micro/f16_denorm.hip), and the two block scales
 //     are undone by one wave-uniform multiply of the accumulator.  Measured against float64 this is the accuracy class
 //     of an fp32 dot product of the same length (tests/test_ops_gpu.py) at half the matrix instructions.
+//   * tr_form 1 (the default since round 3): the second-stage products on the fp16 form too.  The tr planes then hold the
+//     SAME scaled fp16 pairs as the row planes (transposed), and an [L, S] intermediate x is brought into fp16 range in
+//     registers: x . (block unscale of the tr tile) . F with F a power of two that the owning lane keeps per ACCUMULATOR --
+//     lowered (and the accumulator rescaled, exactly) whenever a tile's largest magnitude would leave [.., 2^15), never
+//     raised -- and undone when the accumulator is stored.  An element then carries max(2^-22 |x|, 2^-39 max|x| of its output
+//     row so far): the accuracy class of the first-stage products, at three matrix instructions instead of six and two
+//     planes of LDS traffic instead of three (measured: -13 ... -22 % per kernel, profiles/README.md round 3).
 // Operands that come from HBM are split ONCE by ix_attn_split_f32 into the planes the kernels consume.
 //
 // Layouts.  An [L, S] tile is always computed TRANSPOSED relative to its owner: a workgroup that owns query rows
@@ -30,6 +37,7 @@
 //   row layout  [2 planes][batch*head][Rp][hd]   fp16   fragment of 8 consecutive d of one row  (contraction over d)
 //               + unscale factors [batch*head][Rp / 32] f32 (2^-e of each 32-row block)
 //   tr  layout  [3 planes][batch*head][hd][Rp]   bf16   rows permuted within 16-groups          (contraction over rows)
+//        form 1 [2 planes][batch*head][hd][Rp]   fp16   the row planes' values, transposed and permuted likewise
 //   Rp = R rounded up to 128 (zero rows); keys are walked in tiles of 32 up to ceil(S / 32) * 32.
 #include "common.h"
 
@@ -92,7 +100,7 @@ __device__ __host__ __forceinline__ int fl_perm16(int r) { return (r & 3) | ((r 
 template <int HD>
 __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict__ X, unsigned short* __restrict__ rowp,
                                                          float* __restrict__ unscale, unsigned short* __restrict__ trp, int R,
-                                                         int Rp, int64_t ld, int off, int H, int64_t plane_elems) {
+                                                         int Rp, int64_t ld, int off, int H, int64_t plane_elems, int tr_form) {
     constexpr int EPT = 32 * HD / 256;          // elements per thread: 8 (hd 64) / 4 (hd 32)
     constexpr int TPR = HD / EPT;               // threads per row: 8
     __shared__ __attribute__((aligned(16))) unsigned short lt[3][HD][32 + 8];   // [plane][d][permuted row], 80-byte rows
@@ -109,30 +117,42 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
         if (in) t = *reinterpret_cast<const float4*>(src + i);
         v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
     }
-    if (rowp) {
-        // block scale: the largest magnitude of the 32 x HD block lands in [2^14, 2^15) (fp16 overflows at 65504)
+    unsigned ph[EPT / 2], pm[EPT / 2], pl[EPT / 2];
+    if (rowp || (trp && tr_form == 1)) {
+        // block scale: the largest magnitude of the 32 x HD block lands in [2^14, 2^15) (fp16 overflows at 65504); the
+        // scale itself stops at 2^60 (blocks whose maximum is below 2^-46 keep fewer bits): the kernels' running factors stop
+        // at 2^60 too, so unscale . factor cannot underflow to zero
         float mx = 0.f;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) mx = fmaxf(mx, fabsf(v[i]));
         mx = ix_block_max_256(mx, red);
-        const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;                 // biased exponent of the maximum
-        const bool tiny = e < 16u || e > 250u;                                  // (zero / denormal / inf block: unscaled)
-        const float sc = tiny ? 1.f : __uint_as_float((268u - e) << 23);        // 2^(14 - E)
-        const float us = tiny ? 1.f : __uint_as_float((e - 14u) << 23);         // 2^(E - 14)
+        unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;                       // biased exponent of the maximum
+        const bool odd = e > 250u;                                              // (inf / nan block: unscaled)
+        // a zero (or nearly zero) block gets the SMALLEST unscale factor, not 1: the kernels size their running factors by
+        // bound . unscale, and a block that contributes nothing must not drag them down for the blocks that do
+        e = max(e, 127u + 14u - 60u);
+        const float sc = odd ? 1.f : __uint_as_float((268u - e) << 23);         // 2^(14 - E)
+        const float us = odd ? 1.f : __uint_as_float((e - 14u) << 23);          // 2^(E - 14)
         if (tid == 0) unscale[(int64_t)bh * (Rp / 32) + blockIdx.x] = us;
         unsigned short* dst = rowp + ((int64_t)bh * Rp + r0 + row) * HD + c0;
 #pragma unroll
         for (int i = 0; i < EPT / 2; ++i) {
-            unsigned hh, ll;
-            fl_split2h(v[2 * i] * sc, v[2 * i + 1] * sc, hh, ll);
-            reinterpret_cast<unsigned*>(dst)[i] = hh;
-            reinterpret_cast<unsigned*>(dst + plane_elems)[i] = ll;
+            fl_split2h(v[2 * i] * sc, v[2 * i + 1] * sc, ph[i], pm[i]);
+            if (rowp) {
+                reinterpret_cast<unsigned*>(dst)[i] = ph[i];
+                reinterpret_cast<unsigned*>(dst + plane_elems)[i] = pm[i];
+            }
         }
     }
     if (!trp) return;
-    unsigned ph[EPT / 2], pm[EPT / 2], pl[EPT / 2];
+    if (tr_form == 0) {
 #pragma unroll
-    for (int i = 0; i < EPT / 2; ++i) fl_split3(v[2 * i], v[2 * i + 1], ph[i], pm[i], pl[i]);
+        for (int i = 0; i < EPT / 2; ++i) fl_split3(v[2 * i], v[2 * i + 1], ph[i], pm[i], pl[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT / 2; ++i) pl[i] = 0u;
+    }
+    const int ntp = tr_form == 0 ? 3 : 2;
     const int prow = (row & 16) | fl_perm16(row & 15);
 #pragma unroll
     for (int i = 0; i < EPT / 2; ++i) {
@@ -141,19 +161,21 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
         lt[2][c0 + 2 * i][prow] = (unsigned short)(pl[i] & 0xffff); lt[2][c0 + 2 * i + 1][prow] = (unsigned short)(pl[i] >> 16);
     }
     __syncthreads();
-    // tr layout: per plane HD rows of 32 bf16 (64 bytes = four 16-byte chunks)
-    for (int c = tid; c < 3 * HD * 4; c += 256) {
+    // tr layout: per plane HD rows of 32 16-bit values (64 bytes = four 16-byte chunks)
+    for (int c = tid; c < ntp * HD * 4; c += 256) {
         const int pl_ = c / (HD * 4), d = (c / 4) % HD, ch = c % 4;
         const uint4 val = *reinterpret_cast<const uint4*>(&lt[pl_][d][ch * 8]);
         *reinterpret_cast<uint4*>(trp + pl_ * plane_elems + ((int64_t)bh * HD + d) * Rp + r0 + ch * 8) = val;
     }
 }
 
-extern "C" int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int n, int R, int Rp,
-                                 int64_t ld, int off, int H, int hd, hipStream_t stream) {
+extern "C" int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R,
+                                 int Rp, int64_t ld, int off, int H, int hd, hipStream_t stream) {
     if (n <= 0 || R <= 0) return IX_OK;
     IX_CHECK_ARG(x && (row_planes || tr_planes), "ix_attn_split_f32: null pointer");
-    IX_CHECK_ARG(!row_planes == !row_unscale, "ix_attn_split_f32: row planes and their unscale factors come together");
+    IX_CHECK_ARG(tr_form == 0 || tr_form == 1, "ix_attn_split_f32: tr_form %d (0 = three bf16 planes, 1 = two fp16 planes)", tr_form);
+    IX_CHECK_ARG(row_unscale || !(row_planes || (tr_planes && tr_form == 1)),
+                 "ix_attn_split_f32: fp16 planes (row, or tr of form 1) come with their block unscale factors");
     IX_CHECK_ARG(hd == 32 || hd == 64, "ix_attn_split_f32: head dim %d (32 or 64)", hd);
     IX_CHECK_ARG(Rp % 128 == 0 && Rp >= R, "ix_attn_split_f32: Rp=%d must be R=%d rounded up to 128", Rp, R);
     IX_CHECK_ARG(ld % 4 == 0 && off % 4 == 0 && ((uintptr_t)x & 15) == 0, "ix_attn_split_f32: rows must be 16-byte aligned");
@@ -161,10 +183,10 @@ extern "C" int ix_attn_split_f32(const float* x, void* row_planes, float* row_un
     dim3 grid(Rp / 32, n * H);
     if (hd == 64)
         hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, stream, x, (unsigned short*)row_planes, row_unscale,
-                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane);
+                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane, tr_form);
     else
         hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, stream, x, (unsigned short*)row_planes, row_unscale,
-                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane);
+                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane, tr_form);
     IX_CHECK_LAUNCH("ix_attn_split_f32");
     return IX_OK;
 }
@@ -203,12 +225,12 @@ __device__ __forceinline__ unsigned fl_hash(unsigned seed_lo, unsigned seed_hi, 
 // common machinery of the six kernels
 // ------------------------------------------------------------------------------------------------------------
 // A tile of 32 rows as staged in LDS: "row" segments [2][32][HD + 8] fp16 (fragments along d) and "tr" segments
-// [3][HD][32 + 8] bf16 (fragments along the 32 rows); the 16-byte row padding keeps ds_read_b128 fragment reads
+// [TP][HD][32 + 8] (TP = 3 bf16 planes, or 2 fp16 planes in tr form 1; fragments along the 32 rows); the 16-byte row padding keeps ds_read_b128 fragment reads
 // conflict-free (row pitch / 16 odd).  One unit = one plane of one segment = 4 * HD 16-byte chunks.
-template <int HD>
+template <int HD, int TP>
 struct FlSeg {
     static constexpr int RROW = (HD + 8) * 2, RPLANE = 32 * RROW, RBYTES = 2 * RPLANE;
-    static constexpr int TROW = (32 + 8) * 2, TPLANE = HD * TROW, TBYTES = 3 * TPLANE;
+    static constexpr int TROW = (32 + 8) * 2, TPLANE = HD * TROW, TBYTES = TP * TPLANE;
     // chunk c of a unit: global element offset from the tile's first row / LDS byte offset inside the plane
     static __device__ __forceinline__ int64_t row_src(int c) { return (int64_t)c * 8; }
     static __device__ __forceinline__ int row_dst(int c) { return (c / (HD / 8)) * RROW + (c % (HD / 8)) * 16; }
@@ -223,14 +245,14 @@ struct FlSeg {
 #define FL_DECL_REGS(P) uint4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7, P##8, P##9, P##10, P##11;
 // global -> staging registers (requested early) -> LDS (after the barrier that frees the destination) for the units
 // FIRST .. FIRST + COUNT - 1 (COUNT <= 12) of a tile whose first NROW segments are row segments (2 units each) followed
-// by tr segments (3 units each).  One chunk per thread and unit at HD 64, two units per pass at HD 32 (an odd unit out is
+// by tr segments (TP units each).  One chunk per thread and unit at HD 64, two units per pass at HD 32 (an odd unit out is
 // copied twice).  SRC / DST are expressions in seg_ (segment), pl_ (plane), c_ (chunk).
 #define FL_NREGS(COUNT) (HD == 64 ? (COUNT) : ((COUNT) + 1) / 2)
 #define FL_UNIT_DECODE(I, FIRST, COUNT, NROW)                                                                          \
     const int u_ = (FIRST) + (HD == 64 ? (I) : min(2 * (I) + (tid >> 7), (COUNT) - 1));                                \
     const int c_ = HD == 64 ? tid : (tid & 127);                                                                       \
     const bool isrow_ = u_ < 2 * (NROW);                                                                               \
-    const int seg_ = isrow_ ? u_ / 2 : (NROW) + (u_ - 2 * (NROW)) / 3, pl_ = isrow_ ? u_ % 2 : (u_ - 2 * (NROW)) % 3;  \
+    const int seg_ = isrow_ ? u_ / 2 : (NROW) + (u_ - 2 * (NROW)) / TP, pl_ = isrow_ ? u_ % 2 : (u_ - 2 * (NROW)) % TP; \
     (void)isrow_;
 #define FL_LOAD1(P, I, FIRST, COUNT, NROW, SRC)                                                                        \
     if ((I) < FL_NREGS(COUNT)) {                                                                                       \
@@ -268,21 +290,57 @@ struct FlSeg {
 #define FL_BFRAGS(DST, PTR, ELEM_OFF, PLANE)                                                                           \
     _Pragma("unroll") for (int ks_ = 0; ks_ < NKS; ++ks_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)           \
         DST[ks_][pl_] = *reinterpret_cast<const u32x4*>((PTR) + (ELEM_OFF) + pl_ * (PLANE) + ks_ * 16);
-// 16 accumulator-layout values -> B fragments (3 bf16 planes) of the two 16-row slices
+// 16 accumulator-layout values -> B fragments (TP planes: 3 bf16, or 2 fp16 of values already in fp16 range) of the two
+// 16-row slices
 #define FL_SPLIT16(PLANES, X)                                                                                          \
     _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_) _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {              \
-        unsigned hh_, mm_, ll_;                                                                                        \
-        fl_split3(X[8 * s2_ + 2 * j_], X[8 * s2_ + 2 * j_ + 1], hh_, mm_, ll_);                                        \
+        unsigned hh_, mm_, ll_ = 0u;                                                                                   \
+        if (TP == 3) fl_split3(X[8 * s2_ + 2 * j_], X[8 * s2_ + 2 * j_ + 1], hh_, mm_, ll_);                           \
+        else fl_split2h(X[8 * s2_ + 2 * j_], X[8 * s2_ + 2 * j_ + 1], hh_, mm_);                                       \
         PLANES[s2_][0][j_] = hh_; PLANES[s2_][1][j_] = mm_; PLANES[s2_][2][j_] = ll_;                                  \
     }
 // ACC[db] += X^T[d, row] . PLANES[row, col]   for the tr segment at OFF
 #define FL_STAGE2(ACC, BASE, OFF, ROWIDX, PLANES)                                                                      \
     _Pragma("unroll") for (int s2_ = 0; s2_ < 2; ++s2_) _Pragma("unroll") for (int db_ = 0; db_ < NDB; ++db_) {         \
         u32x4 tf_[3];                                                                                                  \
-        _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) tf_[pl_] = *reinterpret_cast<const u32x4*>(                \
+        _Pragma("unroll") for (int pl_ = 0; pl_ < TP; ++pl_) tf_[pl_] = *reinterpret_cast<const u32x4*>(               \
             (BASE) + (OFF) + pl_ * G::TPLANE + (db_ * 32 + (ROWIDX)) * G::TROW + (s2_ * 16 + 8 * a) * 2);              \
-        FL_MMA6(ACC[db_], tf_, PLANES[s2_])                                                                            \
+        if (TP == 3) { FL_MMA6(ACC[db_], tf_, PLANES[s2_]) } else { FL_MMA3(ACC[db_], tf_, PLANES[s2_]) }              \
     }
+// ---- tr form 1: an [L, S] intermediate into fp16 range ----
+// X (16 accumulator-layout values of one output column per lane) *= US . F, where US is the wave-uniform unscale factor of
+// the tr tile it is about to be multiplied with and F the running power-of-two factor of the accumulator ACC it goes into
+// (one per lane; the two half-waves of a column agree).  F only ever decreases: when the tile's largest magnitude MX (per
+// lane, or any bound of it) times US . F would reach 2^15, F drops to put it into [2^14, 2^15) and ACC is rescaled (exact).
+// Rare after the first tiles of a row, so the whole update sits behind one wave-wide branch.
+#define FL_FIT_BOUND(MXUS, F, ACC)                                                                                      \
+    if (__builtin_amdgcn_ballot_w64((MXUS) * F >= 32768.f)) {                                                          \
+        const unsigned e_ = (__float_as_uint(MXUS) >> 23) & 0xffu;                                                     \
+        const float fn_ = (MXUS) * F >= 32768.f ? __uint_as_float(min(268u - e_, 187u) << 23) : F;                     \
+        const int d_ = (int)(__float_as_uint(fn_) >> 23) - (int)(__float_as_uint(F) >> 23) + 127;                      \
+        const float rs_ = d_ > 0 ? __uint_as_float((unsigned)d_ << 23) : 0.f;                                          \
+        _Pragma("unroll") for (int db_ = 0; db_ < NDB; ++db_) _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)         \
+            ACC[db_][r_] *= rs_;                                                                                       \
+        F = fn_;                                                                                                       \
+    }
+#define FL_FIT16(X, US, F, ACC)                                                                                        \
+    if (TP == 2) {                                                                                                     \
+        float mx_ = 0.f;                                                                                               \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) mx_ = fmaxf(mx_, fabsf(X[r_]));                              \
+        mx_ = fmaxf(mx_, __shfl_xor(mx_, 32, 64)) * (US);                                                              \
+        FL_FIT_BOUND(mx_, F, ACC)                                                                                      \
+        const float c_ = (US) * F;                                                                                     \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[r_] *= c_;                                                 \
+    }
+// the same for values known to lie in [0, BOUND] (probabilities): no maximum is taken
+#define FL_FIT16_BOUNDED(X, BOUND, US, F, ACC)                                                                         \
+    if (TP == 2) {                                                                                                     \
+        const float mxb_ = (BOUND) * (US);                                                                             \
+        FL_FIT_BOUND(mxb_, F, ACC)                                                                                     \
+        const float c_ = (US) * F;                                                                                     \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[r_] *= c_;                                                 \
+    }
+#define FL_F0 1152921504606846976.f   // 2^60: where a running factor starts
 // accumulator-layout output (lane = row of the output tensor, registers = d) -> fp32 rows
 #define FL_STORE_ROWS(ACC, DSTPTR, MUL)                                                                                \
     _Pragma("unroll") for (int db_ = 0; db_ < NDB; ++db_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {            \
@@ -341,12 +399,12 @@ struct FlashArgs {
 // LSE_ONLY: only the row normalisers are produced (q k^T + online softmax statistics, no P v): what the derivative kernels
 // need when the forward OUTPUT came from the fp8 kernel, whose normalisers belong to fp8 scores, not to the fp16 scores
 // the derivative kernels recompute.
-template <int HD, bool DROP, bool LSE_ONLY = false>
+template <int HD, bool DROP, bool LSE_ONLY = false, int TP = 3>
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
-    typedef FlSeg<HD> G;
-    constexpr int OFF_K = 0, OFF_VT = G::RBYTES, BYTES = LSE_ONLY ? G::RBYTES : G::RBYTES + G::TBYTES, NU = LSE_ONLY ? 2 : 5, NROW = 1;
+    typedef FlSeg<HD, TP> G;
+    constexpr int OFF_K = 0, OFF_VT = G::RBYTES, BYTES = LSE_ONLY ? G::RBYTES : G::RBYTES + G::TBYTES, NU = LSE_ONLY ? 2 : 2 + TP, NROW = 1;
     __shared__ __attribute__((aligned(16))) unsigned char ldsb[2][BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, a = lane >> 5;
@@ -356,6 +414,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     const int64_t kro = (int64_t)bh * p.Sp * HD, kto = (int64_t)bh * HD * p.Sp;
     const float* bias = p.bias + (int64_t)b * p.Sp;
     const float* kus = p.k_us + (int64_t)bh * (p.Sp / 32);
+    const float* vus = TP == 2 ? p.v_us + (int64_t)bh * (p.Sp / 32) : kus;
+    float fo = FL_F0;   // (tr form 1) running factor of o
 
     u32x4 qf[NKS][2];
     FL_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q0 + lq) * HD + 8 * a, p.q_plane)
@@ -385,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
         f32x4 kb[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) kb[g] = *reinterpret_cast<const f32x4*>(bias + t0 + 8 * g + 4 * a);
-        const float cs = c2 * kus[t];
+        const float cs = c2 * kus[t], usv = vus[t];
         // next tile's operands: requested now, written to the other LDS buffer after this tile's products (the last
         // iteration re-requests its own tile: unconditional code keeps the staging registers out of scratch memory)
         FL_STAGE_LOAD(sv, 0, NU, NROW, FLF_SRC(min(t0 + 32, ntiles * 32 - 32)))
@@ -432,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
             }
             // ---- O^T[d, query] += V^T[d, key] . P^T[key, query] ----
             u32x4 pp[2][3];
+            FL_FIT16_BOUNDED(x, 1.f, usv, fo, o)   // (exp2(. - running max) <= 1)
             FL_SPLIT16(pp, x)
             FL_STAGE2(o, lds, OFF_VT, lq, pp)
         }
@@ -444,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     const int q = q0 + lq;
     if (q < p.L) {
         if (!LSE_ONLY) {
-            const float inv = p.inv_keep / l;
+            const float inv = TP == 2 ? p.inv_keep / (l * fo) : p.inv_keep / l;
             float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * HD + 4 * a;
             FL_STORE_ROWS(o, dst, inv)
         }
@@ -491,12 +552,12 @@ extern "C" int ix_attn_rowdot_f32(const float* a, const float* b, float* t, int 
 }
 
 // ---- query-owning workgroup: gQ (o1) ---------------------------------------------------------------------------------
-template <int HD, bool DROP>
+template <int HD, bool DROP, int TP = 3>
 __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
-    typedef FlSeg<HD> G;
-    constexpr int OFF_K = 0, OFF_V = G::RBYTES, OFF_KT = 2 * G::RBYTES, BYTES = 2 * G::RBYTES + G::TBYTES, NU = 7, NROW = 2;
+    typedef FlSeg<HD, TP> G;
+    constexpr int OFF_K = 0, OFF_V = G::RBYTES, OFF_KT = 2 * G::RBYTES, BYTES = 2 * G::RBYTES + G::TBYTES, NU = 4 + TP, NROW = 2;
     __shared__ __attribute__((aligned(16))) unsigned char ldsb[2][BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, a = lane >> 5;
@@ -521,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gq[db][r] = 0.f;
+    float fq = FL_F0;
 
     FL_DECL_REGS(sv)
 #define FLQ_SRC(T0)                                                                                                    \
@@ -539,7 +601,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
         f32x4 kb[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) kb[g] = *reinterpret_cast<const f32x4*>(bias + t0 + 8 * g + 4 * a);
-        const float cs = c2 * kus[t], cg = usd * vus[t];
+        const float usk = kus[t];
+        const float cs = c2 * usk, cg = usd * vus[t];
         FL_STAGE_LOAD(sv, 0, NU, NROW, FLQ_SRC(min(t0 + 32, ntiles * 32 - 32)))
         // ---- S^T = K Q^T and gd^T = V dO^T (two independent accumulator chains) ----
         f32x16 s, gd;
@@ -563,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
         for (int r = 0; r < 16; ++r)
             x[r] = fl_exp2(s[r] * cs + kb[r >> 2][r & 3] - lse2) * (FL_M(r, gd[r] * cg) - dl);
         u32x4 pp[2][3];
+        FL_FIT16(x, usk, fq, gq)
         FL_SPLIT16(pp, x)
         // ---- gQ^T[d, query] += K^T[d, key] gs^T[key, query] ----
         FL_STAGE2(gq, lds, OFF_KT, lq, pp)
@@ -574,7 +638,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
     const int q = q0 + lq;
     if (q < p.L) {
         float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * HD + 4 * a;
-        FL_STORE_ROWS(gq, dst, p.scale)
+        const float mq = TP == 2 ? p.scale / fq : p.scale;
+        FL_STORE_ROWS(gq, dst, mq)
     }
 }
 
@@ -582,13 +647,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_q_kernel(FlashArgs p) {
 // One LDS buffer, two phases per tile (as the second-order passes below): the ROW region (q, dO rows) feeds the two
 // [query, key] tiles while the next tile's rows are in flight, the TR region (q, dO transposed + lse, delta) feeds the two
 // output products while the next tile's tr operands are in flight.  49 KB of LDS and <= 256 registers: two workgroups per CU.
-template <int HD, bool DROP>
+template <int HD, bool DROP, int TP = 3>
 __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
-    typedef FlSeg<HD> G;
+    typedef FlSeg<HD, TP> G;
     constexpr int OFF_Q = 0, OFF_D = G::RBYTES, OFF_QT = 2 * G::RBYTES, OFF_DT = 2 * G::RBYTES + G::TBYTES;
-    constexpr int OFF_ST = 2 * G::RBYTES + 2 * G::TBYTES, BYTES = OFF_ST + 256, NROW = 2, NUR = 4, NUT = 6;   // + lse[32], delta[32]
+    constexpr int OFF_ST = 2 * G::RBYTES + 2 * G::TBYTES, BYTES = OFF_ST + 256, NROW = 2, NUR = 4, NUT = 2 * TP;   // + lse[32], delta[32]
     __shared__ __attribute__((aligned(16))) unsigned char lds[BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane & 31, a = lane >> 5;
@@ -611,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { gk[db][r] = 0.f; gv[db][r] = 0.f; }
+    float fk = FL_F0, fv = FL_F0;
 
     FL_DECL_REGS(sv)    // row units (phase 1)
     FL_DECL_REGS(svt)   // tr units (phase 2)
@@ -634,7 +700,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
 
     for (int t = 0; t < ntiles; ++t) {
         const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
-        const float cs = c2 * qus[t], cg = usv * dus[t];
+        const float usq = qus[t], usd = dus[t];
+        const float cs = c2 * usq, cg = usv * usd;
         FL_STAGE_LOAD(sv, 0, NUR, NROW, FLK_SRC(tn))
         // ---- S[query, key] = Q K^T and gd = dO V^T ----
         f32x16 s, gd;
@@ -668,8 +735,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
 #undef FLK_ST
         // ---- gV^T[d, key] += dO^T[d, query] Pd[query, key];  gK^T[d, key] += Q^T[d, query] gs[query, key] ----
         u32x4 pp[2][3];
+        FL_FIT16_BOUNDED(pd, 1.f, usd, fv, gv)
         FL_SPLIT16(pp, pd)
         FL_STAGE2(gv, lds, OFF_DT, lk, pp)
+        FL_FIT16(gs, usq, fk, gk)
         FL_SPLIT16(pp, gs)
         FL_STAGE2(gk, lds, OFF_QT, lk, pp)
         __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
@@ -682,8 +751,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
     if (key < p.S) {
         float* dk = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * HD + 4 * a;
         float* dv = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * HD + 4 * a;
-        FL_STORE_ROWS(gk, dk, p.scale)
-        FL_STORE_ROWS(gv, dv, p.inv_keep)
+        const float mk = TP == 2 ? p.scale / fk : p.scale, mv = TP == 2 ? p.inv_keep / fv : p.inv_keep;
+        FL_STORE_ROWS(gk, dk, mk)
+        FL_STORE_ROWS(gv, dv, mv)
     }
 }
 
@@ -705,11 +775,11 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_kv_kernel(FlashArgs p) {
 // forms the [key, query] tiles out of the ROW region while the next tile's rows are in flight, phase 2 runs the four output
 // products out of the TR region while the next tile's tr operands are in flight; each region is refilled right after the
 // barrier that ends its phase, from one shared set of staging registers.
-template <int HD, bool DROP, bool STATS>
+template <int HD, bool DROP, bool STATS, int TP = 3>
 __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
-    typedef FlSeg<HD> G;
+    typedef FlSeg<HD, TP> G;
     // row segments k, hk, v, hv; then (pass 2) tr segments hk, k, hv, v
     constexpr int OFF_K = 0, OFF_HK = G::RBYTES, OFF_V = 2 * G::RBYTES, OFF_HV = 3 * G::RBYTES;
     constexpr int OFF_HKT = 4 * G::RBYTES, OFF_KT = OFF_HKT + G::TBYTES, OFF_HVT = OFF_KT + G::TBYTES, OFF_VT = OFF_HVT + G::TBYTES;
@@ -717,7 +787,7 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
     // LDS per k-slice: 32 registers fewer, which is what keeps the staging loads out of scratch memory)
     constexpr int OFF_RES = 4 * G::RBYTES + 4 * G::TBYTES;
     constexpr int BYTES = STATS ? 4 * G::RBYTES : OFF_RES + 4 * G::RBYTES;
-    constexpr int NBUF = STATS ? 2 : 1, NROW = 4, NUR = 8, NUT = 12;
+    constexpr int NBUF = STATS ? 2 : 1, NROW = 4, NUR = 8, NUT = 4 * TP;
     __shared__ __attribute__((aligned(16))) unsigned char ldsq[NBUF][BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, a = lane >> 5;
@@ -752,6 +822,7 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dq[db][r] = 0.f; ddo[db][r] = 0.f; }
+    float fdq = FL_F0, fddo = FL_F0;
 
     FL_DECL_REGS(sv)    // row units (phase 1)
     FL_DECL_REGS(svt)   // tr units (phase 2)
@@ -833,21 +904,25 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
             // gs = P (gy - t)                                   dq += hk^T gs
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = pr[r] * (gd[r] - dl);
+            FL_FIT16(x, ushk, fdq, dq)
             FL_SPLIT16(pp, x)
             FL_STAGE2(dq, lds, OFF_HKT, lq, pp)
             // HS = P (G (gy - t) - gy u + M HD - w)             dq += k^T HS
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = pr[r] * (g1[r] * (gd[r] - dl) - gd[r] * uu + hd_[r] - ww);
+            FL_FIT16(x, usk, fdq, dq)
             FL_SPLIT16(pp, x)
             FL_STAGE2(dq, lds, OFF_KT, lq, pp)
             // Pd = M P                                          ddO += hv^T Pd
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r]);
+            FL_FIT16_BOUNDED(x, p.inv_keep, ushv, fddo, ddo)
             FL_SPLIT16(pp, x)
             FL_STAGE2(ddo, lds, OFF_HVT, lq, pp)
             // HgD = M P (G - u)                                 ddO += v^T HgD
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r] * (g1[r] - uu));
+            FL_FIT16(x, usv, fddo, ddo)
             FL_SPLIT16(pp, x)
             FL_STAGE2(ddo, lds, OFF_VT, lq, pp)
             __syncthreads();   // (B) every wave is done with the TR region; the next tile's rows are visible
@@ -870,23 +945,24 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
     if (q < p.L) {
         float* d1 = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * HD + 4 * a;
         float* d4 = p.o4 + ((int64_t)b * p.L + q) * p.ld4 + p.off4 + h * HD + 4 * a;
-        FL_STORE_ROWS(dq, d1, p.scale)
-        FL_STORE_ROWS(ddo, d4, 1.f)
+        const float m1 = TP == 2 ? p.scale / fdq : p.scale, m4 = TP == 2 ? 1.f / fddo : 1.f;
+        FL_STORE_ROWS(dq, d1, m1)
+        FL_STORE_ROWS(ddo, d4, m4)
     }
 }
 
 // pass 3 (key-owning): dk (o2), dv (o3).  Tiles [query, key]: lane = key, registers = queries.  Two-phase tile as in pass 2.
-template <int HD, bool DROP>
+template <int HD, bool DROP, int TP = 3>
 __global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int NKS = HD / 16, NDB = HD / 32;
-    typedef FlSeg<HD> G;
+    typedef FlSeg<HD, TP> G;
     // row segments q, hq, dO; tr segments hq, q, dO; statistics lse, delta, u, w [32] each (part of the TR phase)
     constexpr int OFF_Q = 0, OFF_HQ = G::RBYTES, OFF_D = 2 * G::RBYTES;
     constexpr int OFF_HQT = 3 * G::RBYTES, OFF_QT = OFF_HQT + G::TBYTES, OFF_DT = OFF_QT + G::TBYTES, OFF_ST = OFF_DT + G::TBYTES;
     // + resident: the hk and hv rows of each wave's 32 keys (their B fragments are read from here per k-slice instead of
     // living in 64 registers: with them in registers the staging loads spill, and a spilled in-flight load is waited for)
-    constexpr int OFF_RES = OFF_ST + 512, BYTES = OFF_RES + 4 * 2 * G::RBYTES, NROW = 3, NUR = 6, NUT = 9;
+    constexpr int OFF_RES = OFF_ST + 512, BYTES = OFF_RES + 4 * 2 * G::RBYTES, NROW = 3, NUR = 6, NUT = 3 * TP;
     __shared__ __attribute__((aligned(16))) unsigned char lds[BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lk = lane & 31, a = lane >> 5;
@@ -913,6 +989,7 @@ __global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(Flas
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    float fdk = FL_F0, fdv = FL_F0;
 
     FL_DECL_REGS(sv)    // row units (phase 1)
     FL_DECL_REGS(svt)   // tr units (phase 2)
@@ -984,17 +1061,20 @@ __global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(Flas
         // gs                                                     dk += hq^T gs
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = pr[r] * (gd[r] - FLC_ST(1, r));
+        FL_FIT16(x, ushq, fdk, dk)
         FL_SPLIT16(pp, x)
         FL_STAGE2(dk, lds, OFF_HQT, lk, pp)
         // HS                                                     dk += q^T HS
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             x[r] = pr[r] * (g1[r] * (gd[r] - FLC_ST(1, r)) - gd[r] * FLC_ST(2, r) + hd_[r] - FLC_ST(3, r));
+        FL_FIT16(x, usq, fdk, dk)
         FL_SPLIT16(pp, x)
         FL_STAGE2(dk, lds, OFF_QT, lk, pp)
         // HgD                                                    dv += dO^T HgD
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[r] = FL_M(r, pr[r] * (g1[r] - FLC_ST(2, r)));
+        FL_FIT16(x, usd, fdv, dv)
         FL_SPLIT16(pp, x)
         FL_STAGE2(dv, lds, OFF_DT, lk, pp)
 #undef FLC_ST
@@ -1008,8 +1088,9 @@ __global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(Flas
     if (key < p.S) {
         float* d2 = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * HD + 4 * a;
         float* d3 = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * HD + 4 * a;
-        FL_STORE_ROWS(dk, d2, p.scale)
-        FL_STORE_ROWS(dv, d3, 1.f)
+        const float m2 = TP == 2 ? p.scale / fdk : p.scale, m3 = TP == 2 ? 1.f / fdv : 1.f;
+        FL_STORE_ROWS(dk, d2, m2)
+        FL_STORE_ROWS(dv, d3, m3)
     }
 }
 
@@ -1020,8 +1101,11 @@ __global__ __launch_bounds__(256, HD == 32 ? 2 : 1) void flash_bb_kv_kernel(Flas
 struct ix_attn_planes {
     const void* row;      // fp16 row planes   [2][n*H][Rp][hd]
     const float* unscale; // block unscales    [n*H][Rp / 32]
-    const void* tr;       // bf16 tr planes    [3][n*H][hd][Rp]
+    const void* tr;       // tr planes         [3][n*H][hd][Rp] bf16 (tr_form 0) / [2][n*H][hd][Rp] fp16 (tr_form 1)
+    int tr_form;          // what ix_attn_split_f32 was asked to write; all operands of one call agree
 };
+// second-stage matrix instructions per algorithmic product: 6 (three bf16 planes) or 3 (two fp16 planes)
+#define FL_S2(FORM) ((FORM) == 1 ? 3 : 6)
 
 static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, int H, int L, int Lp, int S, int Sp, int hd,
                      float scale, float p_drop, uint64_t seed) {
@@ -1044,15 +1128,19 @@ static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, in
 #define FL_OUT_OK(LD, OFF) ((LD) % 4 == 0 && (OFF) % 4 == 0)
 // algorithmic FLOPs of ONE [L, S] x hd product over all (batch, head) pairs -- the unit the launch statistics count in
 #define FL_PRODUCT_FLOPS (2.0 * (double)n * (double)H * (double)L * (double)S * (double)hd)
-#define FL_DISPATCH(KERNEL, GRID)                                                                      \
+#define FL_DISPATCH2(KERNEL, GRID, HD_, TP_)                                                           \
+    if (a.thr16) hipLaunchKernelGGL((KERNEL<HD_, true, TP_>), GRID, dim3(256), 0, stream, a);          \
+    else hipLaunchKernelGGL((KERNEL<HD_, false, TP_>), GRID, dim3(256), 0, stream, a);
+#define FL_DISPATCH(KERNEL, GRID, FORM)                                                                \
     if (hd == 64) {                                                                                    \
-        if (a.thr16) hipLaunchKernelGGL((KERNEL<64, true>), GRID, dim3(256), 0, stream, a);            \
-        else hipLaunchKernelGGL((KERNEL<64, false>), GRID, dim3(256), 0, stream, a);                   \
+        if ((FORM) == 1) { FL_DISPATCH2(KERNEL, GRID, 64, 2) } else { FL_DISPATCH2(KERNEL, GRID, 64, 3) } \
     } else {                                                                                           \
-        if (a.thr16) hipLaunchKernelGGL((KERNEL<32, true>), GRID, dim3(256), 0, stream, a);            \
-        else hipLaunchKernelGGL((KERNEL<32, false>), GRID, dim3(256), 0, stream, a);                   \
+        if ((FORM) == 1) { FL_DISPATCH2(KERNEL, GRID, 32, 2) } else { FL_DISPATCH2(KERNEL, GRID, 32, 3) } \
     }
 
+#define FL_DISPATCH_FWD(HD_, TP_)                                                                      \
+    if (a.thr16) hipLaunchKernelGGL((flash_fwd_kernel<HD_, true, false, TP_>), grid, dim3(256), 0, stream, a); \
+    else hipLaunchKernelGGL((flash_fwd_kernel<HD_, false, false, TP_>), grid, dim3(256), 0, stream, a);
 extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k, const ix_attn_planes* v, const float* bias,
                                 float* out, float* lse, int n, int H, int L, int Lp, int S, int Sp, int hd, int64_t ld_out,
                                 int off_out, float scale, float p_drop, uint64_t seed, hipStream_t stream) {
@@ -1066,6 +1154,9 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.q_row = (const unsigned short*)q->row; a.q_us = q->unscale;
     a.k_row = (const unsigned short*)k->row; a.k_us = k->unscale;
     a.v_tr = out ? (const unsigned short*)v->tr : nullptr;
+    const int form = out ? v->tr_form : 0;
+    IX_CHECK_ARG(form == 0 || (form == 1 && v->unscale), "ix_flash_fwd_f32: v tr planes of form %d lack their unscale factors", form);
+    a.v_us = out ? v->unscale : nullptr;
     a.o1 = out; a.ld1 = ld_out; a.off1 = off_out; a.lse = lse;
     dim3 grid((L + 127) / 128, n * H);
     if (!out) {   // row normalisers only
@@ -1076,8 +1167,12 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
         IX_CHECK_LAUNCH("ix_flash_fwd_f32");
         return IX_OK;
     }
-    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 1);
-    FL_DISPATCH(flash_fwd_kernel, grid)
+    ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 1);
+    if (hd == 64) {
+        if (form == 1) { FL_DISPATCH_FWD(64, 2) } else { FL_DISPATCH_FWD(64, 3) }
+    } else {
+        if (form == 1) { FL_DISPATCH_FWD(32, 2) } else { FL_DISPATCH_FWD(32, 3) }
+    }
     ix_prof_end(stream);
     IX_CHECK_LAUNCH("ix_flash_fwd_f32");
     return IX_OK;
@@ -1101,20 +1196,23 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.k_row = (const unsigned short*)k->row; a.k_us = k->unscale; a.k_tr = (const unsigned short*)k->tr;
     a.v_row = (const unsigned short*)v->row; a.v_us = v->unscale;
     a.lse = const_cast<float*>(lse); a.delta = delta;
+    const int form = q->tr_form;
+    IX_CHECK_ARG((form == 0 || form == 1) && k->tr_form == form && d_out->tr_form == form,
+                 "ix_flash_bwd_f32: operands were split with different tr forms");
     a.o1 = gq; a.ld1 = ld_q; a.off1 = off_q; a.o2 = gk; a.ld2 = ld_k; a.off2 = off_k; a.o3 = gv; a.ld3 = ld_v; a.off3 = off_v;
     // algorithmic FLOPs = the products the REFERENCE's graph evaluates (first derivative of softmax(q k^T) v: dP = dO v^T,
     // dV = P^T dO, dQ = dS k, dK = dS^T q -- four; two per kernel); the recomputed S (and gd in the key-owning pass) only count as
     // executed matrix instructions (third argument)
     if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * 6) * FL_PRODUCT_FLOPS, 2);
-        FL_DISPATCH(flash_bwd_q_kernel, grid)
+        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 2);
+        FL_DISPATCH(flash_bwd_q_kernel, grid, form)
         ix_prof_end(stream);
     }
     if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
-        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * 6) * FL_PRODUCT_FLOPS, 3);
-        FL_DISPATCH(flash_bwd_kv_kernel, grid)
+        ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * FL_S2(form)) * FL_PRODUCT_FLOPS, 3);
+        FL_DISPATCH(flash_bwd_kv_kernel, grid, form)
         ix_prof_end(stream);
     }
     IX_CHECK_LAUNCH("ix_flash_bwd_f32");
@@ -1132,6 +1230,9 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     const ix_attn_planes* ops[7] = {q, k, v, d_out, hq, hk, hv};
     for (int i = 0; i < 7; ++i)
         IX_CHECK_ARG(ops[i] && ops[i]->row && ops[i]->unscale && ops[i]->tr, "ix_flash_bwd_bwd_f32: operand %d lacks planes", i);
+    const int form = q->tr_form;
+    for (int i = 0; i < 7; ++i)
+        IX_CHECK_ARG((form == 0 || form == 1) && ops[i]->tr_form == form, "ix_flash_bwd_bwd_f32: operand %d was split with another tr form", i);
     IX_CHECK_ARG(lse && delta && dq && dk && dv && ddo, "ix_flash_bwd_bwd_f32: null pointer");
     IX_CHECK_ARG(FL_OUT_OK(ld_q, off_q) && FL_OUT_OK(ld_k, off_k) && FL_OUT_OK(ld_v, off_v) && FL_OUT_OK(ld_do, off_do),
                  "ix_flash_bwd_bwd_f32: output rows must be 16-byte aligned");
@@ -1155,22 +1256,24 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     // matrix work (third argument).  Algorithmic FLOPs = the ten products of the materialised double-backward graph (hipops.
     // AttentionCoreBwd.backward = what autograd evaluates for the reference): G 2 + HD 1 in the statistics pass, the 4 and 3
     // output products of the other two; recomputed S / gd / G / HD tiles are not algorithmic work
-#define FL_BB_LAUNCH(HD_, DR_)                                                                         \
+#define FL_BB_LAUNCH2(HD_, DR_, TP_)                                                                   \
     ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);                      \
-    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true>), gq, blk, 0, stream, a);                    \
+    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, true, 3>), gq, blk, 0, stream, a);                 \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 6) * FL_PRODUCT_FLOPS, 5);              \
-    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false>), gq, blk, 0, stream, a);                   \
+    ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * FL_S2(form)) * FL_PRODUCT_FLOPS, 5);    \
+    hipLaunchKernelGGL((flash_bb_q_kernel<HD_, DR_, false, TP_>), gq, blk, 0, stream, a);              \
     ix_prof_end(stream);                                                                               \
-    ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 6) * FL_PRODUCT_FLOPS, 6);              \
-    hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_>), gk, blk, 0, stream, a);                         \
+    ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * FL_S2(form)) * FL_PRODUCT_FLOPS, 6);    \
+    hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_, TP_>), gk, blk, 0, stream, a);                    \
     ix_prof_end(stream);
+#define FL_BB_LAUNCH(HD_, DR_) if (form == 1) { FL_BB_LAUNCH2(HD_, DR_, 2) } else { FL_BB_LAUNCH2(HD_, DR_, 3) }
     if (hd == 64) {
         if (a.thr16) { FL_BB_LAUNCH(64, true) } else { FL_BB_LAUNCH(64, false) }
     } else {
         if (a.thr16) { FL_BB_LAUNCH(32, true) } else { FL_BB_LAUNCH(32, false) }
     }
 #undef FL_BB_LAUNCH
+#undef FL_BB_LAUNCH2
     IX_CHECK_LAUNCH("ix_flash_bwd_bwd_f32");
     return IX_OK;
 }
@@ -1449,7 +1552,13 @@ extern "C" int ix_flash_fwd_fp8_f32(const void* q_row8, const float* q_unscale, 
     a.salt = reinterpret_cast<const unsigned*>(ix_g_salt);
     dim3 grid((L + 127) / 128, n * H);
     ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, 2.0 * FL_PRODUCT_FLOPS, 1);
-    FL_DISPATCH(flash_fwd_fp8_kernel, grid)
+    if (hd == 64) {
+        if (a.thr16) hipLaunchKernelGGL((flash_fwd_fp8_kernel<64, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((flash_fwd_fp8_kernel<64, false>), grid, dim3(256), 0, stream, a);
+    } else {
+        if (a.thr16) hipLaunchKernelGGL((flash_fwd_fp8_kernel<32, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((flash_fwd_fp8_kernel<32, false>), grid, dim3(256), 0, stream, a);
+    }
     ix_prof_end(stream);
     IX_CHECK_LAUNCH("ix_flash_fwd_fp8_f32");
     return IX_OK;

@@ -662,31 +662,44 @@ def _pad128(R):
 
 
 class _PlanesC(ctypes.Structure):   # struct ix_attn_planes of include/interactron_hip.h
-    _fields_ = [("row", ctypes.c_void_p), ("unscale", ctypes.c_void_p), ("tr", ctypes.c_void_p)]
+    _fields_ = [("row", ctypes.c_void_p), ("unscale", ctypes.c_void_p), ("tr", ctypes.c_void_p), ("tr_form", ctypes.c_int)]
+
+
+# How the flash kernels run their token-contracting products (P v, dS k, ... and the second-order ones): "f16" = tr form 1, two
+# fp16 planes and three matrix instructions per k-slice, the [L, S] intermediates scaled into fp16 range in registers (default
+# since round 3); "bf16" = tr form 0, three bf16 planes and six instructions.  Both carry the parity record (tests/conftest.py
+# kernel_form).  Read when an operand is split; the derivative passes follow the form their forward was split with.
+FLASH_TR = _os.environ.get("IX_FLASH_TR", "f16")
+_TR_FORMS = {"bf16": 0, "f16": 1}
 
 
 class AttnPlanes:
     """One attention operand as the flash kernels read it: fp16 row planes [2][n*H][Rp][hd] with their block unscale factors
-    [n*H][Rp/32], and bf16 tr planes [3][n*H][hd][Rp] (csrc/flash.hip); ``ref`` is the C view handed to the library."""
+    [n*H][Rp/32], and tr planes -- bf16 [3][n*H][hd][Rp] (form 0) or fp16 [2][n*H][hd][Rp] (form 1) (csrc/flash.hip);
+    ``ref`` is the C view handed to the library."""
 
-    def __init__(self, row, unscale, tr):
-        self.row, self.unscale, self.tr = row, unscale, tr
+    def __init__(self, row, unscale, tr, tr_form=0):
+        self.row, self.unscale, self.tr, self.tr_form = row, unscale, tr, tr_form
         self.c = _PlanesC(row.data_ptr() if row is not None else None, unscale.data_ptr() if unscale is not None else None,
-                          tr.data_ptr() if tr is not None else None)
+                          tr.data_ptr() if tr is not None else None, tr_form)
         self.ref = ctypes.byref(self.c)
 
 
-def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True):
+def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
     """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> AttnPlanes (Rp = R rounded up to 128)."""
     x = _req(x, "attention operand")
     Rp = _pad128(R)
     dev = x.device
+    form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
     rowp = torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if row else None
-    us = torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=dev) if row else None
-    trp = torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev) if tr else None
-    _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if row else None,
-                                trp.data_ptr() if tr else None, n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_f32")
-    return AttnPlanes(rowp, us, trp)
+    us = torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=dev) if row or (tr and form == 1) else None
+    trp = None
+    if tr:
+        trp = (torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if form == 1 else
+               torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev))
+    _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
+                                trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_f32")
+    return AttnPlanes(rowp, us, trp, form)
 
 
 _bias_cache = {}
@@ -844,7 +857,7 @@ class FlashAttentionBwd(Function):
         do = _req(do.contiguous(), "attention dO")
         dev = q.device
         Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
-        dop = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd)
+        dop = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd, tr_form=pl["q"].tr_form)
         delta = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)
         _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
                                      _stream()), "ix_attn_rowdot_f32")
@@ -876,9 +889,9 @@ class FlashAttentionBwd(Function):
             hv = hq
         else:
             hv = _req(hv.contiguous()) if hv is not None else zeros(v)
-        hqp = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd)
-        hkp = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd)
-        hvp = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd)
+        hqp = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
+        hkp = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
+        hvp = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
         dq, dk, dv = _grad_buffers(g, q, k, v, ctx.same_qk)
         ddo = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
         need = ctypes.c_size_t()

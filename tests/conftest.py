@@ -30,8 +30,21 @@ def kernel_form(request):
     """Runs a test once per form of the 12-wave contraction kernel: "x3" = two fp16 planes + a sub-block exponent, three MFMAs
     per k-slice (the default since round 3), "x6" = three bf16 planes, six MFMAs (IX_GEMM_KERNEL=x6).  Both carry the parity
     record of the model-level tests."""
-    from interactron_amd import _lib
+    from interactron_amd import _lib, hipops
     lib = _lib.load()
     old = lib.ix_gemm_set_x3(1 if request.param == "x3" else 0)
+    old_tr, hipops.FLASH_TR = hipops.FLASH_TR, "f16" if request.param == "x3" else "bf16"   # the attention kernels' twin switch
     yield request.param
     lib.ix_gemm_set_x3(old)
+    hipops.FLASH_TR = old_tr
+
+
+@pytest.fixture(params=["f16", "bf16"])
+def flash_form(request):
+    """Runs a test once per form of the flash kernels' token-contracting products: "f16" = two fp16 planes, three MFMAs per
+    k-slice, intermediates scaled into fp16 range in registers (default since round 3); "bf16" = three bf16 planes, six MFMAs
+    (IX_FLASH_TR=bf16)."""
+    from interactron_amd import hipops
+    old, hipops.FLASH_TR = hipops.FLASH_TR, request.param
+    yield request.param
+    hipops.FLASH_TR = old

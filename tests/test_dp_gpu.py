@@ -48,7 +48,7 @@ def _rank(rank, world, port, recorded, out):
     random.seed(11)
     draws = [random.randint(0, 4) for _ in range(world)]
     random.randint = lambda a, b, _r=draws[rank]: _r
-    with ReferenceMatching(recorded, max_flip_share=1.0):
+    with ReferenceMatching(recorded, max_flip_share=1.0, ordered=True):
         _, losses = m(data)
     outer.flat.all_reduce_grads()
     g = {k: (None if p.grad is None else p.grad.detach().cpu().clone()) for k, p in m.named_parameters()}

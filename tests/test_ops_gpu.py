@@ -747,6 +747,7 @@ def _ref_attention(q, k, v, H, scale, mask):
 
 @pytest.mark.parametrize("n,H,L,S,hd,masked", [(2, 8, 361, 361, 32, True), (2, 8, 50, 361, 32, True), (1, 8, 300, 300, 64, False),
                                                 (2, 8, 50, 50, 32, False), (1, 2, 517, 2060, 64, False), (3, 4, 37, 130, 64, True)])
+@pytest.mark.usefixtures("flash_form")
 def test_flash_forward_against_float64(ops, n, H, L, S, hd, masked):
     E = H * hd
     q, k, v = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
@@ -781,6 +782,7 @@ def _ref_attention_drop(q, k, v, H, scale, mask, drop):
 @pytest.mark.parametrize("n,H,L,S,hd,masked,pdrop", [(2, 8, 50, 361, 32, True, 0.0), (1, 4, 200, 200, 64, False, 0.0),
                                                       (2, 2, 70, 130, 32, True, 0.1), (1, 2, 300, 517, 64, False, 0.1),
                                                       (2, 4, 130, 37, 64, True, 0.25)])
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_first_order_against_float64(ops, n, H, L, S, hd, masked, pdrop):
     """Forward and backward of the flash node against float64 autograd of the plain formula, with the kernels' own
     dropout mask (ix_flash_dropmask_f32) applied as a tensor on the reference side."""
@@ -810,6 +812,7 @@ def test_flash_attention_first_order_against_float64(ops, n, H, L, S, hd, masked
         close(a, b, 3e-5, "flash grad " + name)
 
 
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_packed_qk_buffer(ops):
     """q and k read out of one [n, L, 2E] projection buffer (nn.MultiheadAttention self-attention with q = k input):
     the gradient comes back as ONE buffer of that shape."""
@@ -830,6 +833,7 @@ def test_flash_attention_packed_qk_buffer(ops):
     close(gh[1], gr[1], 3e-5, "packed grad v")
 
 
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_same_tensor_for_q_k_v(ops):
     """attention(x, x, x) -- ONE unpacked tensor as query, key and value (equal offsets, overlapping columns): the operands'
     gradients must be SUMMED into x.grad, first and second order (a shared gradient buffer is only legal for the packed
@@ -855,6 +859,7 @@ def test_flash_attention_same_tensor_for_q_k_v(ops):
 
 @pytest.mark.parametrize("n,H,L,S,hd,masked,pdrop", [(2, 4, 50, 90, 32, True, 0.0), (1, 2, 150, 150, 64, False, 0.0),
                                                       (2, 2, 70, 130, 32, True, 0.1), (1, 2, 130, 200, 64, False, 0.1)])
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_second_order_against_float64(ops, n, H, L, S, hd, masked, pdrop):
     """The double backward of the flash node (three recompute passes) against float64 autograd: gradients of a random
     functional of (gq, gk, gv) with respect to q, k, v AND the incoming dO."""
@@ -889,6 +894,7 @@ def test_flash_attention_second_order_against_float64(ops, n, H, L, S, hd, maske
         close(a, b, 6e-5, "flash second-order " + name)
 
 
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_second_order_packed_qk(ops):
     n, H, L, hd = 2, 4, 77, 32
     E = H * hd
@@ -910,7 +916,67 @@ def test_flash_attention_second_order_packed_qk(ops):
         close(a, b, 6e-5, "packed second-order " + name)
 
 
+@pytest.mark.usefixtures("flash_form")
 @pytest.mark.parametrize("hd,pdrop", [(64, 0.0), (32, 0.1)])
+def test_flash_attention_wide_dynamic_range(ops, hd, pdrop):
+    """Operands and cotangents whose magnitudes differ by many orders between rows, between 32-row blocks and along the key
+    axis (later key tiles carry the largest values, so the fp16 form's running factors have to drop in mid-row and rescale
+    their accumulators), one sharply peaked and one uniform attention row, tiny and large cotangents: every output ROW must
+    stay within fp32-class distance of float64 RELATIVE TO THAT ROW'S OWN scale, first and second order."""
+    n, H, L, S = 2, 2, 150, 330
+    E = H * hd
+    q, k, v = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3)
+    ramp = torch.logspace(-4, 3, S).view(1, S, 1)             # values grow by 10^7 along the keys
+    v = v * ramp
+    k = k * torch.logspace(-1, 0.5, S).view(1, S, 1)
+    q[0, 0] *= 8.0                                             # peaked row
+    q[0, 1] *= 1e-4                                            # uniform row
+    q[1, 5:40] *= 1e-3
+    gy = rnd(n, L, E, seed=5) * torch.logspace(-6, 2, L).view(1, L, 1)   # cotangent rows from 1e-6 to 1e2
+    ws = [rnd(n, L, E, seed=6) * 1e-3, rnd(n, S, E, seed=7) * torch.logspace(2, -5, S).view(1, S, 1), rnd(n, S, E, seed=8) * 1e2]
+    # whole 32-row blocks of exact zeros in a value operand, a cotangent and a second-order cotangent (tokens the loss does not
+    # see): their block scale must not size anything (round 3: an unscale factor of 1 for such blocks dragged the running
+    # factors of the fp16 form down and cost the OTHER blocks 1 % -- found by the model-level fixture G11, not by random inputs)
+    v[:, 64:128] = 0.0
+    gy[:, 32:96] = 0.0
+    ws[0][:, 96:128] = 0.0
+    ws[2][:, 192:256] = 0.0
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    seed = 0x2468ACE
+    drop = ops.flash_dropmask(n * H, L, S, pdrop, seed).cpu().double() if pdrop > 0 else None
+
+    def second(dev, dt, fn):
+        x = [t.to(dev, dt).requires_grad_(True) for t in (q, k, v)]
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        out = fn(*x)
+        g1 = torch.autograd.grad(out, x, gyd, create_graph=True)
+        s = sum((a * w.to(dev, dt)).sum() for a, w in zip(g1, ws))
+        return out, g1, torch.autograd.grad(s, x + [gyd])
+
+    oh, g1h, g2h = second("cuda", torch.float32, lambda a, b, c: ops.FlashAttention.apply(a, b, c, g, None, pdrop, seed))
+    orf, g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, None, drop))
+
+    def rows_close(a, b, tol, what):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        a, b = a.reshape(-1, H, hd), b.reshape(-1, H, hd)     # one (row, head) at a time: the unit a kernel lane owns
+        err = (a - b).abs().amax(-1)
+        ref = b.abs().amax(-1)
+        # fp32-class: a row's error against its own scale, with a floor at the tensor's scale x 1e-9 (contributions that a
+        # float32 reference would round away as well)
+        bad = err > tol * ref + 1e-9 * float(b.abs().max())
+        assert not bool(bad.any()), "%s: %d rows off, worst %.3e of its scale" % (
+            what, int(bad.sum()), float((err / ref.clamp_min(1e-300)).max()))
+
+    rows_close(oh, orf, 3e-5, "forward")
+    for name, a, b in zip("qkv", g1h, g1r):
+        rows_close(a, b, 2e-4, "grad " + name)
+    for name, a, b in zip(["q", "k", "v", "dO"], g2h, g2r):
+        rows_close(a, b, 3e-4, "second-order " + name)
+
+
+@pytest.mark.parametrize("hd,pdrop", [(64, 0.0), (32, 0.1)])
+@pytest.mark.usefixtures("flash_form")
 def test_flash_attention_packed_kqv_buffer(ops, hd, pdrop):
     """k, q and v read out of ONE [n, L, 3E] projection buffer (the fusion blocks' three projections as one contraction):
     forward, the single gradient buffer of that layout, and its double backward against float64."""

@@ -576,7 +576,7 @@ def test_episode_batched_equals_sequential_schedule():
             finally:
                 cr.HungarianMatcher.assign = orig
         else:
-            with ReferenceMatching(recorded):
+            with ReferenceMatching(recorded, ordered=True):
                 preds, losses = m(data)
         res.append((preds, losses, {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()},
                     {k: v.get_label(data["actions"][i][:4].tolist()) for i, (k, v) in enumerate(m.path_storage.items())}))
