@@ -537,7 +537,9 @@ def main():
                        "peak_memory_GB": head.get("peak_memory_GB"), "parallelism": "dp%d" % world,
                        "global_batch": args.global_batch if strong else args.episodes * world,
                        "host_issue_ms_per_step": head["host_issue_ms_per_step"], "step_graphs": head["step_graphs"],
-                       "contraction_kernel": os.environ.get("IX_GEMM_KERNEL", "x3 (default: fp16x3 form, bf16x6 for narrow tiles)")},
+                       "contraction_kernel": os.environ.get("IX_GEMM_KERNEL", "x3 (default: fp16x3 form, bf16x6 for narrow tiles)"),
+                       "flash_tr": hipops.FLASH_TR + (" (two fp16 planes, 3 MFMAs per k-slice in the token-contracting products)"
+                                                   if hipops.FLASH_TR == "f16" else " (three bf16 planes, 6 MFMAs)")},
             "gemm_gflop_per_step": head["gemm_gflop_per_step"], "gemm_launches_per_step": head["gemm_launches_per_step"],
             "attention_gflop_per_step": head["attention_gflop_per_step"],
             "roofline": head["roofline"],
