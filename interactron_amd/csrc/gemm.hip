@@ -560,7 +560,10 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
 #pragma unroll
                 for (int c = 0; c < 4; ++c) e[i][c] = gk + c < kmax ? e[i][c] : 0.f;
             }
-            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(e[i][0]), fabsf(e[i][1]))), fmaxf(fabsf(e[i][2]), fabsf(e[i][3])));
+            // |.| as source modifiers of v_max3_f32: 8 instructions for the 16 elements (the compiler's own lowering of
+            // fmaxf(fabsf) spends 28: it canonicalises every |x| with a v_max of its own)
+            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][0]), "v"(e[i][1]));
+            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][2]), "v"(e[i][3]));
         }
         // wave maximum without the LDS crossbar (six ds_bpermute shuffles cost the producers 8 % of the kernel): the bit
         // pattern of a non-negative float orders like an integer; DPP row shifts, then row broadcasts; lane 63 has it
@@ -590,9 +593,15 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             f32x2 x0, x1;
             x0.x = e[i][0] * sc; x0.y = e[i][1] * sc; x1.x = e[i][2] * sc; x1.y = e[i][3] * sc;
             const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
-            const f32x2 b0 = __builtin_convertvector(h0, f32x2), b1 = __builtin_convertvector(h1, f32x2);
+            // residual x * sc - float(h) in ONE instruction per element (v_fma_mix_f32 reads the fp16 half directly; exact: the
+            // scale is a power of two and a float minus its own fp16 rounding is representable), instead of a conversion
+            // back plus a packed fma
             f32x2 r0, r1;
-            r0.x = x0.x - b0.x; r0.y = x0.y - b0.y; r1.x = x1.x - b1.x; r1.y = x1.y - b1.y;
+            const unsigned hb0 = __builtin_bit_cast(unsigned, h0), hb1 = __builtin_bit_cast(unsigned, h1);
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0.x) : "v"(e[i][0]), "v"(sc), "v"(hb0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r0.y) : "v"(e[i][1]), "v"(sc), "v"(hb0));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r1.x) : "v"(e[i][2]), "v"(sc), "v"(hb1));
+            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1.y) : "v"(e[i][3]), "v"(sc), "v"(hb1));
             const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
             unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
             u32x2 ph, pl;
