@@ -255,6 +255,11 @@ struct ix_attn_planes {
 };
 int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R, int Rp,
                       int64_t ld, int off, int H, int hd, ix_stream_t stream);
+/* up to three operands of one attention call (q, k, v / hq, hk, hv) in ONE launch; arrays of `count` entries, null entries
+ * of row_planes / tr_planes as in ix_attn_split_f32 */
+int ix_attn_split_multi_f32(int count, const float* const* x, void* const* row_planes, float* const* row_unscale,
+                            void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
+                            const int* off, int H, int hd, ix_stream_t stream);
 int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, int Sb, int64_t mask_ld, ix_stream_t stream);
 int ix_flash_fwd_f32(const struct ix_attn_planes* q, const struct ix_attn_planes* k, const struct ix_attn_planes* v,
                      const float* bias, float* out, float* lse, int n, int H, int L, int Lp, int S, int Sp, int hd,

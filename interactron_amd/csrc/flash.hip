@@ -97,10 +97,29 @@ __device__ __host__ __forceinline__ int fl_perm16(int r) { return (r & 3) | ((r 
 // split kernel: fp32 [n][R][ld] (head h at columns off + h*hd) -> fp16 row planes (+ block unscale factors) and
 // bf16 tr planes.  One workgroup = one block of 32 rows of one (batch, head).
 // ------------------------------------------------------------------------------------------------------------
+// Up to three operands per launch (blockIdx.z; the q, k, v -- or hq, hk, hv -- of one attention call: one launch instead of
+// three in a step whose small-batch form is bound by its launch count).
+struct SplitOp {
+    const float* x;
+    unsigned short *rowp, *trp;
+    float* unscale;
+    int R, Rp, off;
+    int64_t ld, plane_elems;
+};
+struct SplitOps {
+    SplitOp op[3];
+};
+
 template <int HD>
-__global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict__ X, unsigned short* __restrict__ rowp,
-                                                         float* __restrict__ unscale, unsigned short* __restrict__ trp, int R,
-                                                         int Rp, int64_t ld, int off, int H, int64_t plane_elems, int tr_form) {
+__global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, int tr_form) {
+    const SplitOp& o = ops.op[blockIdx.z];
+    if ((int)blockIdx.x * 32 >= o.Rp) return;
+    const float* __restrict__ X = o.x;
+    unsigned short* __restrict__ rowp = o.rowp;
+    unsigned short* __restrict__ trp = o.trp;
+    float* __restrict__ unscale = o.unscale;
+    const int R = o.R, Rp = o.Rp, off = o.off;
+    const int64_t ld = o.ld, plane_elems = o.plane_elems;
     constexpr int EPT = 32 * HD / 256;          // elements per thread: 8 (hd 64) / 4 (hd 32)
     constexpr int TPR = HD / EPT;               // threads per row: 8
     __shared__ __attribute__((aligned(16))) unsigned short lt[3][HD][32 + 8];   // [plane][d][permuted row], 80-byte rows
@@ -169,26 +188,51 @@ __global__ __launch_bounds__(256) void attn_split_kernel(const float* __restrict
     }
 }
 
+static int fl_split_launch(const char* who, int count, const float* const* x, void* const* row_planes, float* const* unscale,
+                           void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
+                           const int* off, int H, int hd, hipStream_t stream) {
+    IX_CHECK_ARG(count >= 1 && count <= 3, "%s: %d operands (1..3)", who, count);
+    IX_CHECK_ARG(tr_form == 0 || tr_form == 1, "%s: tr_form %d (0 = three bf16 planes, 1 = two fp16 planes)", who, tr_form);
+    IX_CHECK_ARG(hd == 32 || hd == 64, "%s: head dim %d (32 or 64)", who, hd);
+    SplitOps ops;
+    memset(&ops, 0, sizeof(ops));
+    int maxRp = 0;
+    for (int i = 0; i < count; ++i) {
+        IX_CHECK_ARG(x[i] && (row_planes[i] || tr_planes[i]), "%s: null pointer (operand %d)", who, i);
+        IX_CHECK_ARG(unscale[i] || !(row_planes[i] || (tr_planes[i] && tr_form == 1)),
+                     "%s: fp16 planes (row, or tr of form 1) come with their block unscale factors", who);
+        IX_CHECK_ARG(R[i] > 0 && Rp[i] % 128 == 0 && Rp[i] >= R[i], "%s: Rp=%d must be R=%d rounded up to 128", who, Rp[i], R[i]);
+        IX_CHECK_ARG(ld[i] % 4 == 0 && off[i] % 4 == 0 && ((uintptr_t)x[i] & 15) == 0, "%s: rows must be 16-byte aligned", who);
+        SplitOp& o = ops.op[i];
+        o.x = x[i]; o.rowp = (unsigned short*)row_planes[i]; o.trp = (unsigned short*)tr_planes[i]; o.unscale = unscale[i];
+        o.R = R[i]; o.Rp = Rp[i]; o.off = off[i]; o.ld = ld[i];
+        o.plane_elems = (int64_t)n * H * Rp[i] * hd;
+        maxRp = Rp[i] > maxRp ? Rp[i] : maxRp;
+    }
+    dim3 grid(maxRp / 32, n * H, count);
+    if (hd == 64)
+        hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, stream, ops, H, tr_form);
+    else
+        hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, stream, ops, H, tr_form);
+    IX_CHECK_LAUNCH(who);
+    return IX_OK;
+}
+
 extern "C" int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R,
                                  int Rp, int64_t ld, int off, int H, int hd, hipStream_t stream) {
     if (n <= 0 || R <= 0) return IX_OK;
-    IX_CHECK_ARG(x && (row_planes || tr_planes), "ix_attn_split_f32: null pointer");
-    IX_CHECK_ARG(tr_form == 0 || tr_form == 1, "ix_attn_split_f32: tr_form %d (0 = three bf16 planes, 1 = two fp16 planes)", tr_form);
-    IX_CHECK_ARG(row_unscale || !(row_planes || (tr_planes && tr_form == 1)),
-                 "ix_attn_split_f32: fp16 planes (row, or tr of form 1) come with their block unscale factors");
-    IX_CHECK_ARG(hd == 32 || hd == 64, "ix_attn_split_f32: head dim %d (32 or 64)", hd);
-    IX_CHECK_ARG(Rp % 128 == 0 && Rp >= R, "ix_attn_split_f32: Rp=%d must be R=%d rounded up to 128", Rp, R);
-    IX_CHECK_ARG(ld % 4 == 0 && off % 4 == 0 && ((uintptr_t)x & 15) == 0, "ix_attn_split_f32: rows must be 16-byte aligned");
-    const int64_t plane = (int64_t)n * H * Rp * hd;
-    dim3 grid(Rp / 32, n * H);
-    if (hd == 64)
-        hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, stream, x, (unsigned short*)row_planes, row_unscale,
-                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane, tr_form);
-    else
-        hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, stream, x, (unsigned short*)row_planes, row_unscale,
-                           (unsigned short*)tr_planes, R, Rp, ld, off, H, plane, tr_form);
-    IX_CHECK_LAUNCH("ix_attn_split_f32");
-    return IX_OK;
+    return fl_split_launch("ix_attn_split_f32", 1, &x, &row_planes, &row_unscale, &tr_planes, tr_form, n, &R, &Rp, &ld, &off, H, hd,
+                           stream);
+}
+
+// the same for up to three operands of one attention call in ONE launch (arrays of `count` entries)
+extern "C" int ix_attn_split_multi_f32(int count, const float* const* x, void* const* row_planes, float* const* row_unscale,
+                                       void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
+                                       const int* off, int H, int hd, hipStream_t stream) {
+    if (n <= 0 || count <= 0) return IX_OK;
+    IX_CHECK_ARG(x && row_planes && row_unscale && tr_planes && R && Rp && ld && off, "ix_attn_split_multi_f32: null array");
+    return fl_split_launch("ix_attn_split_multi_f32", count, x, row_planes, row_unscale, tr_planes, tr_form, n, R, Rp, ld, off, H, hd,
+                           stream);
 }
 
 // additive key bias [n][Sp]: 0 for a valid key, -inf for a padded (mask != 0) key and for the tail S..Sp

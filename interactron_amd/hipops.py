@@ -702,6 +702,27 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
     return AttnPlanes(rowp, us, trp, form)
 
 
+def attn_split_multi(ops, n, H, hd, tr_form=None):
+    """attn_split for up to three operands of one attention call in ONE launch.  ops: [(x, R, ld, off, row, tr), ...]."""
+    form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
+    cnt = len(ops)
+    xs, rows, uss, trs = [], [], [], []
+    for x, R, ld, off, row, tr in ops:
+        x = _req(x, "attention operand")
+        Rp, dev = _pad128(R), x.device
+        xs.append(x)
+        rows.append(torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if row else None)
+        uss.append(torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=dev) if row or (tr and form == 1) else None)
+        trs.append(None if not tr else torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if form == 1 else
+                   torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev))
+    ptr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() if t is not None else None for t in ts])
+    ints = lambda vs: (ctypes.c_int * cnt)(*vs)
+    _chk(_L().ix_attn_split_multi_f32(cnt, ptr(xs), ptr(rows), ptr(uss), ptr(trs), form, n, ints([o[1] for o in ops]),
+                                      ints([_pad128(o[1]) for o in ops]), (ctypes.c_int64 * cnt)(*[o[2] for o in ops]),
+                                      ints([o[3] for o in ops]), H, hd, _stream()), "ix_attn_split_multi_f32")
+    return [AttnPlanes(r, u, t, form) for r, u, t in zip(rows, uss, trs)]
+
+
 _bias_cache = {}
 _capture = [None]   # capture-local cache of additive key biases while a HIP-graph capture is running
 
@@ -776,9 +797,9 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
     fp8 = dtype == "fp8"
     pl = {"bias": attn_bias(mask, g.n, g.S, dev)}
     if need_backward or not fp8:
-        pl["q"] = attn_split(q, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr=need_backward)
-        pl["k"] = attn_split(k, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr=need_backward)
-        pl["v"] = attn_split(v, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, row=need_backward)
+        pl["q"], pl["k"], pl["v"] = attn_split_multi([(q, g.L, g.q_ld, g.q_off, True, need_backward),
+                                                      (k, g.S, g.k_ld, g.k_off, True, need_backward),
+                                                      (v, g.S, g.v_ld, g.v_off, need_backward, True)], g.n, g.heads, g.hd)
     Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
     out = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
     lse = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)   # (rows L..Lp come back as +inf: P = 0 there)
@@ -889,9 +910,8 @@ class FlashAttentionBwd(Function):
             hv = hq
         else:
             hv = _req(hv.contiguous()) if hv is not None else zeros(v)
-        hqp = attn_split(hq, g.n, g.L, g.q_ld, g.q_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
-        hkp = attn_split(hk, g.n, g.S, g.k_ld, g.k_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
-        hvp = attn_split(hv, g.n, g.S, g.v_ld, g.v_off, g.heads, g.hd, tr_form=pl["q"].tr_form)
+        hqp, hkp, hvp = attn_split_multi([(hq, g.L, g.q_ld, g.q_off, True, True), (hk, g.S, g.k_ld, g.k_off, True, True),
+                                          (hv, g.S, g.v_ld, g.v_off, True, True)], g.n, g.heads, g.hd, tr_form=pl["q"].tr_form)
         dq, dk, dv = _grad_buffers(g, q, k, v, ctx.same_qk)
         ddo = torch.empty(g.n, g.L, E, dtype=torch.float32, device=dev)
         need = ctypes.c_size_t()
