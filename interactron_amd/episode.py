@@ -344,10 +344,11 @@ class _Adaptive(_EpisodeModel):
         st.c_grads = torch.autograd.grad(ops.Dot.apply(det_rows, _loss_weights(E, st.frames.device)), st.c_params, allow_unused=True)
         st.mark("7 first-order backward")
 
-    def _seg_d(self, st):
-        """.grad += the first-order branch's gradients (one multi-tensor launch; a parameter without a .grad gets the tensor)"""
+    @staticmethod
+    def _accumulate(params, grads):
+        """.grad += grads in one multi-tensor launch (a parameter without a .grad gets the tensor)"""
         dst, src = [], []
-        for p, g in zip(st.c_params, st.c_grads):
+        for p, g in zip(params, grads):
             if g is None:
                 continue
             if p.grad is None:
@@ -356,6 +357,10 @@ class _Adaptive(_EpisodeModel):
                 dst.append(p.grad)
                 src.append(g)
         ops.accumulate_multi(dst, src)
+
+    def _seg_d(self, st):
+        """.grad += the first-order branch's gradients"""
+        self._accumulate(st.c_params, st.c_grads)
 
     def _seg_b(self, st):
         E = st.E
@@ -368,8 +373,11 @@ class _Adaptive(_EpisodeModel):
             st.path_ce = path_ce.detach()
         # (the supervisor backward ends in the fusion parameters and the in_proj blocks; nothing keeps a gradient of the
         #  per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
+        # gradients as tensors + ONE multi-tensor accumulation into .grad (torch.autograd.backward would run one AccumulateGrad
+        # add_ per parameter: ~110 launches per chunk in a step whose small-batch form is bound by its launch count)
         with ops.skip_param_grads(frozenset(id(t) for t in st.dtheta)):
-            torch.autograd.backward(total, inputs=self._targets2)
+            grads = torch.autograd.grad(total, self._targets2, allow_unused=True)
+        self._accumulate(self._targets2, grads)
         st.sup_rows = st.sup_rows.detach()
         st.mark("8 second-order backward")
 

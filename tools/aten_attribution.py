@@ -58,7 +58,13 @@ for ev in prof.events():
         if ev.stack:
             site = "(autograd engine)" if any("backward" in f or "autograd" in f for f in ev.stack) else ev.stack[0][-60:]
         else:
-            site = "(no stack: autograd engine thread)"
+            # autograd engine thread: name the node being evaluated (the enclosing "autograd::engine::evaluate_function: X")
+            par, site = ev.cpu_parent, "(no stack: autograd engine thread)"
+            while par is not None:
+                if "evaluate_function" in par.name or par.name.endswith("Backward") or "AccumulateGrad" in par.name:
+                    site = "engine: " + par.name.split("evaluate_function: ")[-1]
+                    break
+                par = par.cpu_parent
     shapes = str([s for s in (ev.input_shapes or []) if s])[:70]
     agg[(ev.name, shapes, site)][0] += t
     agg[(ev.name, shapes, site)][1] += 1
