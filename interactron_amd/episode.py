@@ -164,7 +164,9 @@ class _Adaptive(_EpisodeModel):
         ptrs += [0 if t.grad is None else t.grad.data_ptr() for t in self.parameters()]
         folds = [m._fold for m in self.detector.modules() if getattr(m, "_fold", None) is not None]
         ptrs += [t.data_ptr() for f in folds for t in f[1]]
-        return hash(tuple(ptrs)), folds
+        # ... and the kernel forms a capture bakes in (the tests switch them at run time: a graph must not replay the other form)
+        forms = (ops.FLASH_TR, ops.ATTENTION_IMPL, ops.ATTENTION_DTYPE, ops.contraction_form())
+        return hash((tuple(ptrs), forms)), folds
 
     def invalidate_graphs(self):
         """Drop every captured graph (weights were reloaded / moved); the next call captures afresh."""

@@ -702,6 +702,14 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
     return AttnPlanes(rowp, us, trp, form)
 
 
+def contraction_form():
+    """1 = fp16x3 form of the 12-wave contraction kernel, 0 = bf16x6 (ix_gemm_set_x3 / IX_GEMM_KERNEL)"""
+    lib = _L()
+    cur = lib.ix_gemm_set_x3(1)
+    lib.ix_gemm_set_x3(cur)
+    return cur
+
+
 def attn_split_multi(ops, n, H, hd, tr_form=None):
     """attn_split for up to three operands of one attention call in ONE launch.  ops: [(x, R, ld, off, row, tr), ...]."""
     form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
