@@ -284,3 +284,31 @@ def test_path_storage_world_size_2_gloo_equals_single_process(chunk):
             assert gi == g and lab == per_batch[bi][g], (bi, g, lab, per_batch[bi][g])
     assert set(out[0][1]) == set(out[1][1]) == set(storage)   # every rank holds every root's trie
     assert out[0][1] == out[1][1]
+
+
+def test_reference_matching_replays_call_by_call_when_ordered(lib):
+    """tests/helpers.ReferenceMatching: with two recorded assignments of ONE image that tie exactly (the 128 x 160 data-parallel
+    fixture has such a pair), the default mode hands out the cheapest recorded candidate -- the same one both times -- while
+    ordered=True replays the recording call by call; a recorded assignment that is not optimal is refused either way."""
+    import pytest as _pt
+    from interactron_amd import criterion as cr
+    from tests.helpers import ReferenceMatching
+    cost = torch.tensor([[1.0, 5.0], [1.0, 5.0], [9.0, 2.0]])           # queries 0 and 1 tie for target 0
+    tgt = {"labels": torch.tensor([3, 4]), "boxes": torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.3, 0.3, 0.1, 0.1]])}
+    a = (torch.tensor([0, 2]), torch.tensor([0, 1]))
+    b = (torch.tensor([1, 2]), torch.tensor([0, 1]))
+    from tests.helpers import image_key
+    recorded = {image_key(tgt): [b, a]}
+    m = cr.HungarianMatcher()
+    with ReferenceMatching(recorded, max_flip_share=1.0) as rm:
+        first = m.assign([cost], [tgt])[0]
+        second = m.assign([cost], [tgt])[0]
+    assert torch.equal(first[0], second[0])                               # cheapest candidate, twice the same
+    with ReferenceMatching(recorded, max_flip_share=1.0, ordered=True):
+        first = m.assign([cost], [tgt])[0]
+        second = m.assign([cost], [tgt])[0]
+    assert torch.equal(first[0], b[0]) and torch.equal(second[0], a[0])   # call by call
+    bad = {image_key(tgt): [(torch.tensor([0, 1]), torch.tensor([0, 1]))]}   # costs 6, the optimum 3
+    with _pt.raises(AssertionError):
+        with ReferenceMatching(bad, ordered=True):
+            m.assign([cost], [tgt])
