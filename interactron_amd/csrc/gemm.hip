@@ -422,6 +422,9 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             else        // 4 consecutive rows at k = 4*(tid&7)+i: a wave instruction reads 8 k-rows x 128 B
                 off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
             off = valid ? off * 4 : 0x7ffffff0;
+#ifdef X3_DIAG_NOLOAD   // diagnostic build: every request goes out of range (returns zeros without touching memory)
+            off = 0x7ffffff0;
+#endif
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
@@ -542,6 +545,21 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                                              int* __restrict__ expo) const {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) u32x2 lds_u2;
+#ifdef X3_DIAG_NOCONV   // diagnostic build: raw bits into the planes, no maximum / exponent / conversion work (wrong numbers)
+        if ((tid & 63) == 0) *expo = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int row = KC ? row_of(tid, i) : (tid >> 3) * 4 + i;
+            unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
+            u32x2 ph, pl;
+            ph.x = __float_as_uint(v[i].x) & 0x3bff3bffu; ph.y = __float_as_uint(v[i].y) & 0x3bff3bffu;
+            pl.x = __float_as_uint(v[i].z) & 0x3bff3bffu; pl.y = __float_as_uint(v[i].w) & 0x3bff3bffu;
+            *(lds_u2*)(dst) = ph;
+            *(lds_u2*)(dst + PLANE) = pl;
+        }
+        (void)k0; (void)kmax; (void)erun;
+        return;
+#endif
         float e[NI][4];
         float mx = 0.f;
         const bool tail = k0 + X6_BK > kmax;
@@ -1637,11 +1655,18 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
 #define X3Q_SB __builtin_amdgcn_sched_barrier(0);
     // one k-slice on (A0C, al, B0C, bl); meanwhile the next slice's fragments are fetched: the h planes into (A0N, B0N),
     // the l planes in place as soon as their only product of the slice has issued
+#ifdef X3_DIAG_NOMMA   // diagnostic build (tools/gemm_x3_diag.py): one of the three terms (wrong numbers): the consumers' MFMA cost
+#define X3Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                     \
+    X3Q_LDA(A0N, 0, NBASE, NS) X3Q_LDB(B0N, 0, NBASE, NS) X3Q_SB                                                     \
+    X3Q_LDA(al, 1, NBASE, NS) X3Q_SB X3Q_LDB(bl, 1, NBASE, NS) X3Q_SB                                                \
+    X3Q_MM(A0C, B0C) X3Q_SB
+#else
 #define X3Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                     \
     X3Q_LDA(A0N, 0, NBASE, NS) X3Q_LDB(B0N, 0, NBASE, NS) X3Q_SB                                                     \
     X3Q_MM(al, B0C) X3Q_SB X3Q_LDA(al, 1, NBASE, NS) X3Q_SB                                                          \
     X3Q_MM(A0C, bl) X3Q_SB X3Q_LDB(bl, 1, NBASE, NS) X3Q_SB                                                          \
     X3Q_MM(A0C, B0C) X3Q_SB
+#endif
     // exponents of the image in LDS buffer B_ (wave-uniform values -> scalar registers)
 #define X3Q_EXPO(B_)                                                                                                 \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) eA[i] = __builtin_amdgcn_readfirstlane(expo[B_][wm / 32 + i]);    \
