@@ -962,14 +962,28 @@ extern "C" int ix_diag_tile_fill(float* C, int M, int N, int64_t ldc, int batch,
 // (vmcnt(0)): in the persistent kernel that would make the consumers sit out the HBM acknowledgement of the C tile
 // they have just stored before they may join the next item's first barrier.  Global memory is never used to
 // communicate inside the workgroup, so only the LDS operations have to have completed.
+#ifdef X3_DIAG_HALFBAR   // diagnostic build: every second barrier of a wave is skipped (RACES, wrong numbers): what the
+__device__ __forceinline__ void x6_lds_barrier(int& bc) {   // synchronisation of a K step costs (tools/gemm_x3_diag.py)
+    if ((bc++ & 1) == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+}
+#define x6_lds_barrier() x6_lds_barrier(ix_bc_)
+#define X6_BC_DECL int ix_bc_ = 0;
+#else
 __device__ __forceinline__ void x6_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+#define X6_BC_DECL
+#endif
 
 template <int BN, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(GemmArgs p, int total_items) {
+    X6_BC_DECL
     constexpr int BM = X6_BT, BK = X6_BK;
     constexpr int PLANE_A = BM * X6_ROWB, PLANE_B = BN * X6_ROWB, BUF = 3 * (PLANE_A + PLANE_B);
     constexpr int WM = BN >= 64 ? 64 : 32, WN = BN >= 64 ? BN / 2 : 32, TM = WM / 32, TN = WN / 32;
@@ -1226,6 +1240,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
     static_assert(G == 0 || (G == 1 && KC && !IS_B) || ((G == 2 || G == 3) && !KC && IS_B), "gather mode vs operand layout");
     SplitLoader<BT, KC, SWZ, X3> s0, s1, s2;
+    X6_BC_DECL
 #ifdef X6_DIAG_TIMING
     const int lane = pt & 63, wave = IS_B ? 100 : 4 + (pt >> 6);   // (stamps: the first A-producer wave)
     int dbgn = 0;
@@ -1344,6 +1359,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 // (four waves per SIMD, 128 registers each): two MFMA-issuing waves per SIMD.
 template <int BN, bool A_KC, bool B_KC, bool DEFER, int NC = 4, int GA = 0, int GB = 0>
 __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(GemmArgs p, int total_items) {
+    X6_BC_DECL
     static_assert(NC == 4 || (NC == 8 && !DEFER && BN >= 64), "consumer wave count");
     constexpr int BM = X6_BT;
     constexpr int ROWB = DEFER ? 64 : X6_ROWB;
@@ -1643,6 +1659,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     const int lrow = lane >> 5, lcol = lane & 31;
     const int ko0 = lrow * 16, ko1 = (2 + lrow) * 16;
     x3_f16x8 ahx[TM], ahy[TM], al[TM], bhx[TN], bhy[TN], bl[TN];
+    X6_BC_DECL
 #define X3Q_LDA(DST, PL, BASE, S)                                                                                    \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) DST[i] = *reinterpret_cast<const x3_f16x8*>(                      \
         (BASE) + (PL) * PLANE_A + (wm + i * 32 + lcol) * ROWB + ((S) ? ko1 : ko0));
