@@ -129,6 +129,20 @@ int ix_nhwc_to_nchw_f32(const float* x, float* y, int n, int64_t HW, int C, ix_s
 /* ---- FrozenBatchNorm2d (backbone.py:44-54) ---------------------------------------------------------------- */
 int ix_bn_fold_f32(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* shift,
                    int C, float eps, ix_stream_t stream);
+/* Contraction + frozen-BN affine (+ residual) (+ ReLU) as one launch where the kernel can take it:
+ *   C[b][m][n] = [relu]((A B)[b][m][n] * scale[n] + shift[n] (+ residual[b][m][n])),  C dense [batch_outer][M][N].
+ * Reference: FrozenBatchNorm2d behind every backbone convolution (models/detr_models/backbone.py:19-54) and torchvision's
+ * Bottleneck tail `out += identity; out = relu(out)`.  A split-K launch applies it in its ordered reduction (one launch
+ * fewer); after an unsplit launch the library runs ix_channel_affine_f32 on C -- the same result.
+ * ix_gemm_bn_act_f32: operands as ix_gemm_f32_ws (one batch level).  ix_conv_gemm_bn_act_f32: kind 0 of ix_conv_gemm_f32.
+ * Workspace sizes: ix_workspace_bytes_gemm_f32 / ix_workspace_bytes_conv_gemm_f32 of the same problem. */
+int ix_gemm_epilogue_stats(int64_t* in_reduction, int64_t* separate, int reset); /* where the affine of the fused calls ran */
+int ix_gemm_bn_act_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
+                       int64_t ldb, int batch_outer, int64_t sAo, int64_t sBo, const float* scale, const float* shift,
+                       const float* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_conv_gemm_bn_act_f32(const float* x, const float* w, float* y, int groups, int imgs, int H, int W, int Cin, int OH, int OW,
+                            int Cout, int KH, int KW, int stride, int pad, int dil, const float* scale, const float* shift,
+                            const float* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);
 int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
                           int64_t n, int C, int relu, ix_stream_t stream);
 

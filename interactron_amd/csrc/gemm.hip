@@ -2262,10 +2262,14 @@ static size_t splitk_plane_bytes(int split, int nbatch, int batch_outer, int M, 
 // Deterministic split-K: the s-th split of a contraction writes its partial tile sums into plane s of a caller-provided
 // workspace with plain stores; this kernel adds the planes IN ORDER (s = 0, 1, ...) into C.  Two runs of one binary give the
 // same bits (the fp32 atomics this replaces rounded in arrival order).  blockIdx.y == nbatch: the partial row sums.
+struct SplitEpi {   // fused BN affine (+ residual at C's own index) (+ ReLU) of the reduction; scale == null: none
+    const float *scale, *shift, *res;
+    int relu;
+};
 __global__ void splitk_reduce_kernel(const float* __restrict__ planes, float* __restrict__ C, int M, int N, int64_t ldc,
                                      int64_t sCo, int64_t sCi, int batch_inner, int nbatch, int split, int64_t sSplit, int vec,
                                      const float* __restrict__ rs_planes, float* __restrict__ rowsum, int64_t rowsum_stride,
-                                     int64_t sSplitRowsum, int batch_outer) {
+                                     int64_t sSplitRowsum, int batch_outer, SplitEpi ep) {
     const int zb = blockIdx.y;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (zb == nbatch) {
@@ -2279,6 +2283,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ planes, float* __
     }
     const float* src = planes + (int64_t)zb * M * N;
     float* c = C + (zb / batch_inner) * sCo + (zb % batch_inner) * sCi;
+    const float* er = ep.res ? ep.res + (c - C) : nullptr;
     if (vec) {
         const int N4 = N >> 2;
         const int64_t total = (int64_t)M * N4;
@@ -2288,14 +2293,31 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ planes, float* __
                 const float4 u = reinterpret_cast<const float4*>(src + s * sSplit)[i];
                 v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
             }
-            *reinterpret_cast<float4*>(c + (i / N4) * ldc + (i % N4) * 4) = v;
+            const int64_t o = (i / N4) * ldc + (i % N4) * 4;
+            if (ep.scale) {
+                const int col = (int)(i % N4) * 4;
+                const float4 sc = *reinterpret_cast<const float4*>(ep.scale + col), sh = *reinterpret_cast<const float4*>(ep.shift + col);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (er) {
+                    const float4 rr = *reinterpret_cast<const float4*>(er + o);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (ep.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            }
+            *reinterpret_cast<float4*>(c + o) = v;
         }
     } else {
         const int64_t total = (int64_t)M * N;
         for (int64_t i = t0; i < total; i += gs) {
             float v = src[i];
             for (int s = 1; s < split; ++s) v += src[s * sSplit + i];
-            c[(i / N) * ldc + (i % N)] = v;
+            const int64_t o = (i / N) * ldc + (i % N);
+            if (ep.scale) {
+                v = v * ep.scale[i % N] + ep.shift[i % N];
+                if (er) v += er[o];
+                if (ep.relu) v = fmaxf(v, 0.f);
+            }
+            c[o] = v;
         }
     }
 }
@@ -2350,13 +2372,45 @@ static int splitk_begin(GemmArgs& a, int nbatch, int batch_outer, bool rowsum_in
     return IX_OK;
 }
 static void splitk_finish(const GemmArgs& a, int nbatch, int batch_outer, bool rowsum_in_kernel, const SplitReal& real,
-                          hipStream_t stream) {
+                          hipStream_t stream, SplitEpi ep = SplitEpi{nullptr, nullptr, nullptr, 0}) {
     if (!real.planes) return;
     const int vec = (a.N % 4 == 0) && real.c_vec;
     dim3 grid(ix_grid_1d((int64_t)a.M * a.N / (vec ? 4 : 1), 256), nbatch + (rowsum_in_kernel ? 1 : 0));
     hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, stream, a.C, real.C, a.M, a.N, real.ldc, real.sCo, real.sCi,
                        a.batch_inner, nbatch, a.split_k, a.sSplit, vec, rowsum_in_kernel ? a.rowsum : nullptr, real.rowsum,
-                       real.rowsum_stride, a.sSplitRowsum, batch_outer);
+                       real.rowsum_stride, a.sSplitRowsum, batch_outer, ep);
+}
+
+// Fused epilogue request of the NEXT contraction issued by this thread (armed by ix_gemm_bn_act_f32 /
+// ix_conv_gemm_bn_act_f32 around their call of the plain entry point).  A split-K launch applies it in its ordered
+// reduction (any kernel family) and sets `applied`; otherwise the wrapper runs ix_channel_affine_f32 on the output
+// afterwards.  (The affine in the 12-wave kernel's own store was built and measured in rounds 2 and 3: the extra epilogue
+// code costs EVERY contraction 3-5 %, armed or not -- 90.0 -> 94.8 ms on the 24 heaviest shapes -- more than the separate
+// pass it saves on large outputs; on small, launch-bound problems the plan splits K anyway.)
+struct EpiReq {
+    const float *scale, *shift, *res;
+    int relu, applied;
+};
+static thread_local EpiReq g_epi = {nullptr, nullptr, nullptr, 0, 0};
+static int64_t g_epi_count[2] = {0, 0};   // fused calls whose affine ran: in the split-K reduction | as a separate launch
+extern "C" int ix_gemm_epilogue_stats(int64_t* in_reduction, int64_t* separate, int reset) {
+    if (in_reduction) *in_reduction = g_epi_count[0];
+    if (separate) *separate = g_epi_count[1];
+    if (reset) g_epi_count[0] = g_epi_count[1] = 0;
+    return IX_OK;
+}
+
+// called once the plan is known and splitk_begin has run: a split-K launch takes the epilogue in its ordered reduction
+static SplitEpi epi_place(const GemmArgs& a, const SplitReal& real) {
+    SplitEpi ep = {nullptr, nullptr, nullptr, 0};
+    if (!g_epi.scale) return ep;
+    const bool al = aligned16(g_epi.scale) && aligned16(g_epi.shift) && (!g_epi.res || aligned16(g_epi.res)) && a.N % 4 == 0;
+    if (al && !a.atomic && a.split_k > 1 && real.planes) {
+        ep.scale = g_epi.scale; ep.shift = g_epi.shift; ep.res = g_epi.res; ep.relu = g_epi.relu;
+        g_epi.applied = 1;
+        ++g_epi_count[0];
+    }
+    return ep;
 }
 
 // Which contractions ix_gemm_f32_ws can run on the pre-split fp16x3 kernel (gemm_x3.hip): 16-byte-aligned operands, one
@@ -2554,6 +2608,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     g_flops += 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
     g_launches += 1;
     const bool use_x3 = use_x6 && bn == 128 && x3k_enabled() && g_x6 == 3;
+    const SplitEpi sep = epi_place(a, real);
     if (g_prof_on) {
         ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x3 ? 1129 : (use_x6 ? 1128 : bm), split};
         r.flops = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
@@ -2583,7 +2638,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         launch_cfg<128, 128, 32>(a, a_kcontig, b_kcontig, grid, stream);
     else
         launch_cfg<64, 64, 64>(a, a_kcontig, b_kcontig, grid, stream);
-    splitk_finish(a, nbatch, batch_outer, rowsum_in_kernel, real, stream);
+    splitk_finish(a, nbatch, batch_outer, rowsum_in_kernel, real, stream, sep);
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_gemm_f32");
     return IX_OK;
@@ -2772,10 +2827,53 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         g_rec.push_back(r);
     }
     prof_mark(stream);
+    const SplitEpi sep = epi_place(a, real);
     if (bn == 128) launch_conv_bn<128>(a, kind, items, stream, conv_x3);
     else launch_conv_bn<64>(a, kind, items, stream);
-    splitk_finish(a, groups, groups, false, real, stream);
+    splitk_finish(a, groups, groups, false, real, stream, sep);
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_conv_gemm_f32");
     return IX_OK;
+}
+
+// ---- contraction + frozen-BN affine (+ residual) (+ ReLU) as ONE launch where the kernel can take it -------------------------
+// y = [relu]((A B) * scale[n] + shift[n] (+ residual[m][n])): reference models/detr_models/backbone.py:19-54 (FrozenBatchNorm2d
+// behind every backbone convolution) with torchvision's Bottleneck tail `out += identity; out = relu(out)`.  A split-K
+// launch applies it in its ordered reduction (one launch fewer where launches are what a step costs); an unsplit launch is
+// followed by the affine pass as its own launch (ix_channel_affine_f32) -- the same result.  C: dense [batch][M][N].
+extern "C" int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
+                                     int64_t n, int C, int relu, hipStream_t stream);
+static int epi_finish(int rc, float* C, int64_t total, int N, const float* scale, const float* shift, const float* residual,
+                      int relu, hipStream_t stream) {
+    const int applied = g_epi.applied;
+    g_epi = EpiReq{nullptr, nullptr, nullptr, 0, 0};
+    if (rc != IX_OK || applied) return rc;
+    ++g_epi_count[1];
+    return ix_channel_affine_f32(C, scale, shift, residual, C, total, N, relu, stream);
+}
+
+extern "C" int ix_gemm_bn_act_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig,
+                                  int64_t lda, int64_t ldb, int batch_outer, int64_t sAo, int64_t sBo, const float* scale,
+                                  const float* shift, const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                                  hipStream_t stream) {
+    IX_CHECK_ARG(scale && shift, "ix_gemm_bn_act_f32: null scale / shift");
+    IX_CHECK_ARG(N % 4 == 0 && aligned16(C) && aligned16(scale) && aligned16(shift) && (!residual || aligned16(residual)),
+                 "ix_gemm_bn_act_f32: N %% 4 == 0 and 16-byte aligned C / scale / shift / residual needed");
+    g_epi = EpiReq{scale, shift, residual, relu, 0};
+    const int rc = ix_gemm_f32_ws(A, B, C, nullptr, M, N, K, a_kcontig, b_kcontig, lda, ldb, N, batch_outer, 1, sAo, 0, sBo, 0,
+                                  (int64_t)M * N, 0, 0, 1.f, 0, 0, workspace, workspace_bytes, stream);
+    return epi_finish(rc, C, (int64_t)batch_outer * M * N, N, scale, shift, residual, relu, stream);
+}
+
+extern "C" int ix_conv_gemm_bn_act_f32(const float* x, const float* w, float* y, int groups, int imgs, int H, int W, int Cin,
+                                       int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, const float* scale,
+                                       const float* shift, const float* residual, int relu, void* workspace,
+                                       size_t workspace_bytes, hipStream_t stream) {
+    IX_CHECK_ARG(scale && shift, "ix_conv_gemm_bn_act_f32: null scale / shift");
+    IX_CHECK_ARG(aligned16(scale) && aligned16(shift) && (!residual || aligned16(residual)),
+                 "ix_conv_gemm_bn_act_f32: scale / shift / residual must be 16-byte aligned");
+    g_epi = EpiReq{scale, shift, residual, relu, 0};
+    const int rc = ix_conv_gemm_f32(0, x, w, y, groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil, workspace,
+                                    workspace_bytes, stream);
+    return epi_finish(rc, y, (int64_t)groups * imgs * OH * OW * Cout, Cout, scale, shift, residual, relu, stream);
 }

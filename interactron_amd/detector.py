@@ -50,10 +50,16 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         idt = x
         if self.downsample is not None:
-            idt = self.downsample[1](self.downsample[0](x))
-        y = self.bn1(self.conv1(x), relu=True)
-        y = self.bn2(self.conv2(y), relu=True)
-        return self.bn3(self.conv3(y), residual=idt, relu=True)
+            idt = _conv_bn(self.downsample[0], self.downsample[1], x)
+        y = _conv_bn(self.conv1, self.bn1, x, relu=True)
+        y = _conv_bn(self.conv2, self.bn2, y, relu=True)
+        return _conv_bn(self.conv3, self.bn3, y, residual=idt, relu=True)
+
+
+def _conv_bn(conv, bn, x, residual=None, relu=False):
+    """bn(conv(x)) (+ residual) (+ ReLU) with the frozen-BN affine riding on the convolution's contraction (hipops.conv2d_nhwc_bn_act)"""
+    scale, shift = bn.folded()
+    return ops.conv2d_nhwc_bn_act(x, conv.weight, scale, shift, residual, relu, conv.stride, conv.padding, conv.dilation)
 
 
 def _make_layer(inplanes, planes, blocks, stride, first_dilation, dilation):

@@ -1396,13 +1396,74 @@ class BnAct(Function):
     @staticmethod
     def backward(ctx, g):
         scale, y = ctx.saved_tensors
-        if ctx.relu and not ctx.has_res:   # one pass instead of relu-backward + channel scale
-            return (ReluBwdChannelScale.call(g, y, scale) if ctx.needs_input_grad[0] else None), None, None, None, None
-        if ctx.relu:
-            g = ReluBwd.call(g, y)
-        gx = ChannelScale.call(g, scale) if ctx.needs_input_grad[0] else None
-        gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        gx, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0], ctx.needs_input_grad[3])
         return gx, None, None, gres, None
+
+
+def _bn_act_backward(g, y, scale, relu, has_res, need_x, need_res):
+    """(gradient of the pre-affine tensor, gradient of the residual) of y = [relu](z * scale + shift (+ res)) -- BnAct.backward's
+    arithmetic on differentiable nodes, shared with the fused contraction + affine Functions"""
+    g = g.contiguous()
+    if relu and not has_res:   # one pass instead of relu-backward + channel scale
+        return (ReluBwdChannelScale.call(g, y, scale) if need_x else None), None
+    if relu:
+        g = ReluBwd.call(g, y)
+    return (ChannelScale.call(g, scale) if need_x else None), (g if (has_res and need_res) else None)
+
+
+# IX_FUSE_CONV_BN: "1" = backbone convolutions carry their frozen-BN affine (+ residual) (+ ReLU) on the contraction call
+# (ix_gemm_bn_act_f32 / ix_conv_gemm_bn_act_f32) instead of a separate elementwise launch; "0" = separate launches
+FUSE_CONV_BN = os.environ.get("IX_FUSE_CONV_BN", "1") == "1"
+
+
+class GemmBnAct(Function):
+    """y = [relu]((A B) * scale[n] + shift[n] (+ residual)) for the plain row-major product of Gemm (1 x 1 convolutions);
+    backward = BnAct's backward followed by Gemm's (all differentiable nodes: closed under the MAML double backward)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale, shift, residual, relu, sp):
+        ctx.a_key, ctx.b_key = _param_key(a), _param_key(b)
+        a, b, scale, shift = _req(a, "gemm A"), _req(b, "gemm B"), _req(scale), _req(shift)
+        if residual is not None:
+            residual = _req(residual)
+        assert sp.bi == 1 and sp.alpha == 1.0 and sp.C.offset == 0 and sp.C.ld == sp.N and not sp.C.trans
+        assert sp.A.offset == 0 and sp.B.offset == 0 and (sp.bo == 1 or sp.C.so == sp.M * sp.N)
+        out = torch.empty(sp.out_shape, device=a.device, dtype=torch.float32)
+        nws, _ = _gemm_workspace_bytes(a.data_ptr(), b.data_ptr(), sp)
+        ws = _workspace(nws, a.device) if nws else None
+        _chk(_L().ix_gemm_bn_act_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), sp.M, sp.N, sp.K, 0 if sp.A.trans else 1,
+                                     1 if sp.B.trans else 0, sp.A.ld, sp.B.ld, sp.bo, sp.A.so, sp.B.so, scale.data_ptr(),
+                                     shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                     1 if relu else 0, ws.data_ptr() if nws else None, nws, _stream()), "ix_gemm_bn_act_f32")
+        ctx.sp, ctx.relu, ctx.has_res = sp, relu, residual is not None
+        ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
+        ctx.save_for_backward(a, b, scale, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, scale, y = ctx.saved_tensors
+        need_a = ctx.needs_input_grad[0] and not _is_unwanted(ctx.a_key, _unwanted)
+        need_b = ctx.needs_input_grad[1] and not _is_unwanted(ctx.b_key, _unwanted)
+        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, need_a or need_b, ctx.needs_input_grad[4])
+        da = db = None
+        if gz is not None:
+            da, db = _gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, gz, need_a, need_b)
+        return da, db, None, None, gres, None, None
+
+
+def linear_bn_act(x, weight, scale, shift, residual, relu):
+    """[relu](linear(x, weight) * scale + shift (+ residual)) -- `linear` without bias, episode-batched weights included"""
+    if weight.dim() == 3:
+        E, N, K = weight.shape
+        R = x.numel() // (E * K)
+        sp = GemmSpec(R, N, K, E, 1, View(0, K, False, R * K, 0), View(0, K, True, N * K, 0), View(0, N, False, R * N, 0),
+                      tuple(x.shape[:-1]) + (N,), 1.0)
+    else:
+        K, N = x.shape[-1], weight.shape[0]
+        sp = GemmSpec(x.numel() // K, N, K, 1, 1, View(0, K, False, 0, 0), View(0, K, True, 0, 0), View(0, N, False, 0, 0),
+                      tuple(x.shape[:-1]) + (N,), 1.0)
+    return GemmBnAct.call(x, weight, scale, shift, residual, relu, sp)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1560,6 +1621,62 @@ class ConvBwdWeight(Function):
         ddy = ConvFwd.call(x, g, ctx.cg) if ctx.needs_input_grad[0] else None
         dx = ConvBwdData.call(dy, g, ctx.cg) if ctx.needs_input_grad[1] else None
         return ddy, dx, None, None
+
+
+class ConvFwdBnAct(Function):
+    """y = [relu](conv(x, w) * scale[c] + shift[c] (+ residual)): ConvFwd with the frozen-BN affine in the contraction's store"""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, residual, relu, cg):
+        ctx.w_key = _param_key(w)
+        x, w, scale, shift = _req(x, "conv x"), _req(w, "conv weight"), _req(scale), _req(shift)
+        if residual is not None:
+            residual = _req(residual)
+        out = torch.empty((cg.E * cg.imgs, cg.OH, cg.OW, cg.Cout), device=x.device, dtype=torch.float32)
+        nws = _conv_ws.get((0, cg))
+        if nws is None:
+            n = ctypes.c_size_t(0)
+            _chk(_L().ix_workspace_bytes_conv_gemm_f32(0, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW,
+                                                       ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
+            nws = _conv_ws[(0, cg)] = n.value
+        ws = _workspace(nws, x.device) if nws else None
+        _chk(_L().ix_conv_gemm_bn_act_f32(x.data_ptr(), w.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH,
+                                          cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil, scale.data_ptr(),
+                                          shift.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                          1 if relu else 0, ws.data_ptr() if nws else None, nws, _stream()),
+             "ix_conv_gemm_bn_act_f32")
+        ctx.cg, ctx.relu, ctx.has_res = cg, relu, residual is not None
+        ctx.save_for_backward(x, w, scale, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, scale, y = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[1] and not _is_unwanted(ctx.w_key, _unwanted)
+        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0] or need_w, ctx.needs_input_grad[4])
+        dx = dw = None
+        if gz is not None:
+            dx = ConvBwdData.call(gz, w, ctx.cg) if ctx.needs_input_grad[0] else None
+            dw = ConvBwdWeight.call(gz, x, ctx.cg, tuple(w.shape)) if need_w else None
+        return dx, dw, None, None, gres, None, None
+
+
+def conv2d_nhwc_bn_act(x, weight, scale, shift, residual=None, relu=False, stride=1, pad=0, dil=1):
+    """[relu](conv2d_nhwc(x, weight) * scale + shift (+ residual)): one launch where the contraction kernel takes the affine
+    (1 x 1 / stride 1 and implicit-GEMM geometries, output channels % 4 == 0), else the two separate nodes"""
+    n, H, W, C = x.shape
+    batched = weight.dim() == 5
+    Cout, KH, KW = weight.shape[-4], weight.shape[-3], weight.shape[-2]
+    E = weight.shape[0] if batched else 1
+    if FUSE_CONV_BN and Cout % 4 == 0:
+        if KH == 1 and KW == 1 and stride == 1 and pad == 0:
+            wv = weight_view(weight, E, Cout, C) if batched else weight_view(weight, Cout, C)
+            return linear_bn_act(x, wv, scale, shift, residual, relu)
+        g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
+        cg = ConvGemmGeom(E, n // E, H, W, C, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
+        if conv_gemm_supported(cg):
+            return ConvFwdBnAct.call(x, weight, scale, shift, residual, relu, cg)
+    return BnAct.apply(conv2d_nhwc(x, weight, stride, pad, dil), scale, shift, residual, relu)
 
 
 def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):

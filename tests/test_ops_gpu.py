@@ -240,6 +240,68 @@ def test_implicit_gemm_conv(ops, cin, cout, k, stride, pad, dil, hw, n):
                  [rnd(n, hw, hw + 1, cin, seed=6), w5], name="implicit conv, episode-batched")
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw,n,E,res,relu", [
+    (64, 256, 1, 1, 0, 19, 4, 1, True, True),     # bottleneck tail: 1 x 1 + affine + identity + ReLU (plain contraction path)
+    (256, 64, 1, 1, 0, 19, 4, 2, False, True),    # 1 x 1 + affine + ReLU, per-episode weights
+    (64, 128, 3, 1, 1, 19, 2, 1, False, True),    # 3 x 3 (implicit GEMM) + affine + ReLU
+    (128, 256, 1, 2, 0, 15, 2, 2, False, False),  # the stride-2 downsample: affine only, per-episode weights
+    (64, 64, 3, 1, 1, 38, 5, 1, False, True),     # enough pixels for an unsplit launch (affine in the kernel's store)
+    (64, 128, 1, 1, 0, 75, 4, 1, True, True)])    # enough rows for an unsplit plain contraction
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.usefixtures("kernel_form")
+def test_conv_bn_act_rides_on_the_contraction(ops, fused, cin, cout, k, stride, pad, hw, n, E, res, relu):
+    """hipops.conv2d_nhwc_bn_act -- frozen-BN affine (+ residual) (+ ReLU) riding on the contraction (ix_gemm_bn_act_f32 /
+    ix_conv_gemm_bn_act_f32: in the split-K reduction, or the library's own affine launch after an unsplit plan) and as two
+    separate nodes -- against float64, with both gradients, the residual's, and the gradients of those (the MAML double
+    backward)."""
+    old, ops.FUSE_CONV_BN = ops.FUSE_CONV_BN, fused
+    try:
+        scale = (rnd(cout, seed=31).abs() + 0.5).cuda()
+        shift = rnd(cout, seed=32).cuda()
+        oh = (hw + 2 * pad - (k - 1) - 1) // stride + 1
+        ow = (hw + 1 + 2 * pad - (k - 1) - 1) // stride + 1
+        wshape = (E, cout, cin, k, k) if E > 1 else (cout, cin, k, k)
+        inputs = [rnd(n, hw, hw + 1, cin, seed=1), rnd(*wshape, seed=2, scale=(cin * k * k) ** -0.5)]
+        if res:
+            inputs.append(rnd(n, oh, ow, cout, seed=3))
+
+        def ref(x, w, r=None):
+            per = n // E
+            ws = w if E > 1 else w[None]
+            y = torch.cat([F.conv2d(x[e * per:(e + 1) * per].permute(0, 3, 1, 2), ws[e], None, stride, pad) for e in range(E)])
+            y = y.permute(0, 2, 3, 1) * scale.to(y.device, y.dtype) + shift.to(y.device, y.dtype)
+            if r is not None:
+                y = y + r
+            return torch.relu(y) if relu else y
+
+        def hip(x, w, r=None):
+            wl = w.permute(0, 1, 3, 4, 2).contiguous() if E > 1 else w.permute(0, 2, 3, 1).contiguous()
+            return ops.conv2d_nhwc_bn_act(x, wl, scale, shift, r, relu, stride, pad, 1)
+
+        import ctypes
+        lib = ops._L()
+        lib.ix_gemm_epilogue_stats(None, None, 1)
+        check_op(hip, ref, inputs, name="conv + bn + act (%s)" % ("fused" if fused else "separate"))
+        c = [ctypes.c_int64() for _ in range(2)]
+        lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
+        counts = [v.value for v in c]
+        assert (sum(counts) > 0) == fused, counts
+        _EPI_SEEN[0] += counts[0]; _EPI_SEEN[1] += counts[1]
+    finally:
+        ops.FUSE_CONV_BN = old
+
+
+_EPI_SEEN = [0, 0]
+
+
+def test_conv_bn_act_cases_cover_every_place_the_affine_can_run():
+    """(after the parametrised test above) the fused calls must have exercised the split-K reduction and the library's
+    separate launch (unsplit plans) at least once each"""
+    if sum(_EPI_SEEN) == 0:
+        pytest.skip("run together with test_conv_bn_act_rides_on_the_contraction")
+    assert all(v > 0 for v in _EPI_SEEN), _EPI_SEEN
+
+
 def test_stem_conv_and_maxpool(ops):
     x = rnd(2, 3, 37, 41)
     w = rnd(64, 3, 7, 7, scale=0.1)
