@@ -286,20 +286,30 @@ def test_conv_bn_act_rides_on_the_contraction(ops, fused, cin, cout, k, stride, 
         lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
         counts = [v.value for v in c]
         assert (sum(counts) > 0) == fused, counts
-        _EPI_SEEN[0] += counts[0]; _EPI_SEEN[1] += counts[1]
     finally:
         ops.FUSE_CONV_BN = old
 
 
-_EPI_SEEN = [0, 0]
-
-
-def test_conv_bn_act_cases_cover_every_place_the_affine_can_run():
-    """(after the parametrised test above) the fused calls must have exercised the split-K reduction and the library's
-    separate launch (unsplit plans) at least once each"""
-    if sum(_EPI_SEEN) == 0:
-        pytest.skip("run together with test_conv_bn_act_rides_on_the_contraction")
-    assert all(v > 0 for v in _EPI_SEEN), _EPI_SEEN
+def test_conv_bn_act_reaches_both_places_the_affine_can_run(ops):
+    """forward only, a launch-bound and a large geometry: the affine of the first must run inside the split-K reduction, the
+    affine of the second as the library's own launch after an unsplit plan (ix_gemm_epilogue_stats)"""
+    import ctypes
+    lib = ops._L()
+    seen = []
+    for (n, hw, cin, cout, k) in ((2, 19, 256, 64, 1), (16, 75, 64, 256, 1), (2, 19, 64, 64, 3), (16, 75, 64, 64, 3)):
+        x = rnd(n, hw, hw, cin, seed=1).cuda()
+        w = rnd(cout, k, k, cin, seed=2, scale=(cin * k * k) ** -0.5).cuda()
+        scale, shift = (rnd(cout, seed=3).abs() + 0.5).cuda(), rnd(cout, seed=4).cuda()
+        lib.ix_gemm_epilogue_stats(None, None, 1)
+        y = ops.conv2d_nhwc_bn_act(x, w, scale, shift, None, True, 1, k // 2, 1)
+        ref = torch.relu(ops.conv2d_nhwc(x, w, 1, k // 2, 1) * scale + shift)
+        close(y, ref, 1e-6, "fused vs separate")
+        c = [ctypes.c_int64(), ctypes.c_int64()]
+        lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
+        assert c[0].value + c[1].value == 1, (c[0].value, c[1].value)
+        seen.append(c[0].value)
+    assert 1 in seen and 0 in seen, seen   # (a launch-bound plan splits K: in the reduction; a large one: separate launch)
+    assert seen[1] == 0 and seen[3] == 0, seen
 
 
 def test_stem_conv_and_maxpool(ops):
