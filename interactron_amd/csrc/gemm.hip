@@ -2384,9 +2384,10 @@ static void splitk_finish(const GemmArgs& a, int nbatch, int batch_outer, bool r
 // Fused epilogue request of the NEXT contraction issued by this thread (armed by ix_gemm_bn_act_f32 /
 // ix_conv_gemm_bn_act_f32 around their call of the plain entry point).  A split-K launch applies it in its ordered
 // reduction (any kernel family) and sets `applied`; otherwise the wrapper runs ix_channel_affine_f32 on the output
-// afterwards.  (The affine in the 12-wave kernel's own store was built and measured in rounds 2 and 3: the extra epilogue
-// code costs EVERY contraction 3-5 %, armed or not -- 90.0 -> 94.8 ms on the 24 heaviest shapes -- more than the separate
-// pass it saves on large outputs; on small, launch-bound problems the plan splits K anyway.)
+// afterwards.  (The affine in the 12-wave kernel's own store was built and measured in rounds 2 and 3: at 16 episodes the
+// contraction kernels gain 6 ms -- the consumers' store phase is latency-bound and now also reads the residual -- where the
+// separate, bandwidth-efficient affine launches cost 9: step 277.2 -> 278.3 ms, nothing won; on small, launch-bound problems
+// the plan splits K anyway.)
 struct EpiReq {
     const float *scale, *shift, *res;
     int relu, applied;

@@ -24,9 +24,13 @@ for i, (M, N, K, b, akc, bkc, cnt) in enumerate(shapes):
     C = torch.empty(b, M * N, device="cuda")
     lda = K if akc else M
     ldb = K if bkc else N
+    need = ctypes.c_size_t(0)   # as the product calls it: split-K planes in a caller workspace + ordered reduction (no atomics)
+    assert lib.ix_workspace_bytes_gemm_f32(M, N, K, akc, bkc, lda, ldb, b, 1, M * K, K * N, A.data_ptr(), B.data_ptr(), tile_hint,
+                                           split_hint, ctypes.byref(need)) == 0
+    ws = torch.zeros(max(need.value, 65536) // 4 + 4, device="cuda")
     def run():
-        rc = lib.ix_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, akc, bkc, lda, ldb, N, b, 1,
-                             M * K, 0, K * N, 0, M * N, 0, 0, 1.0, tile_hint, split_hint, stream)
+        rc = lib.ix_gemm_f32_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), None, M, N, K, akc, bkc, lda, ldb, N, b, 1,
+                                M * K, 0, K * N, 0, M * N, 0, 0, 1.0, tile_hint, split_hint, ws.data_ptr(), ws.numel() * 4, stream)
         assert rc == 0
     for _ in range(3):
         run()
