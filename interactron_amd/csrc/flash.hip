@@ -385,6 +385,13 @@ struct FlSeg {
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[r_] *= c_;                                                 \
     }
 #define FL_F0 1152921504606846976.f   // 2^60: where a running factor starts
+// LLVM's instruction-group scheduling strategies as a hint at the top of a tile loop (scheduling only): measured per kernel
+// at L = S = 12 755, hd 64 (tools/flash_ab.sh): strategy 0 -7.8 % on the dq / ddO pass and -2.8 % on the forward, +50 % on the
+// statistics pass; strategy 2 (MFMA / exp interleave) -10.8 % on the statistics pass, -4.4 % on dq / ddO; the key-owning
+// passes gain from neither (strategy 1 aborts the compiler).  MODE < 0: none.
+#define FL_IGLP(MODE)                                                  \
+    if ((MODE) == 0) __builtin_amdgcn_iglp_opt(0);                     \
+    else if ((MODE) == 2) __builtin_amdgcn_iglp_opt(2);
 // accumulator-layout output (lane = row of the output tensor, registers = d) -> fp32 rows
 #define FL_STORE_ROWS(ACC, DSTPTR, MUL)                                                                                \
     _Pragma("unroll") for (int db_ = 0; db_ < NDB; ++db_) _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {            \
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
+        FL_IGLP(HD == 64 ? 0 : -1)
         const unsigned char* lds = ldsb[t & 1];
         const int t0 = t * 32;
         // key bias of this lane's 16 keys: register r <-> key t0 + (r & 3) + 8 (r >> 2) + 4 a.  Requested BEFORE the
@@ -891,6 +899,7 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
+        FL_IGLP(HD == 64 ? (STATS ? 2 : 0) : -1)
         unsigned char* lds = ldsq[STATS ? (t & 1) : 0];
         const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
         f32x4 kb[4];
