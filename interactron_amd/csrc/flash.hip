@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(FlashArgs p) {
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        FL_IGLP(HD == 64 ? 0 : -1)
+        FL_IGLP(0)
         const unsigned char* lds = ldsb[t & 1];
         const int t0 = t * 32;
         // key bias of this lane's 16 keys: register r <-> key t0 + (r & 3) + 8 (r >> 2) + 4 a.  Requested BEFORE the
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256, (STATS || HD == 32) ? 2 : 1) void flash_bb_q_k
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
-        FL_IGLP(HD == 64 ? (STATS ? 2 : 0) : -1)
+        FL_IGLP(STATS ? 2 : 0)
         unsigned char* lds = ldsq[STATS ? (t & 1) : 0];
         const int t0 = t * 32, tn = min(t0 + 32, ntiles * 32 - 32);
         f32x4 kb[4];
