@@ -1,47 +1,30 @@
-"""Scalar logger with the reference's TBLogger interface (utils/logging_utils.py:6-41): values are buffered per name and
-their mean is written once per ``log_values()``.  Writes TensorBoard events when tensorboard is importable, and always a
-``scalars.jsonl`` next to them (tensorboard is not installed on the MI355X image)."""
+"""The scalar log the trainers write (`engine/trainers.py`): `add_value(name, x)` accumulates a running sum per name,
+`log_values()` appends one JSON record of the means to `<log_dir>/scalars.jsonl` and starts the next record.
+
+The reference's trainers hand their numbers to a TensorBoard writer (SURVEY §2 "Logging", out of scope: tensorboard is not
+installed on the MI355X image and image dumps are not part of the path); the class keeps that logger's name so
+`set_logger` / `build_trainer` callers read the same, nothing else of it."""
 import json
 import os
-
-import numpy as np
-import torch
 
 
 class TBLogger:
     def __init__(self, log_dir):
         os.makedirs(log_dir, exist_ok=True)
-        self.log_dir = log_dir
-        try:
-            from torch.utils.tensorboard import SummaryWriter
-            self.writer = SummaryWriter(log_dir=log_dir)
-        except Exception:   # tensorboard missing
-            self.writer = None
-        self.scalar_buffer = {}
-        self.img_buffer = {}
-        self.iter_counter = 0
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+        self.record = 0
+        self._sums = {}     # name -> [sum, count]
 
-    def add_value(self, name, value):
-        assert any(isinstance(value, t) for t in [int, float, np.ndarray, np.floating, torch.Tensor]), \
-            "Invalid type {}. Only int, float, np.ndarray and torch.Tensor are accepted".format(type(value))
-        if isinstance(value, torch.Tensor):
-            assert len(value.shape) == 0, "Got tensor of shape {}. Only single value tensors are valid.".format(value.shape)
-            value = value.item()
-        self.scalar_buffer.setdefault(name, []).append(value)
-
-    def add_image(self, name, img):
-        assert isinstance(img, torch.Tensor), "Invalid type {}. Only torch.Tensor are accepted".format(type(img))
-        self.img_buffer[name] = img
+    def add_value(self, name, x):
+        x = float(x)        # python / numpy scalars and 0-d tensors (one D2H copy for a device tensor); anything else raises
+        acc = self._sums.setdefault(name, [0.0, 0])
+        acc[0] += x
+        acc[1] += 1
 
     def log_values(self):
-        means = {name: float(np.mean(values)) for name, values in self.scalar_buffer.items()}
-        with open(os.path.join(self.log_dir, "scalars.jsonl"), "a") as f:
-            f.write(json.dumps({"iter": self.iter_counter, **means}) + "\n")
-        if self.writer is not None:
-            for name, v in means.items():
-                self.writer.add_scalar(name, v, self.iter_counter)
-            for name, value in self.img_buffer.items():
-                self.writer.add_image(name, value, self.iter_counter, dataformats="HWC")
-        self.scalar_buffer = {}
-        self.img_buffer = {}
-        self.iter_counter += 1
+        line = {"iter": self.record}
+        line.update((name, s / n) for name, (s, n) in self._sums.items())
+        with open(self.path, "a") as f:
+            f.write(json.dumps(line) + "\n")
+        self._sums.clear()
+        self.record += 1

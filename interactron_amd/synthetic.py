@@ -152,3 +152,32 @@ def synthetic_episodes(batch, frames=5, height=300, width=300, tag="bench", devi
         data["category_ids"].append(cats)
         data["boxes"].append(boxes)
     return data
+
+
+def evalrun_weight_edit(state_dict, overrides=None, sharpen=8.0, query_gain=4.0, loss_gain=5e-4):
+    """Fixture G18's weight recipe (tests/golden/make_golden_evalrun.py), applied in place to an ``interactron`` state
+    dict on BOTH sides (the imported reference there, this package in tests/test_engine_gpu.py).
+
+    With procedural weights the detector's 50 queries are indistinguishable (their outputs differ by 3e-4 of their
+    magnitude): every query predicts the same arbitrary class and box, one detection per image survives NMS and every AP is
+    zero.  Closed-form part: the decoder's cross-attention query / key projections x `sharpen` and the learned queries
+    x `query_gain` -- attention that actually selects tokens, as in a trained DETR; queries then differ by 5 % -- and the
+    learned-loss head's last layer x `loss_gain`: with procedural weights the learned loss' gradient clips the inner step at
+    +-0.01 on nearly every detector weight, an adaptation that replaces the detector instead of adjusting it.
+    `overrides` (stored IN the fixture, computed there from a calibration pass of the reference): rows of the class head for
+    the dataset's categories and the last layer of the box head re-centred on the mean query so that classes, scores and boxes
+    spread over the queries, and the policy head's bias minus its mean output so that the chosen move depends on the frames.
+    Everything downstream -- adaptation step, boxes, scores, NMS survivors, matching, policy -- is what the networks
+    compute.  An override is a full tensor or ``{"rows": LongTensor, "values": Tensor}``."""
+    for k, v in state_dict.items():
+        if ".decoder.layers." in k and k.endswith("multihead_attn.in_proj_weight"):
+            v[:2 * v.shape[1]] *= sharpen
+    state_dict["detector.query_embed.weight"] *= query_gain
+    state_dict["fusion.loss_decoder.layers.2.weight"] *= loss_gain
+    state_dict["fusion.loss_decoder.layers.2.bias"] *= loss_gain
+    for k, o in (overrides or {}).items():
+        if isinstance(o, dict):
+            state_dict[k][o["rows"].to(state_dict[k].device)] = o["values"].to(state_dict[k])
+        else:
+            state_dict[k].copy_(o)
+    return state_dict

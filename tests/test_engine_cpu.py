@@ -16,6 +16,8 @@ from interactron_amd.datasets import InteractiveDataset, SequenceDataset, train_
 from interactron_amd.engine import metrics
 from interactron_amd.storage import collate_fn
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def test_g15_ap_metric_matches_reference(golden):
     G = golden("golden_eval.pt")
@@ -235,3 +237,73 @@ def test_episode_batch_loader_shards_the_decode_not_the_batch():
             elif shuffle:
                 assert sorted(sum(first, [])) == sorted(sum([w["episode_ids"].tolist() for w, _ in full], []))
         assert full[-1][1] == 1 and parts[1][-1][0]["frames"].shape[0] == 0   # short last batch: rank 1 idles
+
+
+# ---- evaluation sharded over ranks (SURVEY 8e "Eval"): world_size 2 over gloo == one process ---------------------------------
+class _StubModel(torch.nn.Module):
+    """predict / get_next_action as deterministic functions of the frames (the evaluators' host logic is what is under test:
+    which rank evaluates which episode, the order of the gathered records, the AP numbers -- no GPU, no kernels)"""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def get_next_action(self, data):
+        return int(data["frames"].double().abs().sum().item() * 1000) % 4
+
+    def predict(self, data):
+        b = data["frames"].shape[0]
+        logits, boxes = torch.zeros(b, 1, 12, 1236), torch.zeros(b, 1, 12, 4)
+        for i in range(b):     # episode by episode: the answer must not depend on who shares the batch
+            g = torch.Generator().manual_seed(int(data["frames"][i].double().abs().sum().item() * 10) % (2 ** 31))
+            boxes[i] = torch.rand(1, 12, 4, generator=g) * 0.4 + 0.2
+            cats = data["category_ids"][i][0]
+            for q in range(12):
+                c = int(cats[q % len(cats)]) if len(cats) and q % 3 else 11
+                logits[i, 0, q, c] = 2.0 + 3.0 * float(torch.rand(1, generator=g))
+            if len(cats):
+                boxes[i, 0, 1] = data["boxes"][i][0][0] * torch.tensor([1.0, 1.0, 0.9, 1.1])
+        return {"pred_logits": logits, "pred_boxes": boxes}
+
+
+def _eval_cfg(tmp, kind):
+    root = os.path.join(GOLDEN, "data")
+    return Config(**{"EVALUATOR": {"TYPE": kind, "BATCH_SIZE": 2, "NUM_WORKERS": 0, "OUTPUT_DIRECTORY": tmp, "CHECKPOINT": ""},
+                     "DATASET": {"TEST": {"TYPE": "sequence", "MODE": "test", "IMAGE_ROOT": os.path.join(root, "imgs") + "/",
+                                          "ANNOTATION_ROOT": os.path.join(root, "annotations_eval.json")}}})
+
+
+def _eval_worker(rank, world, port, kind, tmp, out):
+    import torch.distributed as dist
+    from interactron_amd import build_evaluator
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ev = build_evaluator(_StubModel(), _eval_cfg(tmp + "/w%dr%d" % (world, rank), kind))
+    seen = []
+    orig = ev._episodes
+    ev._episodes = lambda mine: (seen.extend(mine), orig(mine))[1]
+    five = ev.evaluate(save_results=False)
+    six = ev.evaluate(save_results=True)
+    wrote = os.path.exists(ev.out_dir + "results.json")
+    dets = json.load(open(ev.out_dir + "results.json"))["detections"] if wrote else None
+    out[(world, rank)] = (tuple(float(x) for x in five), {k: float(v) for k, v in six.items()}, sorted(set(seen)), wrote, dets)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["random_policy_evaluator", "interactive_evaluator"])
+def test_sharded_evaluation_world_size_2_gloo_equals_single_process(kind, tmp_path):
+    """Rank r evaluates test episodes r::2, the detection lists are gathered and merged back into test-set order: same
+    records in the same order, same six AP numbers on both ranks as one process (reference loop:
+    engine/interactive_evaluator.py:35-63, random_policy_evaluator.py:37-60); only rank 0 writes results.json."""
+    import torch.multiprocessing as mp
+    from tests.test_host_cpu import _free_port
+    out = mp.Manager().dict()
+    _eval_worker(0, 1, 0, kind, str(tmp_path), out)
+    mp.spawn(_eval_worker, args=(2, _free_port(), kind, str(tmp_path), out), nprocs=2, join=True)
+    single, r0, r1 = out[(1, 0)], out[(2, 0)], out[(2, 1)]
+    assert single[2] == [0, 1, 2, 3, 4, 5] and r0[2] == [0, 2, 4] and r1[2] == [1, 3, 5]
+    assert r0[0] == r1[0] == single[0] and r0[1] == r1[1] == single[1]
+    assert single[3] and r0[3] and not r1[3]
+    assert r0[4] == single[4] and len(single[4]) > 20 and {d["type"] for d in single[4]} == {"tp", "fp", "fn"}

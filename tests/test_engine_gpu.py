@@ -82,3 +82,59 @@ def test_train_then_evaluate_drop_in(tmp_path):
         _, _, tp, fp, fn = build_evaluator(build_model(cfg.MODEL), cfg, load_checkpoint=True).evaluate()
         counts.append(tp + fn)
     assert counts[0] == counts[1] and counts[0] > 0
+
+
+# ---- fixture G18: the reference's evaluators end to end (tests/golden/make_golden_evalrun.py) ---------------------------
+def _g18_model(G):
+    from interactron_amd import Config, build_model
+    from interactron_amd.synthetic import evalrun_weight_edit, load_procedural
+    model = build_model(Config(**MODEL))
+    load_procedural(model.fusion, "fusion.")      # (build_model's "procedural" covers the detector; as in the parity tests)
+    sd = model.state_dict()
+    sd = {k: v.clone() for k, v in sd.items()}
+    # the conv weights of this package live as [out, kh, kw, in]; state_dict() hands out the reference layout, so the
+    # recipe -- closed-form edit + the stored overrides -- applies name for name
+    evalrun_weight_edit(sd, G["overrides"])
+    model.load_state_dict(sd)
+    return model.cuda()
+
+
+def _g18_cfg(G, tmp_path, kind):
+    from interactron_amd import Config
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    split = {"TYPE": "sequence", "MODE": "test", "IMAGE_ROOT": os.path.join(root, "imgs") + "/",
+             "ANNOTATION_ROOT": os.path.join(root, G["annotations"])}
+    return root, Config(**{"MODEL": MODEL, "DATASET": {"TEST": split},
+                           "EVALUATOR": {"TYPE": kind, "BATCH_SIZE": 1, "NUM_WORKERS": 0, "OUTPUT_DIRECTORY": str(tmp_path),
+                                         "CHECKPOINT": ""}})
+
+
+@pytest.mark.parametrize("kind", ["interactive_evaluator", "random_policy_evaluator"])
+def test_g18_evaluators_end_to_end_against_the_reference(kind, golden, tmp_path):
+    """The only available stand-in for north_star's "AP within +-0.002": the imported reference's evaluators
+    (engine/interactive_evaluator.py:35-262, engine/random_policy_evaluator.py:37-211) were run on tests/golden/data with the
+    fixture's weight recipe; the HIP evaluators must choose the same moves, produce the same records (kind, category, image
+    exactly; IoU and score to 1e-3, box corners to 2e-3) in the same order, the same counts and the six AP numbers to 0.002."""
+    from interactron_amd import build_evaluator
+    G = golden("golden_evalrun.pt")
+    want = G[kind.replace("_evaluator", "")]
+    root, cfg = _g18_cfg(G, tmp_path, kind)
+    model = _g18_model(G)
+    moves = []
+    if kind == "interactive_evaluator":
+        orig = model.get_next_action
+        model.get_next_action = lambda data: (moves.append(int(orig(data))), moves[-1])[1]
+    ev = build_evaluator(model, cfg)
+    summary = ev.evaluate(save_results=True)
+    got = json.load(open(ev.out_dir + "results.json"))["detections"]
+    assert moves == want["actions"], (moves, want["actions"])
+    assert len(got) == len(want["detections"]), (len(got), len(want["detections"]))
+    for i, (g, w) in enumerate(zip(got, want["detections"])):
+        assert (g["type"], g["pred_cat"], g["category_match"]) == (w["type"], w["pred_cat"], w["category_match"]), (i, g, w)
+        assert os.path.relpath(g["img"], root) == w["img"], (i, g["img"], w["img"])
+        assert abs(g["iou"] - w["iou"]) <= 1e-3 and abs(g["pred_score"] - w["pred_score"]) <= 1e-3, (i, g, w)
+        assert max(abs(a - b) for a, b in zip(g["box"], w["box"])) <= 2e-3 and abs(g["area"] - w["area"]) <= 2e-3, (i, g, w)
+    for k, v in want["six"].items():
+        assert abs(float(summary[k]) - v) <= 2e-3, (k, float(summary[k]), v)
+    ap50, ap, tp, fp, fn = ev.evaluate(save_results=False)
+    assert (tp, fp, fn) == tuple(want["returned"][2:]) and abs(ap50 - want["returned"][0]) <= 2e-3 and abs(ap - want["returned"][1]) <= 2e-3

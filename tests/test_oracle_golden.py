@@ -184,3 +184,57 @@ def test_g11_g12_predict_and_policy(golden, det, episode1):
         a, logits = oe.interactron_next_action(det, fus, dd, CFG)
         assert a == M["g12"][s - 1]
         torch.testing.assert_close(logits.reshape(4, 4), M["g12_logits"][s - 1].reshape(4, 4), atol=2e-5, rtol=1e-4)
+
+
+# ---- G18: the oracle behind this package's evaluators == the reference's evaluators end to end ------------------------------
+class _OracleModel(torch.nn.Module):
+    """the model interface the evaluators call (predict / get_next_action / eval), answered by the CPU oracle"""
+
+    def __init__(self, det, fus):
+        super().__init__()
+        self.det, self.fus = det, fus
+        self.anchor = torch.nn.Parameter(torch.zeros(1))   # (the evaluators ask the model where it lives)
+
+    def predict(self, data):
+        return oe.interactron_predict(self.det, self.fus, data, CFG)
+
+    def get_next_action(self, data):
+        return oe.interactron_next_action(self.det, self.fus, data, CFG)[0]
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("kind", ["interactive_evaluator", "random_policy_evaluator"])
+def test_g18_oracle_through_the_evaluators(kind, golden, det_sd, tmp_path):
+    """tests/golden/make_golden_evalrun.py: InteractiveEvaluator / RandomPolicyEvaluator of the imported reference on
+    tests/golden/data.  Same moves, same records in the same order, same six AP numbers from the oracle + engine/."""
+    import json
+    import os
+    from interactron_amd import Config, build_evaluator
+    from interactron_amd.synthetic import evalrun_weight_edit
+    G = golden("golden_evalrun.pt")
+    want = G[kind.replace("_evaluator", "")]
+    sd = dict(det_sd)
+    sd.update(procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(CFG, "gpt").items()}))
+    sd = {k: v.clone() for k, v in sd.items()}
+    evalrun_weight_edit(sd, G["overrides"])
+    model = _OracleModel(strip({k: v for k, v in sd.items() if k.startswith("detector.")}, "detector."),
+                         strip({k: v for k, v in sd.items() if k.startswith("fusion.")}, "fusion."))
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    cfg = Config(**{"EVALUATOR": {"TYPE": kind, "BATCH_SIZE": 1, "NUM_WORKERS": 0, "OUTPUT_DIRECTORY": str(tmp_path), "CHECKPOINT": ""},
+                    "DATASET": {"TEST": {"TYPE": "sequence", "MODE": "test", "IMAGE_ROOT": os.path.join(root, "imgs") + "/",
+                                         "ANNOTATION_ROOT": os.path.join(root, G["annotations"])}}})
+    moves = []
+    orig = model.get_next_action
+    model.get_next_action = lambda data: (moves.append(orig(data)), moves[-1])[1]
+    ev = build_evaluator(model, cfg)
+    summary = ev.evaluate(save_results=True)
+    got = json.load(open(ev.out_dir + "results.json"))["detections"]
+    assert moves == want["actions"]
+    assert len(got) == len(want["detections"])
+    for i, (g, w) in enumerate(zip(got, want["detections"])):
+        assert (g["type"], g["pred_cat"], g["category_match"]) == (w["type"], w["pred_cat"], w["category_match"]), (i, g, w)
+        assert os.path.relpath(g["img"], root) == w["img"]
+        assert abs(g["iou"] - w["iou"]) <= 1e-4 and abs(g["pred_score"] - w["pred_score"]) <= 1e-4, (i, g, w)
+        assert max(abs(a - b) for a, b in zip(g["box"], w["box"])) <= 1e-4, (i, g, w)
+    for k, v in want["six"].items():
+        assert abs(float(summary[k]) - v) <= 1e-6, (k, float(summary[k]), v)
