@@ -318,12 +318,18 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
             lib.ix_gemm_prof_dump(args.gemm_csv.encode())
         cms, cfl, cmf, cn = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
         lib.ix_prof_contractions(cms, cfl, cmf, cn)
+        cby = (ctypes.c_double * 3)()
+        lib.ix_prof_contraction_bytes(cby)
         fms, ffl, fmf, fn = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_int64 * 7)()
         lib.ix_prof_flash(fms, ffl, fmf, fn)
         ms, pairs = ctypes.c_double(), ctypes.c_int64()
         lib.ix_gemm_prof_read(ctypes.byref(ms), ctypes.byref(pairs))
         lib.ix_gemm_prof_enable(0)
         res["roofline"] = build_roofline(list(cms), list(cfl), list(cmf), list(cn), list(fms), list(ffl), list(fmf), list(fn), size)
+        en = cn[1] + cn[2]
+        res["roofline"]["algorithmic_bytes_per_launch"] = (cby[1] + cby[2]) / max(1, en)
+        t = res["roofline"]["traffic"]
+        res["roofline"]["traffic_over_algorithmic"] = (t / res["roofline"]["algorithmic_bytes_per_launch"]) if t and en else None
 
     bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
     assert not bad, "non-finite losses after the timed steps: %s" % bad
@@ -545,6 +551,10 @@ def main():
             "roofline": head["roofline"],
             "cpu_baseline": None,
             "n800": n800,
+            # BASELINE.json's north_star quotes frames/s on synthetic 5 x 3x800x800 episodes: that figure, at top level (the
+            # headline `value` is configs/interactron.yaml at the reference's real 300 x 300 shapes)
+            "north_star": ({"value": n800["value"], "unit": "frames/s", "workload": n800["workload"], "ms_per_step": n800["ms_per_step"],
+                            "steps": n800["steps"]} if n800 is not None and "error" not in n800 else None),
             "small_e": None, "strong": None,
             "hbm_kernels": hbm_kernels(torch, hipops, dev, min(args.chunk, args.episodes) * cfg["BLOCK_SIZE"],
                                        (min(args.chunk, args.episodes), cfg["BLOCK_SIZE"])) if not args.no_roofline else None,
@@ -570,6 +580,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.config)
             if n800 is not None and "error" not in n800:
                 n800["cpu_baseline"] = cpu_detector_800()
+                n800["cpu_baseline"]["comparable"] = False
+                n800["cpu_baseline"]["note"] = ("NOT a like-for-like step: the detector forward alone on one 800 x 800 frame.  A full "
+                                                "meta-train step at T = 12 755 needs 8 x T^2 fp32 attention tensors with double backward "
+                                                "on the host (BASELINE.md 3); never divide the n800 value by this figure")
         sys.stdout.flush()
         os.write(JSON_FD, (json.dumps(line) + "\n").encode())   # the one line on the real stdout
     if world > 1:

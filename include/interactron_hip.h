@@ -63,6 +63,10 @@ int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kconti
 int ix_gemm_presplit_enable(int on);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls);
 int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3); /* by form: fp32 / bf16x6 / fp16x3 */ /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
+/* ALGORITHMIC HBM bytes of the profiled contraction launches by the same three forms: 4 (M K + K N + M N) per batch slice -- each
+ * operand read once, the result written once (an operand shared by all slices is counted per slice: an upper bound).  The
+ * figure a PMC traffic measurement of the same launches is to be compared with (SURVEY 8d / bench.py roofline). */
+int ix_prof_contraction_bytes(double* bytes3);
 
 /* ix_gemm_rowsum_f32: C = alpha A B and, from the same launch, rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  With A
  * stored m-contiguous (a_kcontig = 0) the bf16x6 kernel's A-producer waves accumulate the sums from the tiles they stream

@@ -450,7 +450,10 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
             }
             p0 = wave_min_i32(p0);
             um = wave_max_i32(um);
-            if (p0 == 0x7fffffff) {   // no finite path cost (NaN / inf costs): leave this row unmatched instead of spinning
+            // no finite path cost (NaN / inf costs: every shortest[j] is still INFINITY, which `== lowest` would happily match
+            // and the duals would go NaN along an "infinite" path): the host route (scipy, csrc/lsap.cpp) calls this
+            // infeasible and raises; here the row stays unmatched instead of training on an arbitrary assignment
+            if (p0 == 0x7fffffff || !(lowest < INFINITY)) {
                 sink = -2;
                 break;
             }

@@ -2092,6 +2092,20 @@ extern "C" int ix_prof_contractions(double* ms3, double* flops3, double* mfma_fl
     return IX_OK;
 }
 
+// Algorithmic HBM bytes of the profiled contraction launches by form (see the header).  Call before ix_gemm_prof_read.
+extern "C" int ix_prof_contraction_bytes(double* bytes3) {
+    double by[3] = {0, 0, 0};
+    for (size_t i = 0; i / 2 < g_rec.size() && i + 1 < g_ev_used; i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm == 2002 || r.bm == 3128) continue;
+        const int k = r.bm == 1129 ? 2 : (r.bm == 1128 ? 1 : 0);
+        by[k] += 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N) * (double)(r.nbatch > 0 ? r.nbatch : 1);
+    }
+    for (int k = 0; k < 3; ++k)
+        if (bytes3) bytes3[k] = by[k];
+    return IX_OK;
+}
+
 // Profiled flash attention launches by kernel tag (1 forward, 2 backward-q, 3 backward-kv, 4 statistics, 5 second-order q,
 // 6 second-order kv): summed event time (ms), algorithmic FLOPs, FLOPs of the matrix instructions actually issued
 // (3 fp16 terms per product over the head dim, 6 bf16 terms per product over tokens), launches.  Host arrays of 7

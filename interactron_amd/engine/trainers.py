@@ -91,8 +91,11 @@ class _TrainerBase:
         import torch.distributed as dist
         if self.world > 1 and dist.is_initialized():
             dist.broadcast(outer.flat.params, src=0)
-            for b in self.model.buffers():
-                dist.broadcast(b.data, src=0)
+            with torch.no_grad():
+                for b in self.model.buffers():
+                    dist.broadcast(b, src=0)      # the buffer itself (bumps its version: cached FrozenBN folds see the change)
+            if hasattr(self.model, "invalidate_graphs"):
+                self.model.invalidate_graphs()    # captured graphs / folds made before the sync read the old values
             self._check_replicas(outer)
 
     def _check_replicas(self, outer):
@@ -100,12 +103,17 @@ class _TrainerBase:
         import torch.distributed as dist
         p = outer.flat.params.double()
         stat = torch.stack([p.sum(), (p * p).sum()])
+        finite = torch.isfinite(stat).all().to(stat.dtype).reshape(1)
+        stat = torch.cat([torch.nan_to_num(stat, nan=0.0, posinf=0.0, neginf=0.0), finite])
         lo, hi = stat.clone(), stat.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if float(lo[2]) == 0.0:    # (every rank sees it and raises: NaN != NaN would otherwise read as "drifted apart")
+            raise RuntimeError("non-finite parameters on %s rank(s): the step diverged (this rank: %s)"
+                               % ("every" if float(hi[2]) == 0.0 else "some", "non-finite" if float(finite) == 0.0 else "finite"))
         if not torch.equal(lo, hi):
             raise RuntimeError("data-parallel replicas have drifted apart: parameter checksums differ between ranks "
-                               "(min %s, max %s)" % (lo.tolist(), hi.tolist()))
+                               "(min %s, max %s)" % (lo[:2].tolist(), hi[:2].tolist()))
 
     def _decay_lr(self, cfg, outer, global_tokens):
         """Cosine schedule of the reference (interactron_trainer.py:113-127), counted in tokens of the GLOBAL batch so that

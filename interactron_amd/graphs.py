@@ -27,6 +27,13 @@ from .meta import set_parameters
 # run polls events while a rank captures, which the default "global" mode treats as an error
 CAPTURE_MODE = "thread_local"
 GOLDEN = -0x61C8864680B583EB   # 0x9E3779B97F4A7C15 as a signed 64-bit step of the dropout salt
+# Captured chunks address their ground truth through static CSR buffers with ONE fixed pitch (columns per image in the cost
+# matrices, capacity I * GRAPH_PITCH): the kernels read the per-image counts from `off`, a pitch only has to be >= the
+# largest count.  A signature therefore does not depend on how many boxes a batch happens to carry (real data: it changes
+# batch to batch; keyed on it, every new pair cost an eager step, a capture and a private pool holding a step's activations);
+# a batch with a fuller image runs eagerly.  At most GRAPH_SETS signatures stay captured (least recently used goes first).
+GRAPH_PITCH = 64
+GRAPH_SETS = 4
 
 
 class ChunkState:
@@ -147,6 +154,7 @@ class ChunkGraphs:
         theta = model._theta
         pool, pool_c = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         graphs = []
+        ops.prepare_scratch_slots((0, 1), st.frames.device)   # sized from the warm-up run, tickets zeroed eagerly
         ops.capture_begin(self.salt)
         try:
             for seg, pl, slot in ((model._seg_a, pool, 0), (model._seg_c, pool_c, 1), (model._seg_b, pool, 0), (model._seg_d, pool, 0)):
@@ -210,21 +218,27 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
     if state.get("disabled") or not _wants_graph(model, E, shape) or model.phase_times is not None:
         return eager
     matcher = model.criterion.matcher
-    if type(matcher).assign is not HungarianMatcher._host_assign or max(ldn, ldn1) > ops.LSAP_DEVICE_MAX:
-        return eager   # (assignments pinned by a test, or a side the one-wavefront kernel does not take: host route)
+    if type(matcher).assign is not HungarianMatcher._host_assign or max(ldn, ldn1) > min(GRAPH_PITCH, ops.LSAP_DEVICE_MAX):
+        return eager   # (assignments pinned by a test, or an image with more boxes than the static buffers' pitch: this batch only)
     # gradients must accumulate IN PLACE into existing buffers (trainer.FlatBuffers provides them; after an eager step only
     # never-used parameters such as GPT.pos_emb are still without one).  zero_grad(set_to_none=True) between steps: eager.
     if sum(p.requires_grad and p.grad is None for p in model.parameters()) > 4:
         return eager
-    key = (E, s, tuple(shape), ldn, ldn1, model.detector.training, model.fusion.training)
+    key = (E, s, tuple(shape), model.detector.training, model.fusion.training)
     ent = state.get(key)
+    if ent is not None:
+        state[key] = state.pop(key)   # most recently used last
     if ent is None:   # first call of a signature: eager (warms BN folds, scratch, size caches); the next one captures
         state[key] = "warm"
         return eager
     if ent == "warm" or ent.stamp != model._graph_stamp()[0]:
         def capture_then_run(inputs, policy_labels):
+            fresh_grads = {id(p) for p in model.parameters() if p.grad is None}   # .grad tensors first bound inside the capture
             try:
-                g = ChunkGraphs(model, E, s, shape, ldn, ldn1, inputs["masks"].dtype)
+                held = [k for k, v in state.items() if isinstance(v, ChunkGraphs) and k != key]
+                for old in held[:max(0, len(held) - (GRAPH_SETS - 1))]:
+                    del state[old]          # its graphs, static buffers and both private pools go with it
+                g = ChunkGraphs(model, E, s, shape, GRAPH_PITCH, GRAPH_PITCH, inputs["masks"].dtype)
                 g.load(inputs)
                 g.capture()
             except Exception as e:   # capture not possible here: stay eager from now on, and say so once
@@ -232,6 +246,11 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
                               "rest of this process" % (type(e).__name__, (str(e).splitlines() or [""])[0]))
                 state["disabled"] = True
                 torch.cuda.synchronize()
+                # nothing of the capture ran: its scratch tickets and any .grad buffer it bound are not to be trusted
+                ops.reset_scratch_slots()
+                for p in model.parameters():
+                    if p.grad is not None and id(p) in fresh_grads:
+                        p.grad = None
                 return run_eager(model, E, s, inputs, policy_labels)
             state[key] = g
             return g(inputs, policy_labels)
@@ -252,6 +271,7 @@ class PredictGraph:
 
     def capture(self):
         g = torch.cuda.CUDAGraph()
+        ops.prepare_scratch_slots((0,), self.frames.device)
         ops.capture_begin(None)
         try:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode=CAPTURE_MODE):
@@ -290,6 +310,7 @@ def predict_runner(model, frames, masks):
                               "process" % (type(e).__name__, (str(e).splitlines() or [""])[0]))
                 state["disabled"] = True
                 torch.cuda.synchronize()
+                ops.reset_scratch_slots()
                 return eager(frames, masks)
             state[key] = g
             return g(frames, masks)

@@ -170,11 +170,43 @@ def _workspace(nbytes, device):
     tickets, zero when the buffer is created and left zero by every kernel][split-K planes / reduction partials]."""
     t = _scratch[0]
     if t is None or t.numel() < nbytes:
+        # never inside a graph capture: the buffer would come from the graph's private pool and the zeroing of its tickets
+        # would be RECORDED, not executed -- after a failed capture the module would keep a scratch whose tickets were never
+        # cleared (reductions that then never fire, or fire early).  graphs.* sizes every slot before capture_begin.
+        if _capture[0] is not None:
+            raise _lib.HipLibraryError("the contraction scratch would have to grow inside a HIP-graph capture (%d > %d bytes): "
+                                  "call prepare_scratch_slots() after a warm-up run first" % (nbytes, 0 if t is None else t.numel()))
         if t is not None:
             _scratch_retired.append(t)
         t = _scratch[0] = torch.empty(max(2 * nbytes, 64 << 20), dtype=torch.uint8, device=device)
         t[:TICKET_BYTES].zero_()
     return t
+
+
+def prepare_scratch_slots(slots, device):
+    """Before a capture: every scratch slot the captured launch sequences use exists, is as large as the largest scratch
+    the warm-up run needed (the capture replays the same shapes) and has had its tickets zeroed EAGERLY."""
+    _scratch_slots[_scratch_slot[0]] = _scratch[0]
+    need = max([t.numel() for t in _scratch_slots.values() if t is not None] + [64 << 20])
+    for k in slots:
+        t = _scratch_slots.get(k)
+        if t is None or t.numel() < need:
+            if t is not None:
+                _scratch_retired.append(t)
+            t = _scratch_slots[k] = torch.empty(need, dtype=torch.uint8, device=device)
+            t[:TICKET_BYTES].zero_()
+    _scratch[0] = _scratch_slots.get(_scratch_slot[0])
+
+
+def reset_scratch_slots():
+    """After a FAILED capture: forget every scratch buffer (a captured-but-never-run kernel sequence may have left tickets
+    half way); the next launch allocates and zeroes a fresh one.  The old buffers stay alive for earlier graphs."""
+    for t in list(_scratch_slots.values()) + [_scratch[0]]:
+        if t is not None and not any(t is r for r in _scratch_retired):
+            _scratch_retired.append(t)
+    for k in list(_scratch_slots):
+        _scratch_slots[k] = None
+    _scratch[0] = None
 
 
 _red_ws = {}
@@ -201,8 +233,10 @@ def _reduce_ws(kind, rows, C, groups, device):
     return _workspace(n, device).data_ptr(), n
 
 
-def _gemm_workspace_bytes(pa, pb, sp):
-    x3 = GEMM_X3 and not sp.A.trans and sp.B.trans and sp.N >= 1024 and sp.M >= 1024
+def _gemm_workspace_bytes(pa, pb, sp, presplit=True):
+    """presplit=False: the caller's entry point never takes the opt-in pre-split route (row-sum / BN-fused contractions): size
+    the scratch for ITS plan (split-K planes), not for the fp16 operand planes of a route it will not use."""
+    x3 = presplit and GEMM_X3 and not sp.A.trans and sp.B.trans and sp.N >= 1024 and sp.M >= 1024
     key = (sp.M, sp.N, sp.K, sp.bo, sp.bi, sp.A.trans, sp.B.trans, sp.A.ld, sp.B.ld, sp.A.so, sp.B.so, pa & 15, pb & 15, x3)
     n = _ws_bytes.get(key)
     if n is None:
@@ -397,7 +431,7 @@ class GemmRowsum(Function):
         out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32)
         rs = torch.empty((groups, sp.M) if groups else (sp.M,), device=a.device, dtype=torch.float32)
         pa, pb = a.data_ptr(), b.data_ptr() + sp.B.offset * 4
-        nws, _ = _gemm_workspace_bytes(pa, pb, sp)
+        nws, _ = _gemm_workspace_bytes(pa, pb, sp, presplit=False)
         ws = _workspace(nws, a.device) if nws else None
         _chk(_L().ix_gemm_rowsum_f32(pa, pb, out.data_ptr() + sp.C.offset * 4,
                                      sp.M, sp.N, sp.K, 0, 1 if sp.B.trans else 0, sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.A.so,
@@ -1429,7 +1463,7 @@ class GemmBnAct(Function):
         assert sp.bi == 1 and sp.alpha == 1.0 and sp.C.offset == 0 and sp.C.ld == sp.N and not sp.C.trans
         assert sp.A.offset == 0 and sp.B.offset == 0 and (sp.bo == 1 or sp.C.so == sp.M * sp.N)
         out = torch.empty(sp.out_shape, device=a.device, dtype=torch.float32)
-        nws, _ = _gemm_workspace_bytes(a.data_ptr(), b.data_ptr(), sp)
+        nws, _ = _gemm_workspace_bytes(a.data_ptr(), b.data_ptr(), sp, presplit=False)
         ws = _workspace(nws, a.device) if nws else None
         _chk(_L().ix_gemm_bn_act_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), sp.M, sp.N, sp.K, 0 if sp.A.trans else 1,
                                      1 if sp.B.trans else 0, sp.A.ld, sp.B.ld, sp.bo, sp.A.so, sp.B.so, scale.data_ptr(),

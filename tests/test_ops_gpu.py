@@ -966,6 +966,39 @@ def test_flash_attention_second_order_against_float64(ops, n, H, L, S, hd, maske
         close(a, b, 6e-5, "flash second-order " + name)
 
 
+@pytest.mark.parametrize("n,H,L,S,hd", [(1, 1, 256, 12755, 64), (1, 2, 2060, 2060, 64)])
+@pytest.mark.usefixtures("flash_form")
+def test_flash_second_order_long_rows_against_float64(ops, n, H, L, S, hd):
+    """The head-dim-64 second-order passes at the row lengths of the measured steps -- S = 12 755 keys (the north-star fusion
+    sequence, 399 key tiles) and L = S = 2 060 (the 300 x 300 fusion sequence) -- with dropout 0.1, against float64 autograd on
+    the host (reference models/gpt.py:39-57,191).  The fp16 form's running per-row factors and the online-softmax rescaling
+    depend on the NUMBER of key tiles; the short-row tests stop at 11."""
+    E = H * hd
+    pdrop, seed = 0.1, 0x13579BD
+    q, k, v = rnd(n, L, E, seed=11), rnd(n, S, E, seed=12), rnd(n, S, E, seed=13)
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    drop = ops.flash_dropmask(n * H, L, S, pdrop, seed).cpu().double()
+    gy = rnd(n, L, E, seed=15)
+    ws = [rnd(n, L, E, seed=16), rnd(n, S, E, seed=17), rnd(n, S, E, seed=18)]
+
+    def second(dev, dt, fn):
+        x = [t.to(dev, dt).requires_grad_(True) for t in (q, k, v)]
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        out = fn(*x)
+        g1 = torch.autograd.grad(out, x, gyd, create_graph=True)
+        s = sum((a * w.to(dev, dt)).sum() for a, w in zip(g1, ws))
+        return out, g1, torch.autograd.grad(s, x + [gyd])
+
+    oh, g1h, g2h = second("cuda", torch.float32, lambda a, b, c: ops.FlashAttention.apply(a, b, c, g, None, pdrop, seed))
+    orf, g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, None, drop))
+    close(oh, orf, 2e-5, "long-row forward")
+    for name, a, b in zip("qkv", g1h, g1r):
+        close(a, b, 3e-5, "long-row grad " + name)
+    for name, a, b in zip(["q", "k", "v", "dO"], g2h, g2r):
+        close(a, b, 6e-5, "long-row second-order " + name)
+
+
 @pytest.mark.usefixtures("flash_form")
 def test_flash_attention_second_order_packed_qk(ops):
     n, H, L, hd = 2, 4, 77, 32

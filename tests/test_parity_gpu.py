@@ -171,6 +171,33 @@ def test_device_assignment_equals_host_assignment_bit_for_bit():
                 assert torch.equal(qot[off[i]:off[i + 1]], inv), (Q, kind, sizes[i])
 
 
+def test_device_assignment_leaves_non_finite_images_unmatched():
+    """A cost matrix without a finite path (a row of NaN / +inf: a diverged step) is INFEASIBLE for scipy and the host route
+    (they raise); the device kernel must not augment along "infinite" paths and hand back an arbitrary assignment: the image
+    comes back unmatched (-1 everywhere it could not assign), the finite image beside it is untouched."""
+    from interactron_amd import hipops as ops
+    Q, n = 50, 6
+    gen = torch.Generator().manual_seed(11)
+    good = torch.rand(Q, n, generator=gen)
+    for bad_value in (float("nan"), float("inf")):
+        bad = torch.rand(Q, n, generator=gen)
+        bad[:, 2] = bad_value                      # one target nobody can take at a finite cost
+        cost = torch.zeros(2, Q, 8)
+        cost[0, :, :n], cost[1, :, :n] = bad, good
+        tg = ops.Targets(torch.zeros(2 * n, dtype=torch.int64, device="cuda"), torch.zeros(2 * n, 4, device="cuda"),
+                         torch.tensor([0, n, 2 * n], dtype=torch.int32).cuda(), [n, n])
+        tg.ldn = 8
+        toq, qot = ops.lsap_device(cost.cuda(), tg)
+        toq, qot = toq.cpu(), qot.cpu()
+        r, col = ops.lsap(good.contiguous())
+        want = torch.full((Q,), -1, dtype=torch.int32)
+        want[r] = col.to(torch.int32)
+        assert torch.equal(toq[1], want)
+        assert int(qot[2]) == -1 and not bool((toq[0] == 2).any()), (bad_value, qot[:n], toq[0])
+        assigned = toq[0][toq[0] >= 0]
+        assert assigned.numel() == assigned.unique().numel() and assigned.numel() <= n - 1
+
+
 def test_grouped_set_loss_against_float64():
     """hipops.SetLoss (the losses of several image groups from one pass, each with its own normalisers) against a float64
     restatement of reference detr.py:111-167,238-242 evaluated group by group: forward values of both group layouts and
