@@ -48,7 +48,7 @@ CONFIGS = {   # --config -> (reference yaml, MODEL.TYPE, oracle fusion style)
 }
 
 
-def model_cfg(size, queries, chunk=8, model_type="interactron"):
+def model_cfg(size, queries, chunk=8, model_type="interactron", step_graph=None, compute_dtype="f32"):
     # stride-16 backbone: h = w = ceil(size / 16) after the stem/maxpool/strided stages (19 at 300, 50 at 800)
     h = size
     for k, s, p in ((7, 2, 3), (3, 2, 1), (3, 2, 1), (3, 2, 1)):
@@ -57,7 +57,8 @@ def model_cfg(size, queries, chunk=8, model_type="interactron"):
     return dict(TYPE=model_type, WEIGHTS="procedural", NUM_CLASSES=1235, SET_COST_CLASS=1.0, SET_COST_BBOX=5.0,
                 SET_COST_GIOU=2.0, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=5 * (tokens + queries) + 5,
                 IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
-                ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries, EPISODE_CHUNK=chunk), tokens
+                ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries, EPISODE_CHUNK=chunk,
+                COMPUTE_DTYPE=compute_dtype, **({} if step_graph in (None, "auto") else {"STEP_GRAPH": step_graph})), tokens
 
 
 def to_gpu(data, dev):
@@ -222,7 +223,7 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     from interactron_amd.trainer import FlatOuterStep
     lib, dev, rank, world, local = ctx["lib"], ctx["dev"], ctx["rank"], ctx["world"], ctx["local"]
 
-    cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1])
+    cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1], args.step_graph, args.compute_dtype)
     model = build_model(Config(**cfg))
     if hasattr(model, "fusion"):
         load_procedural(model.fusion, "fusion.")
@@ -311,9 +312,18 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     if want_roofline:
         # HIP-event pair around every launch of the contraction and attention kernels on their own stream, one extra step
         # of the same workload (kept out of the timed region so the events do not perturb `value`).
+        # (issued launch by launch: a replayed graph passes no launch through the library's event brackets)
+        had = getattr(model.config, "STEP_GRAPH", None) if hasattr(model, "config") else None
+        if hasattr(model, "config"):
+            model.config.STEP_GRAPH = "off"
         lib.ix_gemm_prof_enable(1)
         step()
         torch.cuda.synchronize()
+        if hasattr(model, "config"):
+            if had is None:
+                del model.config.STEP_GRAPH
+            else:
+                model.config.STEP_GRAPH = had
         if args.gemm_csv and rank == 0:
             lib.ix_gemm_prof_dump(args.gemm_csv.encode())
         cms, cfl, cmf, cn = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
@@ -457,6 +467,12 @@ def main():
     ap.add_argument("--small-e", type=int, default=2,
                     help="episodes per GPU of the `small_e` sub-measurement at N = 1 (the per-GPU share of the reference's global "
                          "batch on 8 GPUs; replayed from HIP graphs); 0 = skip it")
+    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
+                    help="MODEL.STEP_GRAPH: replay the chunk's launch sequence from captured HIP graphs (auto: chunks up to 4 x 300^2 episodes)")
+    ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16"],
+                    help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the single-pass "
+                         "16-bit mode (BASELINE.json configs[1]: --config multi_frame_baseline --compute-dtype bf16) -- its own line, "
+                         "`dtype` says so, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -495,7 +511,8 @@ def main():
         args.episodes = args.global_batch // world
         args.chunk = min(args.chunk, args.episodes)
     head = run_workload(args, args.size, args.episodes, args.chunk, args.steps, args.warmup, ctx, not args.no_roofline, "bench")
-    headline_cfg = args.size == 300 and args.mode == "train" and args.config == "interactron" and not strong
+    headline_cfg = (args.size == 300 and args.mode == "train" and args.config == "interactron" and not strong
+                    and args.compute_dtype == "f32")
     # The per-GPU share of the reference's global batch of 16 on 8 GPUs (engine/interactron_trainer.py:78-84 + SURVEY 8e): what
     # a rank of the strong-scaling run executes per step.  At N = 1 as `small_e`; at N > 1 the same global batch as `strong`.
     small = strong_run = None
@@ -527,7 +544,10 @@ def main():
         line = {
             "metric": "frames/sec (5-frame episodes)", "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "dtype": "f32" if args.compute_dtype == "f32" else "bf16-class (single-pass 16-bit contractions: fp16 x 2^E per 32x32 block, "
+                                                                "fp32 accumulation; fp32 storage, fp32-grade attention / norms)",
+            "data": "synthetic",
             "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
                                     "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode "
                                     "(dropout on; model-level parity is pinned in eval mode, the dropout kernels op by op)"

@@ -61,6 +61,11 @@ int ix_workspace_bytes_gemm_f32(int M, int N, int K, int a_kcontig, int b_kconti
                                 int batch_inner, int64_t sAo, int64_t sBo, const float* A, const float* B, int tile_hint,
                                 int split_k_hint, size_t* out_host);
 int ix_gemm_presplit_enable(int on);
+/* Single-pass 16-bit contraction mode (MODEL.COMPUTE_DTYPE: bf16 / fp16 -- BASELINE.json configs[1], reference arithmetic
+ * models/gpt.py:39-57, models/detr_multiframe.py:55-109 under autocast-like 16-bit matmuls): every contraction the fp16x3 form
+ * takes runs on its h plane alone (one fp16 value of x * 2^-E per element, block exponent per 32 x 32 sub-block, ONE MFMA per
+ * k-slice, fp32 accumulation).  NOT fp32-grade; process-global; never the parity path.  Returns the previous setting. */
+int ix_gemm_set_single_pass(int on);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls);
 int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3); /* by form: fp32 / bf16x6 / fp16x3 */ /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
 /* ALGORITHMIC HBM bytes of the profiled contraction launches by the same three forms: 4 (M K + K N + M N) per batch slice -- each
@@ -152,6 +157,9 @@ int ix_channel_affine_f32(const float* x, const float* scale, const float* shift
 
 /* ---- elementwise (transformer.py:148-232 residuals/ReLU/dropout, gpt.py:66-78 GELU, detr.py:72 sigmoid) ---- */
 int ix_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, ix_stream_t stream);
+/* out = ((srcs[0] + srcs[1]) + ...) over 2 <= n <= 8 device tensors of `count` floats; `srcs` is a HOST array of device pointers.
+ * The gradient of a tensor with several consumers in one pass (what torch.autograd does with n - 1 aten::add launches). */
+int ix_sum_n_f32(const float* const* srcs, int n, float* out, int64_t count, ix_stream_t stream);
 int ix_mul_f32(const float* a, const float* b, float* out, int64_t n, ix_stream_t stream);
 int ix_scale_f32(const float* x, float* out, int64_t n, float alpha, ix_stream_t stream);
 int ix_scale_dev_f32(const float* x, const float* s, float* out, int64_t n, ix_stream_t stream);

@@ -52,6 +52,10 @@ def arg_check(arg, choices, argname):
 def build_model(args):
     arg_check(args.TYPE, MODEL_TYPES, "model")
     from . import episode
+    dtype = getattr(args, "COMPUTE_DTYPE", None)
+    if dtype is not None:   # MODEL.COMPUTE_DTYPE: f32 (default, the parity path) | bf16 / fp16 (single-pass 16-bit contractions)
+        from . import hipops
+        hipops.set_compute_dtype(dtype)
     return getattr(episode, args.TYPE)(args)
 
 

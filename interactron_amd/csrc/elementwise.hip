@@ -82,6 +82,59 @@ __global__ void map3x2_kernel(const float* __restrict__ a, const float* __restri
         return IX_OK;                                                                                        \
     } while (0)
 
+// out = ((a0 + a1) + a2) + ... (2 <= n <= 8 tensors of one shape, summed left to right): the gradient of a tensor with several
+// consumers in ONE pass (hipops.Fanout / SumN) instead of autograd's n - 1 two-operand adds (reference: every residual
+// connection and every shared activation of models/detr_models/transformer.py:148-232, models/gpt.py:60-78, backbone
+// bottlenecks; under autograd each is a chain of aten::add).  16-byte loads when every pointer allows.
+struct SumNArgs {
+    const float* src[8];
+    int n;
+};
+__global__ void sum_n_kernel(SumNArgs a, float* __restrict__ o, int64_t count, bool vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = count >> 2;
+        for (int64_t k = i; k < n4; k += stride) {
+            float4 s = reinterpret_cast<const float4*>(a.src[0])[k];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) {
+                if (t < a.n) {
+                    const float4 x = reinterpret_cast<const float4*>(a.src[t])[k];
+                    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+                }
+            }
+            reinterpret_cast<float4*>(o)[k] = s;
+        }
+        for (int64_t k = (n4 << 2) + i; k < count; k += stride) {
+            float s = a.src[0][k];
+            for (int t = 1; t < a.n; ++t) s += a.src[t][k];
+            o[k] = s;
+        }
+    } else {
+        for (int64_t k = i; k < count; k += stride) {
+            float s = a.src[0][k];
+            for (int t = 1; t < a.n; ++t) s += a.src[t][k];
+            o[k] = s;
+        }
+    }
+}
+extern "C" int ix_sum_n_f32(const float* const* srcs, int n, float* out, int64_t count, hipStream_t stream) {
+    if (count <= 0) return IX_OK;
+    IX_CHECK_ARG(srcs && out && n >= 2 && n <= 8, "ix_sum_n_f32: 2..8 source tensors");
+    SumNArgs a;
+    bool vec = al16(out);
+    for (int t = 0; t < 8; ++t) {
+        a.src[t] = t < n ? srcs[t] : srcs[0];
+        IX_CHECK_ARG(a.src[t] != nullptr, "ix_sum_n_f32: null source");
+        vec = vec && al16(a.src[t]);
+    }
+    a.n = n;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(ix_grid_1d((count + 3) / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, a, out, count, vec);
+    IX_CHECK_LAUNCH("ix_sum_n_f32");
+    return IX_OK;
+}
+
 // out = alpha*a + beta*b
 extern "C" int ix_axpby_f32(const float* a, const float* b, float* out, int64_t n, float alpha, float beta,
                             hipStream_t stream) {

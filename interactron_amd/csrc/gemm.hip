@@ -385,7 +385,9 @@ typedef float x6_f32x4 __attribute__((ext_vector_type(4)));
 // exponent E per 32-row x 32-k sub-block, and a producer WAVE owns whole sub-blocks (so that E is a wave reduction):
 // m-contiguous operands already are laid out that way (wave w holds rows 32 w .. 32 w + 31 of all 32 k lines); for
 // k-contiguous operands the rows are dealt per wave instead of per pass (row_of).
-template <int BT, bool KC, bool SWZ = false, bool X3 = false>
+// ONE (with X3): the single-pass 16-bit form -- only the h plane is written (no residual), the consumers issue one MFMA per
+// k-slice (MODEL.COMPUTE_DTYPE: bf16 / fp16, never the parity path).
+template <int BT, bool KC, bool SWZ = false, bool X3 = false, bool ONE = false>
 struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
     static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
     static constexpr int ROWB = SWZ ? 64 : X6_ROWB;
@@ -611,6 +613,12 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             f32x2 x0, x1;
             x0.x = e[i][0] * sc; x0.y = e[i][1] * sc; x1.x = e[i][2] * sc; x1.y = e[i][3] * sc;
             const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
+            if (ONE) {   // single-pass form: the rounded value is the operand
+                u32x2 ph1;
+                ph1.x = __builtin_bit_cast(unsigned, h0); ph1.y = __builtin_bit_cast(unsigned, h1);
+                *(lds_u2*)(planes + row * X6_ROWB + (tid & 7) * 8) = ph1;
+                continue;
+            }
             // residual x * sc - float(h) in ONE instruction per element (v_fma_mix_f32 reads the fp16 half directly; exact: the
             // scale is a power of two and a float minus its own fp16 rounding is representable), instead of a conversion
             // back plus a packed fma
@@ -1232,20 +1240,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 
 // One operand's producer waves (256 threads): flat stream of K tiles over the workgroup's items, as in the 8-wave
 // kernel, for the A operand (IS_B false: BT = 128 rows of M) or the B operand (BT = BN rows of N).
-template <int BN, int BT, bool KC, bool IS_B, bool SWZ, int G = 0, bool X3 = false>
+template <int BN, int BT, bool KC, bool IS_B, bool SWZ, int G = 0, bool X3 = false, bool ONE = false>
 __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int buf_bytes,
                                             int plane_off, int pt, int* expo0 = nullptr) {
     constexpr int BK = X6_BK;
-    constexpr int NI_ = SplitLoader<BT, KC, SWZ, X3>::NI;
+    constexpr int NI_ = SplitLoader<BT, KC, SWZ, X3, ONE>::NI;
     static_assert(NI_ == 4 || NI_ == 2 || NI_ == 1, "unexpected ring stage size");
     static_assert(G == 0 || (G == 1 && KC && !IS_B) || ((G == 2 || G == 3) && !KC && IS_B), "gather mode vs operand layout");
-    SplitLoader<BT, KC, SWZ, X3> s0, s1, s2;
+    SplitLoader<BT, KC, SWZ, X3, ONE> s0, s1, s2;
     X6_BC_DECL
 #ifdef X6_DIAG_TIMING
     const int lane = pt & 63, wave = IS_B ? 100 : 4 + (pt >> 6);   // (stamps: the first A-producer wave)
     int dbgn = 0;
 #endif
-    typename SplitLoader<BT, KC, SWZ, X3>::PixRows pr;   // (mode 1 only; dead otherwise)
+    typename SplitLoader<BT, KC, SWZ, X3, ONE>::PixRows pr;   // (mode 1 only; dead otherwise)
     int erun = -1000;                                    // fp16x3 form: running sub-block exponent of the item (store_x3)
     int* const expo = expo0 + (IS_B ? 4 : 0) + (pt >> 6);   // this wave's word in image 0 (image 1: + 8)
     const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
@@ -1627,7 +1635,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
 // ------------------------------------------------------------------------------------------------------------
 typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
 
-template <bool A_KC, bool B_KC, int GA = 0, int GB = 0>
+template <bool A_KC, bool B_KC, int GA = 0, int GB = 0, bool ONE = false>
 __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, int total_items) {
     constexpr int BN = 128, BM = X6_BT, ROWB = X6_ROWB, NC = 4;
     constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 2 * (PLANE_A + PLANE_B);
@@ -1645,12 +1653,12 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     const bool staged = !p.atomic && p.c_vec;
 
     if (wave >= NC + 4) {
-        x6q_produce<BN, BN, B_KC, true, false, GB, true>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
-                                                         &expo[0][0]);
+        x6q_produce<BN, BN, B_KC, true, false, GB, true, ONE>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
+                                                              &expo[0][0]);
         return;
     }
     if (wave >= NC) {
-        x6q_produce<BN, BM, A_KC, false, false, GA, true>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64, &expo[0][0]);
+        x6q_produce<BN, BM, A_KC, false, false, GA, true, ONE>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64, &expo[0][0]);
         return;
     }
 
@@ -1679,10 +1687,15 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     X3Q_MM(A0C, B0C) X3Q_SB
 #else
 #define X3Q_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                     \
-    X3Q_LDA(A0N, 0, NBASE, NS) X3Q_LDB(B0N, 0, NBASE, NS) X3Q_SB                                                     \
-    X3Q_MM(al, B0C) X3Q_SB X3Q_LDA(al, 1, NBASE, NS) X3Q_SB                                                          \
-    X3Q_MM(A0C, bl) X3Q_SB X3Q_LDB(bl, 1, NBASE, NS) X3Q_SB                                                          \
-    X3Q_MM(A0C, B0C) X3Q_SB
+    if (ONE) {   /* single-pass form: h planes only, one product per k-slice */                                       \
+        X3Q_LDA(A0N, 0, NBASE, NS) X3Q_LDB(B0N, 0, NBASE, NS) X3Q_SB                                                 \
+        X3Q_MM(A0C, B0C) X3Q_SB                                                                                      \
+    } else {                                                                                                         \
+        X3Q_LDA(A0N, 0, NBASE, NS) X3Q_LDB(B0N, 0, NBASE, NS) X3Q_SB                                                 \
+        X3Q_MM(al, B0C) X3Q_SB X3Q_LDA(al, 1, NBASE, NS) X3Q_SB                                                      \
+        X3Q_MM(A0C, bl) X3Q_SB X3Q_LDB(bl, 1, NBASE, NS) X3Q_SB                                                      \
+        X3Q_MM(A0C, B0C) X3Q_SB                                                                                      \
+    }
 #endif
     // exponents of the image in LDS buffer B_ (wave-uniform values -> scalar registers)
 #define X3Q_EXPO(B_)                                                                                                 \
@@ -1692,8 +1705,8 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     int eA[TM], eB[TN];
     x6_lds_barrier();   // flat tile 0 is visible
     X3Q_EXPO(0)
-    X3Q_LDA(ahx, 0, lds[0], 0) X3Q_LDA(al, 1, lds[0], 0)
-    X3Q_LDB(bhx, 0, lds[0], 0) X3Q_LDB(bl, 1, lds[0], 0)
+    X3Q_LDA(ahx, 0, lds[0], 0) X3Q_LDB(bhx, 0, lds[0], 0)
+    if (!ONE) { X3Q_LDA(al, 1, lds[0], 0) X3Q_LDB(bl, 1, lds[0], 0) }
     int dbgn = 0;
     (void)dbgn;
     for (; w < last; w += stride) {
@@ -1838,7 +1851,34 @@ extern "C" int ix_gemm_set_x3(int on) {
     return old;
 }
 
+// Single-pass 16-bit mode (MODEL.COMPUTE_DTYPE: bf16 / fp16; hipops.set_compute_dtype): the fp16x3 form's h plane alone -- one
+// fp16 value of x * 2^-E per element (11 significant bits, block exponent per 32 x 32 sub-block: at least bf16's accuracy
+// with fp32's range), ONE v_mfma_f32_32x32x16_f16 per k-slice, fp32 accumulation.  Process-global like ix_gemm_set_x3; it
+// is NOT fp32-grade and never the parity path or the headline.  Returns the previous setting.
+static int g_single_pass = 0;
+extern "C" int ix_gemm_set_single_pass(int on) {
+    const int old = g_single_pass;
+    g_single_pass = on ? 1 : 0;
+    return old;
+}
+
+template <bool ONE>
+static void launch_x3q_(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, false, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, true, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, false, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
+}
+
 static void launch_x3q(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    if (g_single_pass) { launch_x3q_<true>(a, a_kc, b_kc, items, stream); return; }
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
@@ -2627,7 +2667,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     if (g_prof_on) {
         ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x3 ? 1129 : (use_x6 ? 1128 : bm), split};
         r.flops = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
-        r.mfma_flops = r.flops * (use_x3 ? 3.0 : (use_x6 ? 6.0 : 1.0));   // matrix instructions issued per fp32 multiply-add
+        r.mfma_flops = r.flops * (use_x3 ? (g_single_pass ? 1.0 : 3.0) : (use_x6 ? 6.0 : 1.0));   // matrix instructions issued per fp32 multiply-add
         g_rec.push_back(r);
     }
     prof_mark(stream);
@@ -2695,6 +2735,15 @@ static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t s
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
+    if (x3 && BN == 128 && g_single_pass) {   // ... its single-pass form (MODEL.COMPUTE_DTYPE: bf16 / fp16)
+        if (kind == 0)
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, true>), grid, dim3(768), 0, stream, a, items);
+        else if (kind == 1)
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, false, 1, 3, true>), grid, dim3(768), 0, stream, a, items);
+        else
+            hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, false, 0, 2, true>), grid, dim3(768), 0, stream, a, items);
+        return;
+    }
     if (x3 && BN == 128) {   // fp16x3 form of the gathering producers (128-wide tiles only)
         if (kind == 0)
             hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0>), grid, dim3(768), 0, stream, a, items);
@@ -2838,7 +2887,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     if (g_prof_on) {
         ProfRec r = {a.M, a.N, a.K, groups, a_kc, b_kc, conv_x3 ? 1129 : 1128, split};
         r.flops = fl;
-        r.mfma_flops = fl * (conv_x3 ? 3.0 : 6.0);
+        r.mfma_flops = fl * (conv_x3 ? (g_single_pass ? 1.0 : 3.0) : 6.0);
         g_rec.push_back(r);
     }
     prof_mark(stream);

@@ -48,9 +48,9 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x
+        x, idt = ops.fanout(x, 2)   # (two consumers: their gradients are summed in one pass, hipops.Fanout)
         if self.downsample is not None:
-            idt = _conv_bn(self.downsample[0], self.downsample[1], x)
+            idt = _conv_bn(self.downsample[0], self.downsample[1], idt)
         y = _conv_bn(self.conv1, self.bn1, x, relu=True)
         y = _conv_bn(self.conv2, self.bn2, y, relu=True)
         return _conv_bn(self.conv3, self.bn3, y, residual=idt, relu=True)
@@ -162,11 +162,12 @@ class TransformerEncoderLayer(nn.Module):
         self.dropout2 = Dropout(dropout)
 
     def forward(self, src, key_padding_mask, pos):
-        qk = ops.add(src, pos)
-        a = self.self_attn(qk, qk, src, key_padding_mask, qk_same=True)
-        src = self.norm1(ops.add_dropout(src, a, self.dropout1.p, self.dropout1.training))
-        f = self.linear2(ops.relu_dropout(self.linear1(src), self.dropout.p, self.dropout.training))
-        return self.norm2(ops.add_dropout(src, f, self.dropout2.p, self.dropout2.training))
+        s_qk, s_v, s_res = ops.fanout(src, 3)
+        qk = ops.add(s_qk, pos)
+        a = self.self_attn(qk, qk, s_v, key_padding_mask, qk_same=True)
+        s_ffn, s_res = ops.fanout(self.norm1(ops.add_dropout(s_res, a, self.dropout1.p, self.dropout1.training)), 2)
+        f = self.linear2(ops.relu_dropout(self.linear1(s_ffn), self.dropout.p, self.dropout.training))
+        return self.norm2(ops.add_dropout(s_res, f, self.dropout2.p, self.dropout2.training))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -188,15 +189,17 @@ class TransformerDecoderLayer(nn.Module):
         """tgt [n,Q,E]; memory_key = memory + pos (shared by all layers); query_pos [Q*E] broadcast over frames, or
         [episodes, Q*E] (one learned query table per episode's fast weights, frames grouped by episode)."""
         n, Q, E = tgt.shape
-        groups = query_pos.shape[0] if query_pos.dim() == 2 else 1
-        qk = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
-        a = self.self_attn(qk, qk, tgt, None, qk_same=True)
-        tgt = self.norm1(ops.add_dropout(tgt, a, self.dropout1.p, self.dropout1.training))
-        q = ops.AddRowVec.apply(tgt.reshape(n, Q * E), query_pos, groups).reshape(n, Q, E)
+        qp1, qp2 = query_pos if isinstance(query_pos, tuple) else (query_pos, query_pos)
+        groups = qp1.shape[0] if qp1.dim() == 2 else 1
+        t_qk, t_v, t_res = ops.fanout(tgt, 3)
+        qk = ops.AddRowVec.apply(t_qk.reshape(n, Q * E), qp1, groups).reshape(n, Q, E)
+        a = self.self_attn(qk, qk, t_v, None, qk_same=True)
+        t_q, t_res = ops.fanout(self.norm1(ops.add_dropout(t_res, a, self.dropout1.p, self.dropout1.training)), 2)
+        q = ops.AddRowVec.apply(t_q.reshape(n, Q * E), qp2, groups).reshape(n, Q, E)
         c = self.multihead_attn(q, memory_key, memory, memory_key_padding_mask)
-        tgt = self.norm2(ops.add_dropout(tgt, c, self.dropout2.p, self.dropout2.training))
-        f = self.linear2(ops.relu_dropout(self.linear1(tgt), self.dropout.p, self.dropout.training))
-        return self.norm3(ops.add_dropout(tgt, f, self.dropout3.p, self.dropout3.training))
+        t_ffn, t_res = ops.fanout(self.norm2(ops.add_dropout(t_res, c, self.dropout2.p, self.dropout2.training)), 2)
+        f = self.linear2(ops.relu_dropout(self.linear1(t_ffn), self.dropout.p, self.dropout.training))
+        return self.norm3(ops.add_dropout(t_res, f, self.dropout3.p, self.dropout3.training))
 
 
 class TransformerEncoder(nn.Module):
@@ -220,15 +223,23 @@ class TransformerDecoder(nn.Module):
         self.norm = LayerNorm(d_model) if norm else None
 
     def forward(self, tgt, memory, memory_key_padding_mask, pos, query_pos):
+        L = len(self.layers)
+        # the memory feeds every layer's cross-attention (as value, and + pos as key), the learned queries two adds per layer:
+        # one gradient sum each at the end of the backward instead of a chain of two-operand adds (hipops.Fanout)
         if pos is None:
-            memory_key = memory
-        elif pos.shape[0] == 1 and memory.shape[0] > 1:   # one fixed position table shared by a batch of sequences
-            b = memory.shape[0]
-            memory_key = ops.AddRowVec.apply(memory.reshape(b, -1), pos.reshape(-1), 1).reshape(memory.shape)
+            mems = ops.fanout(memory, 2 * L)
+            keys, mems = mems[:L], mems[L:]
         else:
-            memory_key = ops.add(memory, pos)
-        for layer in self.layers:
-            tgt = layer(tgt, memory, memory_key, memory_key_padding_mask, query_pos)
+            mems = ops.fanout(memory, L + 1)
+            if pos.shape[0] == 1 and memory.shape[0] > 1:   # one fixed position table shared by a batch of sequences
+                b = memory.shape[0]
+                memory_key = ops.AddRowVec.apply(mems[L].reshape(b, -1), pos.reshape(-1), 1).reshape(memory.shape)
+            else:
+                memory_key = ops.add(mems[L], pos)
+            keys = ops.fanout(memory_key, L)
+        qps = ops.fanout(query_pos, 2 * L)
+        for i, layer in enumerate(self.layers):
+            tgt = layer(tgt, mems[i], keys[i], memory_key_padding_mask, (qps[2 * i], qps[2 * i + 1]))
         # return_intermediate=True in the reference, but only hs[-1] is consumed (detr.py:69): norm the last output
         return self.norm(tgt) if self.norm is not None else tgt
 
@@ -246,10 +257,10 @@ class Transformer(nn.Module):
     def forward(self, src, mask, query_embed, pos):
         n, hw, E = src.shape
         Q = query_embed.shape[-2]
-        memory = self.encoder(src, mask, pos)
+        memory, m_dec = ops.fanout(self.encoder(src, mask, pos), 2)   # (the caller's copy and the decoder's)
         tgt = torch.zeros(n, Q, E, device=src.device, dtype=torch.float32)
         qe = query_embed.reshape(Q * E) if query_embed.dim() == 2 else query_embed.reshape(-1, Q * E)
-        hs = self.decoder(tgt, memory, mask, pos, qe)
+        hs = self.decoder(tgt, m_dec, mask, pos, qe)
         return hs, memory
 
 
@@ -293,9 +304,10 @@ class DETR(nn.Module):
         n, h, w, c = feat.shape
         src = self.input_proj(feat.reshape(n, h * w, c))
         hs, memory = self.transformer(src, mask.reshape(n, h * w), self.query_embed.weight, pos)
+        h_cls, h_box, hs = ops.fanout(hs, 3)
         return {
-            "pred_logits": self.class_embed(hs),
-            "pred_boxes": ops.Sigmoid.apply(self.bbox_embed(hs)),
+            "pred_logits": self.class_embed(h_cls),
+            "pred_boxes": ops.Sigmoid.apply(self.bbox_embed(h_box)),
             "image_features": feat.permute(0, 3, 1, 2),
             "embedded_memory_features": memory.reshape(n, h, w, -1).permute(0, 3, 1, 2),
             "box_features": hs,

@@ -67,9 +67,10 @@ class Block(nn.Module):
 
     def forward(self, x):
         # x + dropout(branch) as one pass each (reference gpt.py:75-77; the dropouts are attn.resid_drop and mlp[3])
-        x = ops.add_dropout(x, self.attn(self.ln1(x)), self.attn.resid_drop.p, self.attn.resid_drop.training)
+        x, r = ops.fanout(x, 2)   # (branch + residual: one gradient sum, hipops.Fanout)
+        x, r = ops.fanout(ops.add_dropout(r, self.attn(self.ln1(x)), self.attn.resid_drop.p, self.attn.resid_drop.training), 2)
         m = self.mlp[2](self.mlp[1](self.mlp[0](self.ln2(x))))
-        return ops.add_dropout(x, m, self.mlp[3].p, self.mlp[3].training)
+        return ops.add_dropout(r, m, self.mlp[3].p, self.mlp[3].training)
 
 
 class GPT(nn.Module):
@@ -108,10 +109,11 @@ def _token_inputs(mod, x):
 
 
 def _decode(mod, y_preds, y_actions):
-    return {"seq": y_preds.squeeze(),
-            "pred_boxes": ops.Sigmoid.apply(mod.box_decoder(y_preds)).squeeze(),
-            "pred_logits": mod.logit_decoder(y_preds).squeeze(),
-            "loss": mod.loss_decoder(y_preds),
+    y_seq, y_box, y_logit, y_loss = ops.fanout(y_preds, 4)
+    return {"seq": y_seq.squeeze(),
+            "pred_boxes": ops.Sigmoid.apply(mod.box_decoder(y_box)).squeeze(),
+            "pred_logits": mod.logit_decoder(y_logit).squeeze(),
+            "loss": mod.loss_decoder(y_loss),
             "actions": mod.action_decoder(y_actions).squeeze()}
 
 

@@ -205,9 +205,11 @@ def _wants_graph(model, E, shape):
         return False
     if mode in (True, "true", "on", "1", 1):
         return True
-    # auto: small chunks are bound by the host issuing the launches; large ones are GPU-bound and a private pool would
-    # only double their memory
-    return E * shape[1] * shape[2] <= 4 * 300 * 300
+    # auto: small chunks are bound by the host issuing the launches; the reference batch of 16 x 300^2 episodes is GPU-bound but
+    # still gains 2.7 % from a replay (no launch gaps, the first-order branch beside the second-order backward: 262.3 -> 255.3
+    # ms, r4e; the pools REUSE the 58 GB the eager warm-up step has freed).  Larger chunks (800 x 800: 19 GB per episode)
+    # would need the eager step's cached memory and the pools' at once
+    return E * shape[1] * shape[2] <= 16 * 300 * 300
 
 
 def chunk_runner(model, E, s, shape, ldn, ldn1):

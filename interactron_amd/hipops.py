@@ -378,21 +378,26 @@ class Gemm(Function):
         fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
                 and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
                 and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
-        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, need_a, need_b and not fuse)
+        # (recorded backward: dC feeds up to three nodes -- one alias each, so that ITS gradient is one sum, Fanout)
+        dcs = list(fanout(dc, int(need_a) + int(need_b) + int(need_bias and not fuse)))
+        da, db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, need_a, need_b and not fuse, dcs)
         dbias = None
         if fuse:
             s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
                          View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
-            db, dbias = GemmRowsum.call(dc, a, s, ctx.bias_groups)
+            db, dbias = GemmRowsum.call(dcs.pop(), a, s, ctx.bias_groups)
         elif need_bias:
-            dbias = ColSum.call(dc.reshape(ctx.bias_groups, -1, sp.N) if ctx.bias_groups else dc.reshape(-1, sp.N))
+            d = dcs.pop()
+            dbias = ColSum.call(d.reshape(ctx.bias_groups, -1, sp.N) if ctx.bias_groups else d.reshape(-1, sp.N))
         return da, db, dbias, None
 
 
-def _gemm_backward(sp, a, b, a_shape, b_shape, dc, need_a, need_b):
-    """Gradients of C = alpha A B w.r.t. the storage of A and of B (each again one strided contraction)."""
+def _gemm_backward(sp, a, b, a_shape, b_shape, dc, need_a, need_b, dcs=None):
+    """Gradients of C = alpha A B w.r.t. the storage of A and of B (each again one strided contraction).  `dcs`: aliases of dC
+    to consume, one per node (hipops.fanout), or None."""
     da = db = None
     if need_a:
+        dc = dcs.pop() if dcs else dc
         if not sp.A.trans:   # dA (MxK) = alpha * dC (MxN) * B^T (NxK)
             s = GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B),
                          View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
@@ -402,6 +407,7 @@ def _gemm_backward(sp, a, b, a_shape, b_shape, dc, need_a, need_b):
                          View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
             da = Gemm.call(b, dc, None, s)
     if need_b:
+        dc = dcs.pop() if dcs else dc
         if not sp.B.trans:   # dB (KxN) = alpha * A^T (KxM) * dC (MxN)
             s = GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C,
                          View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha)
@@ -737,11 +743,32 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
 
 
 def contraction_form():
-    """1 = fp16x3 form of the 12-wave contraction kernel, 0 = bf16x6 (ix_gemm_set_x3 / IX_GEMM_KERNEL)"""
+    """1 = fp16x3 form of the 12-wave contraction kernel, 0 = bf16x6 (ix_gemm_set_x3 / IX_GEMM_KERNEL); + 2 in the
+    single-pass 16-bit mode (a captured graph must not replay another form: episode._graph_stamp)"""
     lib = _L()
     cur = lib.ix_gemm_set_x3(1)
     lib.ix_gemm_set_x3(cur)
-    return cur
+    return cur + (2 if COMPUTE_DTYPE != "f32" else 0)
+
+
+# MODEL.COMPUTE_DTYPE (BASELINE.json configs[1]: "multi_frame_baseline ... bf16").  "f32" (default): every contraction is
+# fp32-grade (three fp16 / six bf16 matrix instructions per product) -- the parity path and every headline number.
+# "bf16" / "fp16": the 16-bit SINGLE-PASS mode -- contractions round each operand once to 16 bits (an fp16 value of
+# x * 2^-E with one exponent per 32 x 32 sub-block: 11 significant bits, i.e. bf16's accuracy or better, and fp32's
+# range) and issue ONE matrix instruction per k-slice with fp32 accumulation; activations stay fp32 in HBM, LayerNorm /
+# softmax statistics and the attention core stay fp32-grade.  Process-global (like the kernel-form switches).
+COMPUTE_DTYPE = "f32"
+
+
+def set_compute_dtype(name):
+    global COMPUTE_DTYPE
+    name = {"float32": "f32", "fp32": "f32", "f32": "f32", "bf16": "bf16", "bfloat16": "bf16", "fp16": "bf16", "half": "bf16",
+            "f16": "bf16"}.get(str(name).lower())
+    if name is None:
+        raise ValueError("MODEL.COMPUTE_DTYPE must be f32, bf16 or fp16")
+    _chk(0 if _L().ix_gemm_set_single_pass(1 if name == "bf16" else 0) in (0, 1) else 1, "ix_gemm_set_single_pass")
+    old, COMPUTE_DTYPE = COMPUTE_DTYPE, name
+    return old
 
 
 def attn_split_multi(ops, n, H, hd, tr_form=None):
@@ -1048,6 +1075,62 @@ class Axpby(Function):
 
 def add(a, b):
     return Axpby.call(a, b, 1.0, 1.0)
+
+
+# ---- tensors with several consumers --------------------------------------------------------------------------------------
+# The autograd engine sums the gradients of a tensor that feeds n nodes with n - 1 two-operand aten::add launches (each
+# reads two tensors and writes one): 800 launches / 13 ms of a 16-episode step were the last stock kernels on the path.
+# `fanout(x, n)` hands out n aliases of x whose gradients come back TOGETHER and are summed by one hand-written pass
+# (ix_sum_n_f32: n reads, one write, left to right).  Closed under differentiation: the sum's own backward hands its
+# cotangent to every operand, no kernel.
+FANOUT = os.environ.get("IX_FANOUT", "1") == "1"   # "0": plain aliases, autograd sums (A/B runs)
+
+
+def sum_n(tensors):
+    """((t0 + t1) + t2) + ... over 2..8 tensors of one shape, one launch; longer lists in groups of 8"""
+    ts = [_req(t) for t in tensors]
+    while len(ts) > 1:
+        head, ts = ts[:8], ts[8:]
+        if len(head) == 1:
+            ts.insert(0, head[0])
+            break
+        out = torch.empty_like(head[0])
+        arr = (ctypes.c_void_p * len(head))(*[t.data_ptr() for t in head])
+        _chk(_L().ix_sum_n_f32(arr, len(head), out.data_ptr(), out.numel(), _stream()), "ix_sum_n_f32")
+        ts.insert(0, out)
+    return ts[0]
+
+
+class SumN(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        assert all(x.shape == xs[0].shape for x in xs), [tuple(x.shape) for x in xs]
+        return sum_n(xs)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g if need else None for need in ctx.needs_input_grad)
+
+
+class Fanout(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        return (gs[0] if len(gs) == 1 else SumN.call(*gs)), None
+
+
+def fanout(x, n):
+    """n aliases of x for n consumers (x itself n times when nothing is recorded or x needs no gradient)"""
+    if n <= 1 or not FANOUT or not torch.is_grad_enabled() or not x.requires_grad:
+        return (x,) * n
+    return Fanout.apply(x, n)
 
 
 class Scale(Function):

@@ -680,6 +680,45 @@ def test_f16x3_kernel_is_fp32_grade(ops, akc, bkc):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_single_pass_contraction_is_16_bit_grade(ops, akc, bkc):
+    """MODEL.COMPUTE_DTYPE: bf16 / fp16 (ix_gemm_set_single_pass): the h plane of the fp16x3 form alone, one MFMA per k-slice.
+    Stated accuracy: every operand rounded once to 11 significant bits under its 32 x 32 sub-block's exponent, fp32
+    accumulation => |C - C64| <= 1e-3 sum|a||b| (bf16's 8 bits would give 8e-3); and the mode must really be on (an error
+    well above the fp32-grade kernel's), switch back afterwards, and keep fp32's RANGE (rows spread over e^+-8)."""
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    # (shapes the cost model gives 128-wide tiles of the fp16x3 form: narrower problems stay on the bf16x6 / exact-fp32 kernels,
+    #  i.e. fp32-grade, in this mode too)
+    for (M, N, K, b, split, kind) in [(384, 256, 512, 2, 1, "plain"), (300, 260, 1808, 2, 3, "plain"), (1804, 512, 260, 1, 1, "rows")]:
+        a, w = rnd(b, M, K, seed=1), rnd(b, K, N, seed=3)
+        if kind == "rows":
+            a = a * (2.0 * rnd(b, M, 1, seed=2)).exp()
+            w = w * (2.0 * rnd(b, 1, N, seed=5)).exp()
+        a, w = a.cuda(), w.cuda()
+        bias = rnd(N, seed=4).cuda()
+        ref = 0.75 * (a.double() @ w.double()) + bias.double()
+        scale = 0.75 * (a.double().abs() @ w.double().abs()) + bias.double().abs() + 1e-300
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        errs = {}
+        for single in (1, 0):
+            old_form, old = lib.ix_gemm_set_x3(1), lib.ix_gemm_set_single_pass(single)
+            try:
+                C = torch.full((b, M, N), float("nan"), device="cuda")
+                rc = lib.ix_gemm_f32(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc,
+                                     K if akc else M, K if bkc else N, N, b, 1, M * K, 0, K * N, 0, M * N, 0, 0, 0.75, 1128,
+                                     split, stream)
+                assert rc == 0, lib.ix_last_error()
+                errs[single] = float(((C.double() - ref).abs() / scale).max())
+            finally:
+                lib.ix_gemm_set_single_pass(old)
+                lib.ix_gemm_set_x3(old_form)
+        assert errs[1] <= 1e-3, (M, N, K, kind, errs)
+        assert errs[1] >= 1e-5 and errs[0] <= 6e-7, (M, N, K, kind, errs)   # the switch switches, and switches back
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     """The pre-split fp16x3 route of ix_gemm_f32_ws (two fp16 planes + one power-of-two scale per 32 rows, three fp16 MFMA
     terms) against float64: every operand layout, ragged M/N/K, batches, shared operands (stride 0), bias, alpha, the

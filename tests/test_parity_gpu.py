@@ -349,6 +349,14 @@ def test_g11_g12_predict_and_next_action(golden, interactron_model, episode1):
 # sample, HIP 2.7 %; it was 1.7 % before the round-3 retune of the tile / split plans -- another summation order), every
 # other tensor below 3e-3.  The worst three are printed.
 F64_SLACK = {"x6": (2e-3, 1e-3), "x3": (6e-3, 3e-2)}
+# ... and that looser fp16x3 bound may only be USED by kink tensors: every tensor but at most F64_KINK_TENSORS of them must
+# meet F64_TIGHT (norm, strided sample) in either form.  Round 4 looked for the cause (profiles/README.md): the outliers are
+# backbone weights of the second-order pass (layer4.0.conv3 2.6 %, layer3.0.conv2 1.9 % of the sample's scale, the
+# reference's own float32 0.7 % on both) and they do NOT move when the convolutions' weight-gradient contractions run on
+# the bf16x6 form (24-bit operands) -- the difference is upstream: single elements whose ReLU mask / clipped inner step
+# flips under another rounding, not the operand precision of one contraction.  Third-worst tensor: below 1e-5.
+F64_TIGHT = (3e-3, 5e-3)
+F64_KINK_TENSORS = 2
 
 
 def test_g13_g16_meta_train_step_and_outer_update(golden, kernel_form):
@@ -400,6 +408,9 @@ def test_g13_g16_meta_train_step_and_outer_update(golden, kernel_form):
               "reference error %.2e" % ((name,) + ex[0] + (sorted(e[1] for e in ex)[len(ex) // 2], sorted(e[2] for e in ex)[len(ex) // 2])))
     assert ex_norm[0][0] <= F64_SLACK[kernel_form][0], ex_norm[:3]
     assert ex_samp[0][0] <= F64_SLACK[kernel_form][1], ex_samp[:3]
+    loose = {e[3] for e in ex_norm if e[0] > F64_TIGHT[0]} | {e[3] for e in ex_samp if e[0] > F64_TIGHT[1]}
+    assert len(loose) <= F64_KINK_TENSORS, ("more than %d tensors need the loose bound" % F64_KINK_TENSORS, sorted(loose))
+    assert all("backbone" in k for k in loose), sorted(loose)
     labels = {k: v.get_label(data["actions"][0][:4].tolist()) for k, v in m.path_storage.items()}
     assert labels == T["g13"]["path_labels"]
     # G16: clip_grad_norm_(all, 1.0) + Adam(detector, 1e-5) + Adam(fusion, 1e-4) as one fused flat-buffer step
@@ -713,6 +724,53 @@ def test_config2_multiframe(golden, episode1):
     for k, p in m.fusion.named_parameters():
         check_grad(O["multiframe_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="mf/fusion." + k,
                    norm64=F64["fusion_grads"].get(k))
+
+
+def test_config2_multiframe_single_pass_16_bit(golden, episode1):
+    """BASELINE.json configs[1] (multi_frame_baseline ... bf16): MODEL.COMPUTE_DTYPE bf16 -- contractions in the single-pass
+    16-bit mode (hipops.set_compute_dtype) -- against the reference's fp32 recording at SURVEY 8d's bf16 tolerances: logits
+    within 3e-2, boxes within 5e-3 (absolute), losses 2 %, the Hungarian assignments the reference's up to proven ties (ReferenceMatching:
+    equal optimum to 1e-4), gradient norms of the trained networks within 5 %.  Reference arithmetic: models/gpt.py:39-57, models/detr_multiframe.py:55-109."""
+    from interactron_amd import hipops
+    O = golden("golden_configs.pt")
+    old = hipops.set_compute_dtype("bf16")
+    try:
+        m = make("detr_multiframe")
+        pred = m.predict(episode1)
+        for k, tol in (("pred_logits", 3e-2), ("pred_boxes", 5e-3)):
+            rec = O["multiframe_predict"][k]
+            got = pred[k].detach().cpu()
+            if "full" in rec:
+                err = float((got - rec["full"]).abs().max())
+            else:
+                err = float((got.reshape(-1)[rec["idx"]] - rec["sample"]).abs().max())
+            print("single-pass 16-bit, predict %s: max abs error %.2e (bound %.0e)" % (k, err, tol))
+            assert err <= tol, (k, err)
+        m.zero_grad()
+        # (every difference from the reference's assignment is still PROVEN a tie -- equal optimum to 1e-4 under this path's own
+        #  cost matrix; 16-bit noise just decides more of the RNG-free weights' ties the other way: no cap on their number)
+        with ReferenceMatching(golden("golden_indices.pt")["multiframe_forward"], max_flip_share=1.0) as rm:
+            preds, losses = m(episode1)
+        print("single-pass 16-bit: %d of %d images matched differently from the reference's recording (proven ties)" % (rm.flips, rm.calls))
+        for k, v in O["multiframe_forward"]["losses"].items():
+            assert abs(float(losses[k]) - float(v)) <= 2e-2 * max(abs(float(v)), 1.0), (k, float(losses[k]), float(v))
+        worst = (0.0, "")
+        for grp, mod in (("detector", m.detector), ("fusion", m.fusion)):
+            for k, p in mod.named_parameters():
+                rec = O["multiframe_forward"][grp + "_grads"][k]
+                if rec is None:
+                    assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                    continue
+                n = float(p.grad.double().norm())
+                if max(n, rec["norm"]) < 1e-6:
+                    continue
+                rel = abs(n - rec["norm"]) / rec["norm"]
+                worst = max(worst, (rel, grp + "." + k))
+        print("single-pass 16-bit, worst gradient-norm deviation %.2e on %s" % worst)
+        assert worst[0] <= 5e-2, worst
+    finally:
+        hipops.set_compute_dtype(old)
+    assert hipops.COMPUTE_DTYPE == "f32"
 
 
 @pytest.mark.usefixtures("kernel_form")
