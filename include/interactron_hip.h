@@ -73,6 +73,23 @@ int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64
  * figure a PMC traffic measurement of the same launches is to be compared with (SURVEY 8d / bench.py roofline). */
 int ix_prof_contraction_bytes(double* bytes3);
 
+/* ---- "activation x weight planes" contraction (csrc/gemm_wp.hip): C[b] = alpha A[b] W[b]^T (+ bias) with the WEIGHT converted
+ * once into the kernel's own LDS image (two fp16 planes of w 2^-E, one exponent per 32 output rows) and streamed by the
+ * LDS-DMA path, the activation split in the consumers' registers -- what nn.Linear's forward and input gradient are
+ * (reference models/detr_models/transformer.py:148-232, models/gpt.py:39-78).  fp32-grade like the fp16x3 form of ix_gemm_f32.
+ *   ix_wp_planes_bytes : sizes of `planes` / `unscale` for a weight of N rows x K (nb batch slices)
+ *   ix_wp_split_f32    : W(n, k) = k_contig ? W[n ld + k] : W[k ld + n]  ->  planes, unscale (caller-owned device buffers)
+ *   ix_gemm_wp_f32     : A(m, k) = A[bo sAo + bi sAi + m lda + k], K % 32 == 0, 16-byte aligned rows; b_shared: one weight for
+ *                        every slice, else slice bo of the planes; C row-major at ldc; bias [N] per outer slice (sBias) or null */
+int ix_wp_planes_bytes(int N, int K, int nb, size_t* planes_bytes_host, size_t* unscale_bytes_host);
+int ix_wp_split_f32(const float* W, int64_t ld, int64_t batch_stride, int N, int K, int k_contig, int nb, void* planes,
+                    float* unscale, ix_stream_t stream);
+int ix_prof_wp(double* ms, double* flops, int64_t* launches); /* profiled launches of the weight-planes kernel (also in slot [2] of ix_prof_contractions) */
+int ix_gemm_wp_debug(int flags); /* diagnostic switches of tools/wp_bench.py (0 = off; the product never sets them) */
+int ix_gemm_wp_f32(const float* A, int64_t lda, int64_t sAo, int64_t sAi, const void* planes, const float* unscale, int b_shared,
+                   float* C, int64_t ldc, int64_t sCo, int64_t sCi, const float* bias, int64_t sBias, int M, int N, int K,
+                   int batch_outer, int batch_inner, float alpha, ix_stream_t stream);
+
 /* ix_gemm_rowsum_f32: C = alpha A B and, from the same launch, rowsum[bo * rowsum_stride + m] = sum_k A(m, k).  With A
  * stored m-contiguous (a_kcontig = 0) the bf16x6 kernel's A-producer waves accumulate the sums from the tiles they stream
  * anyway: the bias gradient colsum(dy) of a Linear rides on its weight-gradient contraction dW = dy^T x (reference:

@@ -36,6 +36,7 @@ extern const uint64_t* ix_g_salt;
 // launch statistics / per-launch HIP-event brackets shared by the contraction and attention kernels (gemm.hip)
 void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops, int tag);
 void ix_prof_end(hipStream_t stream);
+void ix_prof_begin_wp(hipStream_t stream, int M, int N, int K, int nbatch);
 
 static inline int ix_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

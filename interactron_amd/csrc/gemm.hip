@@ -2095,7 +2095,7 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
         const ProfRec& r = g_rec[i / 2];
         if (r.bm == 3128) continue;   // pre-split fp16x3 kernel: reported by ix_prof_x3
-        const int k = r.bm == 2002 ? 2 : ((r.bm == 1128 || r.bm == 1129) ? 1 : 0);
+        const int k = r.bm == 2002 ? 2 : ((r.bm == 1128 || r.bm == 1129 || r.bm == 1131) ? 1 : 0);
         ms[k] += t;
         fl[k] += r.flops;
         n[k] += 1;
@@ -2120,7 +2120,7 @@ extern "C" int ix_prof_contractions(double* ms3, double* flops3, double* mfma_fl
         hipEventSynchronize(g_ev[i + 1]);
         float t = 0.f;
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
-        const int k = r.bm == 1129 ? 2 : (r.bm == 1128 ? 1 : 0);
+        const int k = (r.bm == 1129 || r.bm == 1131) ? 2 : (r.bm == 1128 ? 1 : 0);
         ms[k] += t; fl[k] += r.flops; mf[k] += r.mfma_flops > 0 ? r.mfma_flops : r.flops; n[k] += 1;
     }
     for (int k = 0; k < 3; ++k) {
@@ -2138,7 +2138,7 @@ extern "C" int ix_prof_contraction_bytes(double* bytes3) {
     for (size_t i = 0; i / 2 < g_rec.size() && i + 1 < g_ev_used; i += 2) {
         const ProfRec& r = g_rec[i / 2];
         if (r.bm == 2002 || r.bm == 3128) continue;
-        const int k = r.bm == 1129 ? 2 : (r.bm == 1128 ? 1 : 0);
+        const int k = (r.bm == 1129 || r.bm == 1131) ? 2 : (r.bm == 1128 ? 1 : 0);
         by[k] += 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N) * (double)(r.nbatch > 0 ? r.nbatch : 1);
     }
     for (int k = 0; k < 3; ++k)
@@ -2241,6 +2241,38 @@ void ix_prof_begin(hipStream_t stream, int kind, double flops, double mfma_flops
     prof_mark(stream);
 }
 void ix_prof_end(hipStream_t stream) { prof_mark(stream); }
+// ... and for the activation x weight-planes contraction kernel (csrc/gemm_wp.hip): a contraction like the others (counted by
+// ix_gemm_stats; tile code 1131; the fp16x3 form's arithmetic: three matrix instructions per fp32 multiply-add)
+void ix_prof_begin_wp(hipStream_t stream, int M, int N, int K, int nbatch) {
+    const double fl = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+    g_flops += fl;
+    g_launches += 1;
+    if (!g_prof_on) return;
+    ProfRec r = {M, N, K, nbatch, 1, 1, 1131, 1};
+    r.flops = fl;
+    r.mfma_flops = 3.0 * fl;
+    g_rec.push_back(r);
+    prof_mark(stream);
+}
+
+// Profiled launches of the weight-planes kernel alone (they are ALSO part of slot [2], the fp16x3 arithmetic, of
+// ix_prof_contractions): summed event time (ms), algorithmic FLOPs, launches.  Call before ix_gemm_prof_read.
+extern "C" int ix_prof_wp(double* ms, double* flops, int64_t* launches) {
+    double m = 0, f = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm != 1131) continue;
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        m += t; f += r.flops; n += 1;
+    }
+    if (ms) *ms = m;
+    if (flops) *flops = f;
+    if (launches) *launches = n;
+    return IX_OK;
+}
 
 // ---- tile / split-K plan ------------------------------------------------------------------------------------------
 // Tile / split-K selection by a small cost model (cycles on the most loaded CU).  The MFMA pipes of a CU are the

@@ -1,0 +1,387 @@
+// fp32-grade GEMM "activation x WEIGHT PLANES" on the fp16 matrix cores -- the third contraction kernel behind the Linear
+// layers (reference call sites: nn.Linear of models/detr_models/transformer.py:148-232, models/gpt.py:39-78, detr.py:37-40,
+// 299-311 and the input gradients autograd derives from them).
+//
+//   C[b](M x N) = alpha * A[b](M x K) * W[b](N x K)^T (+ bias[n])        A fp32, k-contiguous rows;  W = a weight
+//
+// Why a third kernel.  The 12-wave kernel (gemm.hip) converts BOTH fp32 operands to fp16 planes on the fly, in eight
+// producer waves, once per output tile they feed; a K step of 32 takes it ~2000 clocks of which the matrix pipe is busy 768
+// (profiles/r3i_gemm_x3_diag_bounds.txt: the producers' load -> scale -> convert -> LDS chain and the 12-wave barrier).  A
+// WEIGHT is read by every row tile of every contraction that uses it, several times per step (forward, input gradient,
+// their second-order twins): it is converted ONCE here (ix_wp_split_f32: two fp16 planes of w * 2^-E with one exponent per
+// 32 output rows, stored as the very LDS image the kernel wants) and then streamed HBM -> LDS by the DMA path
+// (global_load_lds, 16 bytes per lane, no registers, no VALU).  The ACTIVATION operand also goes HBM -> LDS by DMA, raw
+// fp32, and is split into (h, l) fp16 planes in the CONSUMER's registers right before the MFMAs that use it (two
+// v_fma_mix*_f16 per element: h = fp16(x 2^-E), l = fp16(x 2^-E - h), E per 32 x 32 sub-block, monotone along K as in the
+// 12-wave kernel's fp16x3 form).  No producer waves, no conversion chain across a barrier: 4 waves of 64 x 64 outputs per
+// 128 x 128 tile, 64 KB of LDS, two workgroups per CU covering each other's barrier.
+//
+// Arithmetic = the fp16x3 form's: x = (h + l) 2^E, three products l.h + h.l + h.h on v_mfma_f32_32x32x16_f16, fp32
+// accumulation; dropped l.l = 2^-22 relative.  The weight's exponent is per 32 rows over ALL of K (weights are homogeneous
+// along K; an element is resolved to 2^-25 of its 32-row slab's maximum), the activation's per 32 x 32 sub-block.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WP_BM = 128, WP_BN = 128, WP_BK = 32;
+constexpr int WP_A_BYTES = WP_BM * WP_BK * 4;          // raw fp32 image of the A tile: 128 rows x 128 B
+constexpr int WP_B_BYTES = 2 * WP_BN * WP_BK * 2;      // two fp16 planes of the W tile: 2 x 128 rows x 64 B
+constexpr int WP_STAGE = WP_A_BYTES + WP_B_BYTES;      // 32 KB
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight planes.  W(n, k), n < N, k < K, from fp32 storage  b_kc ? W[n * ld + k] : W[k * ld + n]  ->
+//   planes  [nb][tiles_n][KT][plane h, l][128 rows][64 bytes]   (tile images: rows of 32 fp16, the four 16-byte chunks of a
+//            row XOR-swizzled with bits 2-3 of the row -- the layout the consumers' ds_read_b128 wants, conflict-free)
+//   unscale [nb][tiles_n * 4]   float 2^E per 32-row block: w = (h + l) * unscale
+// One workgroup per (32-row block, batch slice): pass 1 finds the block's largest magnitude over all K, pass 2 re-reads the
+// slab (L2) and converts.  Rows past N and k past K are written as zeros (tiles are complete).
+// ------------------------------------------------------------------------------------------------------------
+template <bool KC>
+__global__ __launch_bounds__(256) void wp_split_kernel(const float* __restrict__ W, int64_t ld, int64_t sb, int N, int K, int KT,
+                                                       int tiles_n, unsigned char* __restrict__ planes, float* __restrict__ unscale,
+                                                       bool vec) {
+    __shared__ float red[4];
+    __shared__ float tile[32][33];
+    const int tid = threadIdx.x, rb = blockIdx.x, r0 = rb * 32, b = blockIdx.y;
+    const float* base = W + (int64_t)b * sb;
+    // KC: thread = (row tid / 8, four consecutive k at 4 * (tid % 8));  !KC: thread = (k line tid / 8, four consecutive rows)
+    const int hi = tid >> 3, lo4 = (tid & 7) * 4;
+    auto load4 = [&](int kt) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KC) {
+            const int r = r0 + hi, k = kt * 32 + lo4;
+            if (r < N && k < K) {
+                const float* p = base + (int64_t)r * ld + k;
+                if (vec && k + 3 < K) v = *reinterpret_cast<const float4*>(p);
+                else { v.x = p[0]; if (k + 1 < K) v.y = p[1]; if (k + 2 < K) v.z = p[2]; if (k + 3 < K) v.w = p[3]; }
+            }
+        } else {
+            const int k = kt * 32 + hi, r = r0 + lo4;
+            if (k < K && r < N) {
+                const float* p = base + (int64_t)k * ld + r;
+                if (vec && r + 3 < N) v = *reinterpret_cast<const float4*>(p);
+                else { v.x = p[0]; if (r + 1 < N) v.y = p[1]; if (r + 2 < N) v.z = p[2]; if (r + 3 < N) v.w = p[3]; }
+            }
+        }
+        return v;
+    };
+    float mx = 0.f;
+    for (int kt = 0; kt < KT; ++kt) {
+        const float4 v = load4(kt);
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    mx = ix_block_max_256(mx, red);
+    const unsigned e = (__float_as_uint(mx) >> 23) & 0xffu;
+    const bool tiny = e < 16u || e > 250u;                               // zero / denormal / inf block: unscaled
+    const float sc = tiny ? 1.f : __uint_as_float((268u - e) << 23);     // block maximum into [2^14, 2^15)
+    const float us = tiny ? 1.f : __uint_as_float((e - 14u) << 23);
+    if (tid == 0) unscale[(int64_t)b * (tiles_n * 4) + rb] = us;
+    const int tn = rb >> 2, rt = (rb & 3) * 32 + hi;                     // tile, row inside the tile (this thread's row)
+    unsigned char* out = planes + ((int64_t)b * tiles_n + tn) * (int64_t)KT * WP_B_BYTES;
+    for (int kt = 0; kt < KT; ++kt) {
+        float4 v = load4(kt);
+        if (!KC) {   // [k line][4 rows] -> [row][4 k] through LDS
+            __syncthreads();
+            tile[hi][lo4] = v.x; tile[hi][lo4 + 1] = v.y; tile[hi][lo4 + 2] = v.z; tile[hi][lo4 + 3] = v.w;
+            __syncthreads();
+            v.x = tile[lo4][hi]; v.y = tile[lo4 + 1][hi]; v.z = tile[lo4 + 2][hi]; v.w = tile[lo4 + 3][hi];
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        f32x2 x0, x1;
+        x0.x = v.x * sc; x0.y = v.y * sc; x1.x = v.z * sc; x1.y = v.w * sc;
+        const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
+        const f32x2 b0 = __builtin_convertvector(h0, f32x2), b1 = __builtin_convertvector(h1, f32x2);
+        f32x2 q0, q1;
+        q0.x = x0.x - b0.x; q0.y = x0.y - b0.y; q1.x = x1.x - b1.x; q1.y = x1.y - b1.y;
+        const f16x2 l0 = __builtin_convertvector(q0, f16x2), l1 = __builtin_convertvector(q1, f16x2);
+        // four k = lo4 .. lo4 + 3 of row rt: 8 bytes at chunk lo4 / 8 (swizzled), byte (lo4 % 8) * 2 inside it
+        unsigned char* dst = out + (int64_t)kt * WP_B_BYTES + rt * 64 + ((((tid & 7) >> 1) ^ ((rt >> 2) & 3)) << 4) + ((tid & 1) << 3);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+        *reinterpret_cast<uint2*>(dst + WP_BN * 64) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+    }
+}
+
+static inline int64_t wp_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+extern "C" int ix_wp_planes_bytes(int N, int K, int nb, size_t* planes_bytes, size_t* unscale_bytes) {
+    IX_CHECK_ARG(N > 0 && K > 0 && nb > 0 && planes_bytes && unscale_bytes, "ix_wp_planes_bytes: bad args");
+    const int64_t tn = wp_up(N, WP_BN) / WP_BN, KT = wp_up(K, WP_BK) / WP_BK;
+    *planes_bytes = (size_t)((int64_t)nb * tn * KT * WP_B_BYTES);
+    *unscale_bytes = (size_t)((int64_t)nb * tn * 4 * sizeof(float));
+    return IX_OK;
+}
+
+extern "C" int ix_wp_split_f32(const float* W, int64_t ld, int64_t batch_stride, int N, int K, int k_contig, int nb, void* planes,
+                               float* unscale, hipStream_t stream) {
+    IX_CHECK_ARG(W && planes && unscale && N > 0 && K > 0 && nb > 0, "ix_wp_split_f32: bad args");
+    IX_CHECK_ARG((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "ix_wp_split_f32: 16-byte aligned planes needed");
+    const bool vec = (reinterpret_cast<uintptr_t>(W) & 15) == 0 && ld % 4 == 0 && batch_stride % 4 == 0;   // else scalar loads
+    const int tn = (int)(wp_up(N, WP_BN) / WP_BN), KT = (int)(wp_up(K, WP_BK) / WP_BK);
+    const dim3 grid(tn * 4, nb);
+    if (k_contig)
+        hipLaunchKernelGGL(wp_split_kernel<true>, grid, dim3(256), 0, stream, W, ld, batch_stride, N, K, KT, tn, (unsigned char*)planes, unscale, vec);
+    else
+        hipLaunchKernelGGL(wp_split_kernel<false>, grid, dim3(256), 0, stream, W, ld, batch_stride, N, K, KT, tn, (unsigned char*)planes, unscale, vec);
+    IX_CHECK_LAUNCH("ix_wp_split_f32");
+    return IX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------------------------
+struct WpArgs {
+    const float* A;
+    const unsigned char* Bp;
+    const float* Bus;
+    float* C;
+    const float* bias;
+    int64_t lda, sAo, sAi, ldc, sCo, sCi, sBias, sBp;   // elements (sBp: bytes); sBp / sBus 0 = weight shared by all slices
+    int sBus;
+    int M, N, K, KT, tiles_m, tiles_n, batch_inner;
+    float alpha;
+    int dbg;   // tools/wp_bench.py only (ix_gemm_wp_debug): 1 no C stores, 2 no conversion / MFMA, 4 no DMA after the first stage
+};
+
+__device__ __forceinline__ int wp_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// 16 bytes per lane, global -> LDS, no registers (LDS-DMA): LDS address = lds (wave-uniform) + lane * 16; global address =
+// buffer base + voff (per lane) + soff (scalar: the K advance costs no vector instruction) + IMM
+template <int IMM>
+__device__ __forceinline__ void wp_dma16(__amdgpu_buffer_rsrc_t r, int voff, int soff, void* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, IMM, 0);
+}
+
+// (x0, x1) * sc -> packed fp16 pair h;  then l = fp16(x * sc - h), one rounding each (v_fma_mix*_f16 take fp32 and fp16 sources)
+__device__ __forceinline__ unsigned wp_cvt_h(float x0, float x1, float sc) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(d) : "v"(x0), "v"(x1), "v"(sc));
+    return d;
+}
+__device__ __forceinline__ unsigned wp_cvt_l(float x0, float x1, float sc, unsigned h) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(d) : "v"(x0), "v"(x1), "v"(sc), "v"(h));
+    return d;
+}
+
+// One LDS stage per workgroup (32 KB), at most 128 registers: FOUR workgroups per CU.  A workgroup's own K step is plainly
+// serial -- DMA the stage, wait, barrier, [read fragments, split A, 12 MFMAs] x 2 slices, barrier -- and the other three
+// workgroups of the CU fill every one of its waits (their DMA, conversion, MFMA and C-store phases interleave by themselves).
+// Measured on the 2-stage / 2-workgroup predecessor (tools/wp_bench.py d1..d7): loads, arithmetic and C stores of a tile each
+// took about a third of its time and did not overlap.
+__global__ __launch_bounds__(256, 4) void gemm_wp_kernel(WpArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WP_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, la = lane >> 5;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = wp_xcd_swizzle(blockIdx.x, nwg);
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (tile % group_size) % gm, tn = (tile % group_size) / gm;
+    const int m0 = tm * WP_BM, n0 = tn * WP_BN;
+    const int zb = blockIdx.y, bo = zb / p.batch_inner, bi = zb % p.batch_inner;
+    const float* A = p.A + bo * p.sAo + bi * p.sAi;
+    const unsigned char* Bt = p.Bp + (int64_t)bo * p.sBp + (int64_t)tn * p.KT * WP_B_BYTES;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // ---- DMA offsets of this lane: A pieces q = 4 wave .. 4 wave + 3 (8 rows x 128 B each), W pieces likewise ------------
+    // LDS slot of lane l in piece q = q * 64 + l: row = slot / 8, physical 16-byte chunk = slot % 8; it receives the LOGICAL chunk
+    // (phys ^ ((row >> 1) & 7)) of that row -- the swizzle the fragment reads below undo (conflict-free ds_read_b128)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bt, 0, p.KT * WP_B_BYTES, 0x00020000);
+    int va[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = (wave * 4 + q) * 64 + lane, row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
+        va[q] = (min(m0 + row, p.M - 1) * (int)p.lda + c * 4) * 4;
+    }
+    const int vb = wave * 4096 + lane * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int erun[2] = {-1000, -1000};   // running exponent of this wave's two A row blocks (wave-uniform)
+
+    // fragment addresses: A row (wm + 32 i + lr): logical 16-byte chunks 4 s + 2 la, + 1 of the 128-byte fp32 row;
+    // W row (wn + 32 j + lr): logical chunk 2 s + la of the 64-byte fp16 row
+    int offA[2], offB[2], swA[2], swB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm + 32 * i + lr;
+        offA[i] = row * 128;
+        swA[i] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = wn + 32 * j + lr;
+        offB[j] = WP_A_BYTES + row * 64;
+        swB[j] = (row >> 2) & 3;
+    }
+
+    const int nk = p.KT;
+    if ((p.dbg & 8) && (blockIdx.x + blockIdx.y * gridDim.x) < 1024) {   // experiment: de-phase the first round's workgroups
+        const int ph = ((blockIdx.x >> 3) & 3);
+        for (int t = 0; t < ph * (p.dbg >> 8); ++t) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt == 0 || !(p.dbg & 4)) {
+            unsigned char* dst = lds + wave * 4096;
+            wp_dma16<0>(rA, va[0], kt * 128, dst);
+            wp_dma16<0>(rA, va[1], kt * 128, dst + 1024);
+            wp_dma16<0>(rA, va[2], kt * 128, dst + 2048);
+            wp_dma16<0>(rA, va[3], kt * 128, dst + 3072);
+            // (the instruction's immediate offset advances the global AND the LDS address)
+            wp_dma16<0>(rB, vb, kt * WP_B_BYTES, dst + WP_A_BYTES);
+            wp_dma16<1024>(rB, vb, kt * WP_B_BYTES, dst + WP_A_BYTES);
+            wp_dma16<2048>(rB, vb, kt * WP_B_BYTES, dst + WP_A_BYTES);
+            wp_dma16<3072>(rB, vb, kt * WP_B_BYTES, dst + WP_A_BYTES);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        __syncthreads();                                    // everybody's have
+        if (!(p.dbg & 2)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // ---- A: raw fp32 fragments of this slice, sub-block (32 rows x 16 k) maximum, exponent, split into (h, l) ----
+                f32x4 xa[2][2];
+                u32x4 bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int o = offA[i] + (((4 * s + 2 * la) ^ swA[i]) << 4);
+                    xa[i][0] = *reinterpret_cast<const f32x4*>(lds + o);
+                    xa[i][1] = *reinterpret_cast<const f32x4*>(lds + (o ^ 16));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int o = offB[j] + (((2 * s + la) ^ swB[j]) << 4);
+                    bh[j] = *reinterpret_cast<const u32x4*>(lds + o);
+                    bl[j] = *reinterpret_cast<const u32x4*>(lds + o + WP_BN * 64);
+                }
+                u32x4 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float mx = 0.f;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xa[i][h].x), "v"(xa[i][h].y));
+                        asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(xa[i][h].z), "v"(xa[i][h].w));
+                    }
+                    // E only has to change when some value would leave [0, 2^15) under the running scale (wave vote); then the
+                    // sub-block maximum by DPP (no LDS), and the sums of this row block are brought to the new exponent, exactly
+                    const float lim = erun[i] <= -1000 ? 0.f : __uint_as_float((unsigned)(142 + erun[i]) << 23);   // 2^(15 + erun)
+                    if (__ballot(mx >= lim) != 0) {
+                        int mi = (int)__float_as_uint(mx);
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x111, 0xf, 0xf, false));
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x112, 0xf, 0xf, false));
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x114, 0xf, 0xf, false));
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x118, 0xf, 0xf, false));
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x142, 0xa, 0xf, false));
+                        mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x143, 0xc, 0xf, false));
+                        const int eb = (__builtin_amdgcn_readlane(mi, 63) >> 23) & 0xff;
+                        const int E = (eb < 16 || eb > 250) ? erun[i] : eb - 141;
+                        if (E > erun[i]) {
+                            const int d = max(erun[i] - E, -400);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_amdgcn_ldexpf(acc[i][j][r], d);
+                            erun[i] = E;
+                        }
+                    }
+                    const float sc = erun[i] <= -1000 ? 1.f : __uint_as_float((unsigned)(127 - erun[i]) << 23);
+                    const f32x4 v0 = xa[i][0], v1 = xa[i][1];
+                    u32x4 h, l;
+                    h.x = wp_cvt_h(v0.x, v0.y, sc); h.y = wp_cvt_h(v0.z, v0.w, sc); h.z = wp_cvt_h(v1.x, v1.y, sc); h.w = wp_cvt_h(v1.z, v1.w, sc);
+                    l.x = wp_cvt_l(v0.x, v0.y, sc, h.x); l.y = wp_cvt_l(v0.z, v0.w, sc, h.y);
+                    l.z = wp_cvt_l(v1.x, v1.y, sc, h.z); l.w = wp_cvt_l(v1.z, v1.w, sc, h.w);
+                    ah[i] = h; al[i] = l;
+                }
+                // ---- 3 terms x 4 blocks: smallest terms first ----
+#define WP_MM(FA, FB)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =            \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, FA[i]), __builtin_bit_cast(f16x8, FB[j]), acc[i][j], 0, 0, 0);
+                WP_MM(al, bh)
+                WP_MM(ah, bl)
+                WP_MM(ah, bh)
+#undef WP_MM
+            }
+        }
+        __syncthreads();   // the stage may be overwritten
+    }
+
+    // ---- epilogue: undo the exponents, alpha, bias; one 128-byte row segment per store instruction and half wave ----
+    if (p.dbg & 1) {
+        if (acc[0][0][0] == 12345.678f) p.C[0] = 1.f;   // (keeps the sums alive)
+        return;
+    }
+    const float* us = p.Bus + (int64_t)bo * p.sBus + tn * 4 + (wn >> 5);
+    float* C = p.C + bo * p.sCo + bi * p.sCi;
+    const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = max(erun[i], -400);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + lr;
+            if (col >= p.N) continue;
+            const float sc = p.alpha * us[j];
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * la;
+                if (row < p.M) C[(int64_t)row * p.ldc + col] = __builtin_amdgcn_ldexpf(acc[i][j][r], u) * sc + bv;
+            }
+        }
+    }
+}
+
+static int g_wp_dbg = 0;
+extern "C" int ix_gemm_wp_debug(int flags) {   // diagnostic (tools/wp_bench.py): what a tile's time is made of; wrong numbers when set
+    const int old = g_wp_dbg;
+    g_wp_dbg = flags;
+    return old;
+}
+
+// A(m, k) = A[bo * sAo + bi * sAi + m * lda + k] (fp32, K % 32 == 0, 16-byte aligned rows); weight planes / unscale from
+// ix_wp_split_f32 (batch slice bo, or one shared set: b_shared); C row-major [M, N] at ldc.
+extern "C" int ix_gemm_wp_f32(const float* A, int64_t lda, int64_t sAo, int64_t sAi, const void* planes, const float* unscale,
+                              int b_shared, float* C, int64_t ldc, int64_t sCo, int64_t sCi, const float* bias, int64_t sBias,
+                              int M, int N, int K, int batch_outer, int batch_inner, float alpha, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch_outer <= 0 || batch_inner <= 0) return IX_OK;
+    IX_CHECK_ARG(A && planes && unscale && C && K > 0 && K % WP_BK == 0, "ix_gemm_wp_f32: null operand or K %% 32 != 0");
+    IX_CHECK_ARG((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && sAo % 4 == 0 && sAi % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(planes) & 15) == 0,
+                 "ix_gemm_wp_f32: 16-byte aligned activation rows needed");
+    IX_CHECK_ARG((int64_t)M * lda * 4 < 0x7ffffff0ll, "ix_gemm_wp_f32: activation slice beyond 2 GB (32-bit DMA offsets)");
+    WpArgs a;
+    a.A = A; a.Bp = (const unsigned char*)planes; a.Bus = unscale; a.C = C; a.bias = bias;
+    a.lda = lda; a.sAo = sAo; a.sAi = sAi; a.ldc = ldc; a.sCo = sCo; a.sCi = sCi; a.sBias = sBias;
+    a.M = M; a.N = N; a.K = K; a.KT = K / WP_BK;
+    a.tiles_m = ix_div_up(M, WP_BM); a.tiles_n = ix_div_up(N, WP_BN);
+    a.sBp = b_shared ? 0 : (int64_t)a.tiles_n * a.KT * WP_B_BYTES;
+    a.sBus = b_shared ? 0 : a.tiles_n * 4;
+    a.batch_inner = batch_inner; a.alpha = alpha;
+    a.dbg = g_wp_dbg;
+    const dim3 grid(a.tiles_m * a.tiles_n, batch_outer * batch_inner);
+    ix_prof_begin_wp(stream, M, N, K, batch_outer * batch_inner);
+    hipLaunchKernelGGL(gemm_wp_kernel, grid, dim3(256), 0, stream, a);
+    ix_prof_end(stream);
+    IX_CHECK_LAUNCH("ix_gemm_wp_f32");
+    return IX_OK;
+}

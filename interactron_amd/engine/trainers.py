@@ -96,6 +96,8 @@ class _TrainerBase:
                     dist.broadcast(b, src=0)      # the buffer itself (bumps its version: cached FrozenBN folds see the change)
             if hasattr(self.model, "invalidate_graphs"):
                 self.model.invalidate_graphs()    # captured graphs / folds made before the sync read the old values
+            from .. import hipops
+            hipops.weights_changed()              # (the flat buffer was rewritten under the parameters' views)
             self._check_replicas(outer)
 
     def _check_replicas(self, outer):

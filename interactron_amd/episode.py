@@ -174,6 +174,7 @@ class _Adaptive(_EpisodeModel):
             self._graphs = {}
         self.__dict__.pop("_chunk_graphs", None)
         self.__dict__.pop("_predict_graphs", None)
+        ops.weights_changed()
 
     def load_state_dict(self, *args, **kwargs):
         # load_state_dict copies IN PLACE (addresses unchanged) but FrozenBatchNorm2d drops its folded scale/shift, which
@@ -565,8 +566,12 @@ class interactron(_Adaptive):
                 self._policy_logits(sf, sm)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._policy_logits(sf, sm)
+            ops.capture_begin(None)   # (capture-local caches: key biases, weight planes)
+            try:
+                with torch.cuda.graph(graph):
+                    out = self._policy_logits(sf, sm)
+            finally:
+                ops.capture_end()
             stamp, folds = self._graph_stamp()   # (after the warm-up: the folds exist now; held alive with the graph)
             ent = self._graphs[key] = (stamp, graph, sf, sm, out, folds)
         _, graph, sf, sm, out, _ = ent

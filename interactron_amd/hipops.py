@@ -251,6 +251,95 @@ def _gemm_workspace_bytes(pa, pb, sp, presplit=True):
     return n
 
 
+# ---- activation x WEIGHT PLANES (csrc/gemm_wp.hip) ---------------------------------------------------------------------------
+# A Linear layer's forward and input gradient multiply an activation by a WEIGHT.  The 12-wave kernel converts both fp32
+# operands to fp16 planes in its producer waves, once per output tile; a weight is read by every row tile of every
+# contraction that uses it, several times per step.  Route: the weight is converted ONCE per (tensor, version, orientation) into
+# the kernel's own LDS image (ix_wp_split_f32) -- cached on the tensor object, re-made when the tensor changes -- and the
+# contraction runs on gemm_wp_kernel (weight planes and raw fp32 activation tiles by LDS-DMA, activation split in the
+# consumers' registers, four workgroups per CU).  Same arithmetic class as the fp16x3 form (tests/test_ops_gpu.py::
+# test_weight_planes_contraction_*).  Which operands are weights: `mark_weight` (set by linear() / weight_view()).
+GEMM_WP = os.environ.get("IX_GEMM_WP", "1") == "1"
+WP_MIN_ROWS = int(os.environ.get("IX_GEMM_WP_MIN_ROWS", "4096"))
+_wp_stats = {"routed": 0, "splits": 0}
+# Cached planes stand for (tensor object, its autograd version, its address, this epoch).  The epoch is bumped by everything that
+# rewrites parameters BEHIND autograd's back: the fused Adam kernel and the flat re-homing of trainer.FlatBuffers (raw
+# pointers), replica broadcasts, load_state_dict.  Code that edits `p.data` in place by other means calls weights_changed().
+_wp_epoch = [0]
+
+
+def weights_changed():
+    _wp_epoch[0] += 1
+
+
+def mark_weight(w):
+    w._ix_weight = True
+    return w
+
+
+def _wp_plan(a, b, bias, sp):
+    """-> (k_contig, ld, batch_stride, shared) when this contraction takes the weight-planes route, else None"""
+    if not (GEMM_WP and getattr(b, "_ix_weight", False)) or COMPUTE_DTYPE != "f32":
+        return None
+    A, B, C = sp.A, sp.B, sp.C
+    if A.trans or C.trans or sp.K % 32 or sp.M < 128 or sp.N < 128 or sp.alpha != 1.0:
+        return None
+    if (A.ld | A.offset | A.so | A.si) & 3 or sp.M * A.ld >= (1 << 29) or a.data_ptr() & 15:
+        return None
+    # the weight view: contiguous [N, K] rows (k-contiguous) or contiguous [K, N] (n-contiguous), one per outer slice or shared
+    if B.offset & 3 or B.si != 0 and sp.bi > 1:
+        return None
+    if B.ld != (sp.K if B.trans else sp.N) or B.so not in (0, sp.N * sp.K):
+        return None
+    if bias is not None and bias.dim() == 2 and bias.shape[0] != sp.bo:
+        return None
+    # measured (tools/wp_bench.py, profiles/r4i_wp_bench.txt): 1.25-1.35x the 12-wave kernel on long activations (M >= 12 500
+    # rows per slice), 1.15-1.28x at 1805 rows x 16 episodes when N >= 512 and a tie or a loss at N = 256 with K >= 1024 --
+    # and a weight is used about once per orientation and weight set per step, so at 1805 rows the split (10-12 % of such a
+    # contraction) eats the gain (r4g / r4h: routed launches 40.6 -> 35.9 ms, splits + 6.5 ms).  The route is taken where the
+    # split is noise: long activations.  IX_GEMM_WP_MIN_ROWS moves the threshold (tests: 128).
+    if sp.M < WP_MIN_ROWS or (sp.N <= 256 and sp.K >= 1024 and sp.M < 8192):
+        return None
+    if -(-sp.M // 128) * -(-sp.N // 128) * sp.bo * sp.bi < 96:
+        return None   # a handful of tiles cannot fill four workgroups per CU (the 12-wave kernel splits K for those)
+    if torch.cuda.is_current_stream_capturing() and _capture[0] is None:
+        return None   # a capture this module was not told about: nowhere safe to keep planes that only exist at replay
+    lib = _L()
+    if lib.ix_gemm_set_x3(1) != 1:   # the bf16x6 form was asked for (IX_GEMM_KERNEL=x6, the tests' kernel_form): this route is
+        lib.ix_gemm_set_x3(0)        # the fp16x3 arithmetic -- leave the contraction to the 12-wave kernel's bf16x6 form
+        return None
+    return (1 if B.trans else 0, B.ld, B.so, B.so == 0 or sp.bo == 1)
+
+
+def _wp_planes(b, sp, plan):
+    """(planes, unscale) of weight operand `b` for this orientation: cached on the tensor object while its version stands.
+    Inside a HIP-graph capture the cache is the capture's own (the split is part of the graph: a replay must redo it, weights
+    change between replays while their addresses stay)."""
+    kc, ld, so, shared = plan
+    nb = 1 if shared else sp.bo
+    key = (kc, ld, so, sp.B.offset, sp.N, sp.K, nb, _wp_epoch[0])
+    if _capture[0] is not None:
+        store, tag = _capture[0], ("wp", id(b)) + key
+    else:
+        store = b.__dict__.setdefault("_ix_wp", {})
+        tag = key
+        if len(store) > 4:   # (superseded epochs / versions of this tensor)
+            store.clear()
+    hit = store.get(tag)
+    if hit is not None and hit[2] == b._version and hit[3] == b.data_ptr():
+        return hit[0], hit[1]
+    L = _L()
+    pb, ub = ctypes.c_size_t(), ctypes.c_size_t()
+    _chk(L.ix_wp_planes_bytes(sp.N, sp.K, nb, ctypes.byref(pb), ctypes.byref(ub)), "ix_wp_planes_bytes")
+    planes = torch.empty(pb.value, dtype=torch.uint8, device=b.device)
+    unscale = torch.empty(ub.value // 4, dtype=torch.float32, device=b.device)
+    _chk(L.ix_wp_split_f32(b.data_ptr() + sp.B.offset * 4, ld, so if not shared else 0, sp.N, sp.K, kc, nb, planes.data_ptr(),
+                           unscale.data_ptr(), _stream()), "ix_wp_split_f32")
+    store[tag] = (planes, unscale, b._version, b.data_ptr(), b if _capture[0] is not None else None)
+    _wp_stats["splits"] += 1
+    return planes, unscale
+
+
 def _run_gemm(a, b, bias, sp, fill=True):
     """fill=False: the caller guarantees nobody reads the elements of `out` the product does not write (the pad columns
     of attention tensors: every consumer stops at the row length) -- saves a memset of the whole tensor."""
@@ -259,6 +348,16 @@ def _run_gemm(a, b, bias, sp, fill=True):
     assert not sp.C.trans
     esz = 4
     pa, pb = a.data_ptr() + sp.A.offset * esz, b.data_ptr() + sp.B.offset * esz
+    plan = _wp_plan(a, b, bias, sp)
+    if plan is not None:
+        planes, unscale = _wp_planes(b, sp, plan)
+        _wp_stats["routed"] += 1
+        _chk(_L().ix_gemm_wp_f32(pa, sp.A.ld, sp.A.so, sp.A.si, planes.data_ptr(), unscale.data_ptr(), 1 if plan[3] else 0,
+                                 out.data_ptr() + sp.C.offset * esz, sp.C.ld, sp.C.so, sp.C.si,
+                                 bias.data_ptr() if bias is not None else None,
+                                 sp.N if (bias is not None and bias.dim() == 2) else 0, sp.M, sp.N, sp.K, sp.bo, sp.bi, sp.alpha,
+                                 _stream()), "ix_gemm_wp_f32")
+        return out
     nws, x3 = _gemm_workspace_bytes(pa, pb, sp)
     ws = _workspace(nws, a.device) if nws else None
     L = _L()
@@ -308,7 +407,7 @@ def weight_view(w, *shape):
     v = w.reshape(*shape)
     if v is not w:
         v._ix_of_param = _param_key(w)
-    return v
+    return mark_weight(v)
 
 
 def _is_unwanted(key, skip):
@@ -465,6 +564,7 @@ def linear(x, weight, bias=None):
 
     Episode-batched form: weight [E, N, K] (+ bias [E, N]) holds one set of MAML fast weights per episode and the
     leading dim of x is E * (rows per episode); episode e's rows meet episode e's weights in ONE batched launch."""
+    mark_weight(weight)
     if weight.dim() == 3:
         E, N, K = weight.shape
         assert x.shape[-1] == K and x.numel() % (E * K) == 0, (tuple(x.shape), tuple(weight.shape))
@@ -2300,3 +2400,4 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq=None, max_norm=0.0,
     _chk(_L().ix_adam_step_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                step, sumsq.data_ptr() if sumsq is not None else None, max_norm, 1 if zero_grad else 0,
                                _stream()), "ix_adam_step_f32")
+    weights_changed()   # (raw-pointer update: no autograd version moves; cached weight planes are void)

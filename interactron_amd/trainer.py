@@ -85,6 +85,9 @@ class FlatBuffers:
                 self.grads[o:o + n].copy_(p.grad.reshape(-1))
             p.data = self.params[o:o + n].view(p.shape)
             p.grad = self.grads[o:o + n].view(p.shape)
+        if dev.type == "cuda":
+            from . import hipops
+            hipops.weights_changed()
 
     def all_reduce_grads(self):
         """The path's single data-path collective: SUM of the flat meta-gradient buffer over all ranks."""

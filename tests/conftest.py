@@ -25,16 +25,26 @@ def golden():
     return load
 
 
-@pytest.fixture(params=["x3", "x6"])
+@pytest.fixture(params=["x3", "x6", "x3wp"])
 def kernel_form(request):
-    """Runs a test once per form of the 12-wave contraction kernel: "x3" = two fp16 planes + a sub-block exponent, three MFMAs
-    per k-slice (the default since round 3), "x6" = three bf16 planes, six MFMAs (IX_GEMM_KERNEL=x6).  Both carry the parity
-    record of the model-level tests."""
+    """Runs a test once per form of the contraction kernels: "x3" = two fp16 planes + a sub-block exponent, three MFMAs per
+    k-slice (the default since round 3), "x6" = three bf16 planes, six MFMAs (IX_GEMM_KERNEL=x6), "x3wp" (round 4) = x3 with
+    EVERY eligible Linear contraction on the activation x weight-planes kernel (csrc/gemm_wp.hip; the product routes only long
+    activations there, hipops.WP_MIN_ROWS).  All three carry the parity record of the model-level tests."""
     from interactron_amd import _lib, hipops
+    if request.param == "x3wp" and "conv" in request.node.name:
+        pytest.skip("convolutions gather their activation operand: never on the weight-planes route")
     lib = _lib.load()
-    old = lib.ix_gemm_set_x3(1 if request.param == "x3" else 0)
-    old_tr, hipops.FLASH_TR = hipops.FLASH_TR, "f16" if request.param == "x3" else "bf16"   # the attention kernels' twin switch
-    yield request.param
+    old = lib.ix_gemm_set_x3(0 if request.param == "x6" else 1)
+    old_tr, hipops.FLASH_TR = hipops.FLASH_TR, "bf16" if request.param == "x6" else "f16"   # the attention kernels' twin switch
+    old_rows, old_wp = hipops.WP_MIN_ROWS, hipops.GEMM_WP
+    if request.param == "x3wp":
+        hipops.WP_MIN_ROWS, hipops.GEMM_WP = 128, True
+        before = hipops._wp_stats["routed"]
+    yield "x3" if request.param == "x3wp" else request.param
+    if request.param == "x3wp" and any(k in request.node.name for k in ("g7", "g13", "config")):   # (full-size models)
+        assert hipops._wp_stats["routed"] > before, "the weight-planes route was never taken"
+    hipops.WP_MIN_ROWS, hipops.GEMM_WP = old_rows, old_wp
     lib.ix_gemm_set_x3(old)
     hipops.FLASH_TR = old_tr
 

@@ -718,6 +718,61 @@ def test_single_pass_contraction_is_16_bit_grade(ops, akc, bkc):
         assert errs[1] >= 1e-5 and errs[0] <= 6e-7, (M, N, K, kind, errs)   # the switch switches, and switches back
 
 
+@pytest.mark.parametrize("bkc", [1, 0])
+def test_weight_planes_contraction_is_fp32_grade(ops, bkc):
+    """ix_wp_split_f32 + ix_gemm_wp_f32 (csrc/gemm_wp.hip: weight converted once into the kernel's LDS image, LDS-DMA, activation
+    split in the consumers' registers) through the raw C-ABI against float64: both weight layouts, per-slice and shared
+    weights, ragged M / N, bias per slice / shared / none, an inner batch, activations whose magnitude ramps by 2^+-20 along K
+    and differs by e^+-8 between rows, weights whose rows differ by e^+-3.5 (exponent per 32 rows), zero and denormal
+    activation sub-blocks.  Bound: the fp16x3 form's (6e-7 sum|a||w|; 1.5e-6 on the ramps)."""
+    import ctypes
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    cases = [(300, 260, 256, 2, 1, False, "plain"), (1805, 512, 96, 3, 1, False, "rows"), (130, 129, 2048, 1, 2, True, "ramp_up"),
+             (257, 384, 1024, 2, 1, True, "ramp_down"), (128, 128, 64, 1, 1, False, "zeros"), (256, 256, 512, 1, 1, True, "denormal")]
+    for (M, N, K, bo, bi, shared, kind) in cases:
+        a = rnd(bo, bi, M, K, seed=1)
+        # (weight rows spread over e^+-3.5: one exponent serves 32 rows, an element is resolved to 2^-25 of its slab's maximum --
+        #  the 12-wave kernel's 32 x 32 sub-blocks behave the same way; rows a million times apart inside one block are not
+        #  what a weight matrix looks like)
+        w = rnd(1 if shared else bo, N, K, seed=3) * (1.0 * rnd(1 if shared else bo, N, 1, seed=5)).exp()
+        if kind == "rows":
+            a = a * (2.0 * rnd(bo, bi, M, 1, seed=2)).exp()
+        if kind in ("ramp_up", "ramp_down"):
+            a = a * torch.exp2(torch.linspace(-20, 20, K) * (1 if kind == "ramp_up" else -1))[None, None, None, :]
+        if kind == "zeros":
+            a = torch.zeros_like(a)
+        if kind == "denormal":
+            a[:, :, :32, :64] *= 1e-42
+        a, w = a.cuda(), w.cuda()
+        for bias_kind in ("slice", "shared", "none"):
+            bias = None if bias_kind == "none" else (rnd(bo, N, seed=4) if bias_kind == "slice" else rnd(N, seed=4)).cuda()
+            W = w if bkc else w.transpose(1, 2).contiguous()          # [nb, N, K] rows or [nb, K, N]
+            nb = w.shape[0]
+            pb, ub = ctypes.c_size_t(), ctypes.c_size_t()
+            assert lib.ix_wp_planes_bytes(N, K, nb, ctypes.byref(pb), ctypes.byref(ub)) == 0
+            planes = torch.full((pb.value,), 0x7f, dtype=torch.uint8, device="cuda")
+            us = torch.empty(ub.value // 4, device="cuda")
+            rc = lib.ix_wp_split_f32(W.data_ptr(), K if bkc else N, N * K, N, K, bkc, nb, planes.data_ptr(), us.data_ptr(), stream)
+            assert rc == 0, lib.ix_last_error()
+            ldc = N + 4
+            C = torch.full((bo, bi, M, ldc), float("nan"), device="cuda")
+            rc = lib.ix_gemm_wp_f32(a.data_ptr(), K, bi * M * K, M * K, planes.data_ptr(), us.data_ptr(), 1 if shared else 0, C.data_ptr(),
+                                    ldc, bi * M * ldc, M * ldc, bias.data_ptr() if bias is not None else None,
+                                    N if bias_kind == "slice" else 0, M, N, K, bo, bi, 1.0, stream)
+            assert rc == 0, lib.ix_last_error()
+            wd = w.double().expand(bo, N, K)[:, None]                 # [bo, 1, N, K]
+            ref = a.double() @ wd.transpose(-1, -2)
+            scale = a.double().abs() @ wd.abs().transpose(-1, -2) + 1e-300
+            if bias is not None:
+                bb = bias.double()[:, None, None, :] if bias_kind == "slice" else bias.double()
+                ref, scale = ref + bb, scale + bb.abs()
+            err = float(((C[..., :N].double() - ref).abs() / scale).max())
+            assert err <= (1.5e-6 if kind.startswith("ramp") else 6e-7), (M, N, K, bo, bi, shared, kind, bias_kind, err)
+            assert bool(torch.isnan(C[..., N:]).all()), "wrote outside its rows"
+
+
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     """The pre-split fp16x3 route of ix_gemm_f32_ws (two fp16 planes + one power-of-two scale per 32 rows, three fp16 MFMA
