@@ -207,9 +207,10 @@ def _wants_graph(model, E, shape):
         return True
     # auto: small chunks are bound by the host issuing the launches; the reference batch of 16 x 300^2 episodes is GPU-bound but
     # still gains 2.7 % from a replay (no launch gaps, the first-order branch beside the second-order backward: 262.3 -> 255.3
-    # ms, r4e; the pools REUSE the 58 GB the eager warm-up step has freed).  Larger chunks (800 x 800: 19 GB per episode)
-    # would need the eager step's cached memory and the pools' at once
-    return E * shape[1] * shape[2] <= 16 * 300 * 300
+    # ms, r4e).  A capture's private pools hold a whole step's working set (58 GB at 16 x 300^2, 152 GB at 8 x 800^2): the
+    # eager warm-up step's cached blocks are handed back first and the capture only goes ahead when the device has room for
+    # the warm-up's measured peak (chunk_runner); chunks beyond 8 x 800^2 stay eager
+    return E * shape[1] * shape[2] <= 8 * 800 * 800
 
 
 def chunk_runner(model, E, s, shape, ldn, ldn1):
@@ -232,6 +233,15 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
         state[key] = state.pop(key)   # most recently used last
     if ent is None:   # first call of a signature: eager (warms BN folds, scratch, size caches); the next one captures
         state[key] = "warm"
+
+        def warm(inputs, policy_labels):   # ... and measures what a step of this signature needs beyond what is already held
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            res = run_eager(model, E, s, inputs, policy_labels)
+            model.__dict__.setdefault("_chunk_peaks", {})[key] = torch.cuda.max_memory_allocated() - base
+            return res
+        return warm
+    if ent == "eager":
         return eager
     if ent == "warm" or ent.stamp != model._graph_stamp()[0]:
         def capture_then_run(inputs, policy_labels):
@@ -240,6 +250,14 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
                 held = [k for k, v in state.items() if isinstance(v, ChunkGraphs) and k != key]
                 for old in held[:max(0, len(held) - (GRAPH_SETS - 1))]:
                     del state[old]          # its graphs, static buffers and both private pools go with it
+                need = model.__dict__.get("_chunk_peaks", {}).get(key, 0)
+                if need > (8 << 30):   # a large working set: the pools must find it as FREE device memory
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()   # (the warm-up step's blocks sit in the allocator's cache, useless to a private pool)
+                    free, _ = torch.cuda.mem_get_info()
+                    if free < 1.15 * need + (4 << 30):
+                        state[key] = "eager"   # not an error: this signature simply stays on eager launches
+                        return run_eager(model, E, s, inputs, policy_labels)
                 g = ChunkGraphs(model, E, s, shape, GRAPH_PITCH, GRAPH_PITCH, inputs["masks"].dtype)
                 g.load(inputs)
                 g.capture()

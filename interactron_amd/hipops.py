@@ -260,7 +260,7 @@ def _gemm_workspace_bytes(pa, pb, sp, presplit=True):
 # consumers' registers, four workgroups per CU).  Same arithmetic class as the fp16x3 form (tests/test_ops_gpu.py::
 # test_weight_planes_contraction_*).  Which operands are weights: `mark_weight` (set by linear() / weight_view()).
 GEMM_WP = os.environ.get("IX_GEMM_WP", "1") == "1"
-WP_MIN_ROWS = int(os.environ.get("IX_GEMM_WP_MIN_ROWS", "4096"))
+WP_MIN_ROWS = int(os.environ.get("IX_GEMM_WP_MIN_ROWS", "8192"))
 _wp_stats = {"routed": 0, "splits": 0}
 # Cached planes stand for (tensor object, its autograd version, its address, this epoch).  The epoch is bumped by everything that
 # rewrites parameters BEHIND autograd's back: the fused Adam kernel and the flat re-homing of trainer.FlatBuffers (raw
@@ -300,8 +300,8 @@ def _wp_plan(a, b, bias, sp):
     # split is noise: long activations.  IX_GEMM_WP_MIN_ROWS moves the threshold (tests: 128).
     if sp.M < WP_MIN_ROWS or (sp.N <= 256 and sp.K >= 1024 and sp.M < 8192):
         return None
-    if -(-sp.M // 128) * -(-sp.N // 128) * sp.bo * sp.bi < 96:
-        return None   # a handful of tiles cannot fill four workgroups per CU (the 12-wave kernel splits K for those)
+    if -(-sp.M // 128) * -(-sp.N // 128) * sp.bo * sp.bi < (512 if WP_MIN_ROWS > 128 else 96):
+        return None   # too few tiles for four workgroups on each of 256 CUs (the 12-wave kernel is persistent and splits K)
     if torch.cuda.is_current_stream_capturing() and _capture[0] is None:
         return None   # a capture this module was not told about: nowhere safe to keep planes that only exist at replay
     lib = _L()
