@@ -550,7 +550,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
                                     "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode "
-                                    "(dropout on; model-level parity is pinned in eval mode, the dropout kernels op by op)"
+                                    "(dropout on; model-level parity is pinned in eval mode AND, with the kernels' own dropout masks handed to the oracle, "
+                                    "in train mode: tests/test_parity_gpu.py::test_train_mode_step_with_the_kernels_own_dropout_masks_against_the_oracle)"
                                     % (CONFIGS[args.config][0], CONFIGS[args.config][1], args.episodes, args.size, args.size,
                                        args.queries, cfg["BLOCK_SIZE"])) if args.mode == "train" else
                                    ("%s %s, one episode at a time (%d episodes/GPU x 5 frames x 3x%dx%d), eval mode"

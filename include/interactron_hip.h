@@ -85,7 +85,8 @@ int ix_wp_planes_bytes(int N, int K, int nb, size_t* planes_bytes_host, size_t* 
 int ix_wp_split_f32(const float* W, int64_t ld, int64_t batch_stride, int N, int K, int k_contig, int nb, void* planes,
                     float* unscale, ix_stream_t stream);
 int ix_prof_wp(double* ms, double* flops, int64_t* launches); /* profiled launches of the weight-planes kernel (also in slot [2] of ix_prof_contractions) */
-int ix_gemm_wp_debug(int flags); /* diagnostic switches of tools/wp_bench.py (0 = off; the product never sets them) */
+int ix_gemm_wp_debug(int flags);
+int ix_gemm_wp_debug_stamps(int64_t* device_buffer); /* 8 x int64 per workgroup, filled when flag 16 is set (tools/wp_timeline.py) */ /* diagnostic switches of tools/wp_bench.py (0 = off; the product never sets them) */
 int ix_gemm_wp_f32(const float* A, int64_t lda, int64_t sAo, int64_t sAi, const void* planes, const float* unscale, int b_shared,
                    float* C, int64_t ldc, int64_t sCo, int64_t sCi, const float* bias, int64_t sBias, int M, int N, int K,
                    int batch_outer, int batch_inner, float alpha, ix_stream_t stream);

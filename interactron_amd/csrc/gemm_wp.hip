@@ -144,6 +144,7 @@ struct WpArgs {
     int M, N, K, KT, tiles_m, tiles_n, batch_inner;
     float alpha;
     int dbg;   // tools/wp_bench.py only (ix_gemm_wp_debug): 1 no C stores, 2 no conversion / MFMA, 4 no DMA after the first stage
+    long long* stamps;   // dbg 16: per workgroup [start, first stage landed, K loop done, stores issued, stores acknowledged, HW_ID]
 };
 
 __device__ __forceinline__ int wp_xcd_swizzle(int bid, int nwg) {
@@ -236,6 +237,13 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(WpArgs p) {
     }
 
     const int nk = p.KT;
+    const bool stamp = (p.dbg & 16) && p.stamps && tid == 0;
+    long long* const st_ = stamp ? p.stamps + 8 * (int64_t)(blockIdx.x + blockIdx.y * gridDim.x) : nullptr;
+    if (stamp) {
+        st_[0] = wall_clock64();
+        st_[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID (wave, simd, cu, sh, se ...), XCC_ID below
+        st_[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    }
     if ((p.dbg & 8) && (blockIdx.x + blockIdx.y * gridDim.x) < 1024) {   // experiment: de-phase the first round's workgroups
         const int ph = ((blockIdx.x >> 3) & 3);
         for (int t = 0; t < ph * (p.dbg >> 8); ++t) __builtin_amdgcn_s_sleep(127);
@@ -255,6 +263,7 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(WpArgs p) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
         __syncthreads();                                    // everybody's have
+        if (stamp && kt == 0) st_[1] = wall_clock64();
         if (!(p.dbg & 2)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(WpArgs p) {
     }
 
     // ---- epilogue: undo the exponents, alpha, bias; one 128-byte row segment per store instruction and half wave ----
+    if (stamp) st_[2] = wall_clock64();
     if (p.dbg & 1) {
         if (acc[0][0][0] == 12345.678f) p.C[0] = 1.f;   // (keeps the sums alive)
         return;
@@ -349,9 +359,19 @@ __global__ __launch_bounds__(256, 4) void gemm_wp_kernel(WpArgs p) {
             }
         }
     }
+    if (stamp) {
+        st_[3] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_[4] = wall_clock64();
+    }
 }
 
 static int g_wp_dbg = 0;
+static long long* g_wp_stamps = nullptr;
+extern "C" int ix_gemm_wp_debug_stamps(long long* device_buffer) {   // 8 x int64 per workgroup (dbg flag 16); diagnostic
+    g_wp_stamps = device_buffer;
+    return IX_OK;
+}
 extern "C" int ix_gemm_wp_debug(int flags) {   // diagnostic (tools/wp_bench.py): what a tile's time is made of; wrong numbers when set
     const int old = g_wp_dbg;
     g_wp_dbg = flags;
@@ -378,6 +398,7 @@ extern "C" int ix_gemm_wp_f32(const float* A, int64_t lda, int64_t sAo, int64_t 
     a.sBus = b_shared ? 0 : a.tiles_n * 4;
     a.batch_inner = batch_inner; a.alpha = alpha;
     a.dbg = g_wp_dbg;
+    a.stamps = g_wp_stamps;
     const dim3 grid(a.tiles_m * a.tiles_n, batch_outer * batch_inner);
     ix_prof_begin_wp(stream, M, N, K, batch_outer * batch_inner);
     hipLaunchKernelGGL(gemm_wp_kernel, grid, dim3(256), 0, stream, a);

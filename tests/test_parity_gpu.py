@@ -817,6 +817,150 @@ def test_oracle_parity_fresh_inputs_small_resolution():
         torch.testing.assert_close(out[k].cpu(), v, atol=tol, rtol=1e-3, msg=lambda s: k + ": " + s)
 
 
+# ---- train mode (dropout ON) against the oracle, with the HIP path's own dropout masks handed to the oracle --------------------
+def _hip_elementwise_keep(seed, n, p):
+    """The counter-hash mask of csrc/elementwise.hip (dropout_kernel / relu_dropout_kernel / add_dropout_kernel: mix32 of
+    seed ^ index * 0xD6E8FEB86659FD93, keep <=> draw >= p * 2^32), restated in numpy uint64 arithmetic: keep / (1 - p)."""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        k = np.arange(n, dtype=np.uint64)
+        z = (np.uint64(seed) ^ (k * np.uint64(0xD6E8FEB86659FD93))) & M
+        z = (z + np.uint64(0x9E3779B97F4A7C15)) & M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+        r = (z ^ (z >> np.uint64(31))) >> np.uint64(32)
+    thresh = np.uint64(int(float(np.float32(p)) * 4294967296.0))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy((r >= thresh).astype(np.float32) * scale)
+
+
+class _RecordDropoutSites:
+    """Records, in call order, every dropout-carrying op the HIP path issues: (kind, shape of the masked tensor, p, seed)."""
+
+    def __enter__(self):
+        from interactron_amd import hipops as ops
+        self.ops, self.sites, self._orig = ops, [], {}
+        seeds = []
+        self._orig["_next_seed"] = ops._next_seed
+        ops._next_seed = lambda: (seeds.append(self._orig["_next_seed"]()), seeds[-1])[1]
+
+        def wrap(name, shape_of, p_of):
+            orig = getattr(ops, name)
+            self._orig[name] = orig
+
+            def f(*a):
+                n0 = len(seeds)
+                out = orig(*a)
+                if len(seeds) > n0:
+                    assert len(seeds) == n0 + 1
+                    self.sites.append((name, tuple(shape_of(a)), float(p_of(a)), seeds[-1]))
+                return out
+            setattr(ops, name, f)
+        wrap("dropout", lambda a: a[0].shape, lambda a: a[1])
+        wrap("add_dropout", lambda a: a[1].shape, lambda a: a[2])
+        wrap("relu_dropout", lambda a: a[0].shape, lambda a: a[1])
+        wrap("attention", lambda a: (a[3] * a[4], a[5], a[6]), lambda a: a[16])   # (nbatch * heads, L, S), p
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._orig.items():
+            setattr(self.ops, k, v)
+
+    def masks(self):
+        out = []
+        for kind, shape, p, seed in self.sites:
+            if kind == "attention":
+                out.append(self.ops.flash_dropmask(shape[0], shape[1], shape[2], p, seed).cpu().float())
+            else:
+                n = 1
+                for d in shape:
+                    n *= d
+                out.append(_hip_elementwise_keep(seed, n, p).reshape(shape))
+        return out
+
+
+def test_train_mode_step_with_the_kernels_own_dropout_masks_against_the_oracle():
+    """The step bench.py times runs in TRAIN mode (dropout 0.1 in every transformer); model-level parity was eval-mode only
+    because two implementations draw different masks.  Here the HIP path's masks -- pure functions of (seed, element index),
+    recorded site by site in call order (78 + 13 sites: three detector passes, the fusion) -- are materialised and handed to
+    the CPU oracle's F.dropout calls in the same order: one full meta-train step (reference models/interactron.py:61-151 with
+    detector.train() / fusion.train(), :153-161) on one episode at 128 x 160, losses within 2e-3, every gradient tensor's norm
+    within 5e-3 (at most two kink-bound backbone tensors within 1.5e-2) and direction (cosine) within 1e-3 of the oracle's."""
+    import torch.nn.functional as F
+    from interactron_amd import Config, build_model, hipops
+    from interactron_amd.synthetic import procedural_state_dict
+    from oracle import detector as od, episode as oe, fusion as of
+    cfg = dict(MODEL_CFG, TYPE="interactron", BLOCK_SIZE=5 * (8 * 10 + 50) + 5, EPISODE_CHUNK=1, STEP_GRAPH="off")
+    m = build_model(Config(**cfg))
+    load_procedural(m.fusion, "fusion.")
+    m = m.cuda().train()
+    data = synthetic_episodes(1, height=128, width=160, tag="trainmode")
+    random.seed(11)
+    hipops.manual_seed(4321)
+    m.zero_grad()
+    with _RecordDropoutSites() as rec:
+        _, losses = m(to_gpu(data))
+    torch.cuda.synchronize()
+    masks = rec.masks()
+    kinds = [s[0] for s in rec.sites]
+    assert kinds.count("attention") == 3 * 18 + 4 and len(kinds) == 3 * (18 + 42) + 13, (len(kinds), kinds.count("attention"))
+
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+    ocfg = {k: v for k, v in cfg.items() if k not in ("TYPE", "EPISODE_CHUNK", "STEP_GRAPH", "WEIGHTS")}
+    fus = {k[len("fusion."):]: v for k, v in
+           procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(ocfg, "gpt").items()}).items()}
+    queue = list(masks)
+    real_dropout = F.dropout
+
+    def fed_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p <= 0.0:
+            return x
+        mk = queue.pop(0)
+        if tuple(mk.shape) != tuple(x.shape):
+            if mk.dim() == 3 and x.dim() == 3 and (mk.shape[1], mk.shape[0], mk.shape[2]) == tuple(x.shape):
+                mk = mk.permute(1, 0, 2)            # [frames, tokens, d] here, [tokens, frames, d] in the reference's DETR
+            else:
+                assert mk.numel() == x.numel(), ("dropout site order differs", tuple(mk.shape), tuple(x.shape))
+                mk = mk.reshape(x.shape)            # [batch * heads, L, S] -> [batch, heads, L, S]
+        return x * mk.to(x.dtype)
+    F.dropout = fed_dropout
+    try:
+        random.seed(11)
+        _, ref_losses, ref_grads = oe.interactron_forward(det, fus, data, ocfg, {}, "gpt", training=True)
+    finally:
+        F.dropout = real_dropout
+    assert not queue, "%d dropout sites of the HIP path were never reached by the oracle" % len(queue)
+    for k, v in ref_losses.items():
+        assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), (k, float(losses[k]), float(v))
+    devs = []
+    for group, module in (("fusion", m.fusion), ("detector", m.detector)):
+        for name, p_ in module.named_parameters():
+            ref = ref_grads[group].get(name)
+            if ref is None:
+                assert p_.grad is None or float(p_.grad.abs().max()) == 0.0, name
+                continue
+            g = p_.grad.detach().cpu()
+            if g.dim() == 4 and tuple(g.shape) != tuple(ref.shape):
+                g = g.permute(0, 3, 1, 2)
+            rn, gn = float(ref.norm()), float(g.norm())
+            if max(rn, gn) < 1e-6:
+                continue
+            cos = float((g.double().reshape(-1) @ ref.double().reshape(-1)) / (gn * rn)) if ref.numel() > 1 else 1.0
+            devs.append((abs(gn - rn) / rn, 1.0 - cos, ref.numel(), group + "." + name))
+    devs.sort(reverse=True)
+    print("train-mode step with shared dropout masks: %d sites, %d gradient tensors; worst norm deviations %s; worst 1 - cosine %.2e"
+          % (len(kinds), len(devs), [(round(d[0], 5), d[3]) for d in devs[:4]], max(d[1] for d in devs)))
+    # every tensor within 5e-3 of the oracle's norm (one-element tensors 5e-2) -- except that a few second-order backbone weights
+    # sit on ReLU / clip kinks of the inner step (the eval-mode G13 test shows the same tensors, and the reference's own float32
+    # is 0.7 % off float64 there): at most two of them, within 1.5e-2 (measured: one, 8.7e-3); directions (1 - cosine) within
+    # 1e-3 everywhere (measured 3.4e-4)
+    loose = [d for d in devs if d[0] > (5e-2 if d[2] == 1 else 5e-3)]
+    assert len(loose) <= 2 and all("backbone" in d[3] and d[0] <= 1.5e-2 for d in loose), loose
+    assert max(d[1] for d in devs) <= 1e-3, sorted(devs, key=lambda d: -d[1])[:3]
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from interactron_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
