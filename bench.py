@@ -70,22 +70,28 @@ def to_gpu(data, dev):
 
 
 def pmc_traffic(kernel, size):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command at this frame size
-    (profiles/*_pmc_hbm_traffic_<size>.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes; the 300x300 files of earlier rounds
-    carry no suffix); None when no profile of that shape exists.  PMC counters cannot be collected from inside the process,
-    so this is the profile's figure, not a live one."""
+    """HBM bytes per launch of the fp32-on-16-bit contraction kernels (`kernel` and the kernels that share its launches' slot in
+    the live counters: both forms of the 12-wave kernel and the weight-planes kernel), launch-weighted, from the committed
+    rocprofv3 PMC passes of this same command at this frame size (profiles/*_pmc_hbm_traffic_<size>.json: FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes; the 300x300 files of earlier rounds carry no suffix); None when no profile of that shape
+    exists.  PMC counters cannot be collected from inside the process, so this is the profile's figure, not a live one."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic_%d.json" % size)))
     if not files and size == 300:
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
+    group = ("gemm_f32_f16x3_p12_kernel", "gemm_f32_bf16x6_p12_kernel", "gemm_wp_kernel")
     for f in reversed(files):
         try:
             ks = json.load(open(f))["kernels"]
         except (KeyError, ValueError, OSError):
             continue
+        tot = n = 0.0
         for name, v in ks.items():
-            if name.startswith(kernel):
-                return v["hbm_bytes_per_launch"]
+            if name.startswith(group):
+                tot += v["hbm_bytes_per_launch"] * v["launches"]
+                n += v["launches"]
+        if n:
+            return tot / n
     return None
 
 

@@ -4,7 +4,7 @@ import collections, csv, json, re, sys
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
-    m = re.search(r"(gemm_f32_\w+?kernel)", r["Kernel_Name"])
+    m = re.search(r"(gemm_f32_\w+?kernel|gemm_wp_kernel)", r["Kernel_Name"])
     if not m:
         continue
     k = m.group(1)
