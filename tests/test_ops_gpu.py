@@ -773,6 +773,59 @@ def test_weight_planes_contraction_is_fp32_grade(ops, bkc):
             assert bool(torch.isnan(C[..., N:]).all()), "wrote outside its rows"
 
 
+def test_weight_planes_cache_follows_the_weight(ops):
+    """hipops caches a weight's planes on the tensor object (key: view, autograd version, address, epoch).  They must be re-made
+    when the weight changes: by an autograd-visible in-place op (version), by the fused Adam kernel that writes through raw
+    pointers (epoch bump in hipops.adam_step), by re-homing into trainer.FlatBuffers (address / epoch) -- and must NOT be re-made
+    between two uses of an unchanged weight.  Forward and input gradient (the other orientation) both checked against the
+    12-wave kernel's result on the same data."""
+    from interactron_amd.trainer import FlatBuffers
+    old_rows, old_wp = ops.WP_MIN_ROWS, ops.GEMM_WP
+    ops.WP_MIN_ROWS, ops.GEMM_WP = 128, True
+    try:
+        x = rnd(4096, 512, seed=1).cuda().requires_grad_(True)
+        w = torch.nn.Parameter(rnd(512, 512, seed=2).cuda())
+        b = torch.nn.Parameter(rnd(512, seed=3).cuda())
+
+        def both():
+            y = ops.linear(x, w, b)
+            (gx,) = torch.autograd.grad(y, [x], rnd(4096, 512, seed=4).cuda())
+            return y.detach().clone(), gx.clone()
+
+        def reference():
+            ops.GEMM_WP = False
+            try:
+                return both()
+            finally:
+                ops.GEMM_WP = True
+
+        def check(what):
+            r0, s0 = ops._wp_stats["routed"], ops._wp_stats["splits"]
+            y, gx = both()
+            assert ops._wp_stats["routed"] == r0 + 2, what          # forward + input gradient took the route
+            yr, gr = reference()
+            assert float((y - yr).abs().max()) <= 1e-5 * float(yr.abs().max()), what
+            assert float((gx - gr).abs().max()) <= 1e-5 * float(gr.abs().max()), what
+            return ops._wp_stats["splits"] - s0
+
+        assert check("first use") == 2                               # two orientations
+        assert check("unchanged weight") == 0                        # cached
+        with torch.no_grad():
+            w.mul_(1.5)                                              # autograd-visible: version moves
+        assert check("after an in-place op") == 2
+        g = torch.ones_like(w)
+        m, v = torch.zeros_like(w), torch.zeros_like(w)
+        ops.adam_step(w.data.reshape(-1), g.reshape(-1), m.reshape(-1), v.reshape(-1), 0.05, 0.9, 0.999, 1e-8, 1)   # raw pointers
+        assert check("after the fused Adam kernel") == 2
+        FlatBuffers([[w, b]])                                        # re-homed: new storage
+        assert check("after FlatBuffers re-homing") == 2
+        w.data.add_(0.25)                                            # behind everybody's back ...
+        ops.weights_changed()                                        # ... unless told
+        assert check("after weights_changed()") == 2
+    finally:
+        ops.WP_MIN_ROWS, ops.GEMM_WP = old_rows, old_wp
+
+
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_f16x3_presplit_contraction_is_fp32_grade(ops, akc, bkc):
     """The pre-split fp16x3 route of ix_gemm_f32_ws (two fp16 planes + one power-of-two scale per 32 rows, three fp16 MFMA
