@@ -324,7 +324,8 @@ def test_g8_g9_fusion_and_learned_loss_gradient(golden, interactron_model, episo
     finally:
         set_parameters(m.detector, theta)
     for name, gi in zip(M["theta_names"], g):
-        check_grad(M["g9"]["grads"][name], gi, rel=5e-3, what="g9/" + name)
+        # FIRST-order gradients meet SURVEY 8d's proposal (1e-3 per tensor; measured worst 5.6e-5: tools/parity_survey.sh, r4)
+        check_grad(M["g9"]["grads"][name], gi, rel=1e-3, what="g9/" + name)
 
 
 @pytest.mark.usefixtures("kernel_form")
@@ -700,7 +701,7 @@ def test_config1_detr(golden, episode1):
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
     F64 = golden("golden_train_f64.pt")["configs"]["detr_forward"]["grads"]
     for k, p in m.model.named_parameters():
-        check_grad(O["detr_forward"]["grads"][k], p.grad, rel=5e-3, what="detr/" + k, norm64=F64.get(k))
+        check_grad(O["detr_forward"]["grads"][k], p.grad, rel=1e-3, what="detr/" + k, norm64=F64.get(k))   # first order: 1e-3
 
 
 @pytest.mark.usefixtures("kernel_form")
@@ -719,10 +720,10 @@ def test_config2_multiframe(golden, episode1):
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
     F64 = golden("golden_train_f64.pt")["configs"]["multiframe_forward"]
     for k, p in m.detector.named_parameters():
-        check_grad(O["multiframe_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="mf/detector." + k,
+        check_grad(O["multiframe_forward"]["detector_grads"][k], p.grad, rel=1e-3, what="mf/detector." + k,   # first order: 1e-3
                    norm64=F64["detector_grads"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(O["multiframe_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="mf/fusion." + k,
+        check_grad(O["multiframe_forward"]["fusion_grads"][k], p.grad, rel=1e-3, what="mf/fusion." + k,
                    norm64=F64["fusion_grads"].get(k))
 
 
