@@ -220,6 +220,13 @@ int ix_bcast_rows_f32(const float* v, float* out, int64_t rows, int C, int group
 int ix_colsum_f32(const float* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
                   ix_stream_t stream);
 int ix_workspace_bytes_colsum_f32(int64_t rows, int C, int groups, size_t* out_host);
+/* total = sum_e ||x_e||_2 over the rows of x [E, n] (E <= 1024) in one launch, norms[e] beside it; its backward
+ * gx = g x_e / ||x_e|| (g: device scalar) and that kernel's own backward (cotangent H -> Gx, Gg): the learned loss of a chunk
+ * of episodes, reference models/interactron.py:96 `torch.norm(fusion_out["loss"])` per task, differentiated twice by MAML. */
+int ix_rownorm_sum_f32(const float* x, float* norms, float* total, int E, int n, ix_stream_t stream);
+int ix_rownorm_sum_bwd_f32(const float* x, const float* norms, const float* g, float* gx, int E, int n, ix_stream_t stream);
+int ix_rownorm_sum_bwd_bwd_f32(const float* x, const float* norms, const float* g, const float* H, float* Gx, float* Gg, int E,
+                               int n, ix_stream_t stream);
 int ix_dot_f32(const float* a, const float* b, float* out, int64_t n, void* workspace, size_t workspace_bytes,
                ix_stream_t stream); /* workspace: IX_TICKET_BYTES + 1024 bytes */
 

@@ -522,6 +522,88 @@ extern "C" int ix_dot_f32(const float* a, const float* b, float* out, int64_t n,
     return IX_OK;
 }
 
+// ---- sum of row L2 norms: the learned loss of a chunk of episodes in ONE launch ---------------------------------------
+// total = sum_e ||x_e||, x [E, n] (reference models/interactron.py:96: `learned_loss = torch.norm(fusion_out["loss"])`, once per
+// task; the episode-batched step needs the E norms of a chunk and their sum: E dot products + E square roots + a stack + a
+// sum before).  One workgroup: wave w takes rows w, w + 4, ...; the row sums are added in row order (deterministic).  The
+// backward y = g x_e / ||x_e|| and ITS backward (the MAML meta-gradient differentiates the inner gradient) are the two
+// kernels below; a zero row has gradient 0, as torch.norm's backward masks it.
+__device__ __forceinline__ float rn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void rownorm_sum_kernel(const float* __restrict__ x, float* __restrict__ norms,
+                                                          float* __restrict__ total, int E, int n) {
+    __shared__ float sn[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < E; e += 4) {
+        float s = 0.f;
+        for (int j = lane; j < n; j += 64) { const float v = x[(int64_t)e * n + j]; s += v * v; }
+        s = sqrtf(rn_wave_sum(s));
+        if (lane == 0) { norms[e] = s; sn[e] = s; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t += sn[e];
+        *total = t;
+    }
+}
+// gx[e][j] = g * x[e][j] / norms[e]   (g: one device scalar)
+__global__ void rownorm_sum_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms, const float* __restrict__ g,
+                                       float* __restrict__ gx, int E, int n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)E * n) return;
+    const float nm = norms[i / n];
+    gx[i] = nm > 0.f ? *g * x[i] / nm : 0.f;
+}
+// cotangent H of y = g x / ||x_e||:  Gg = sum_e <H_e, x_e> / n_e;  Gx[e] = g (H_e / n_e - x_e <H_e, x_e> / n_e^3)
+__global__ __launch_bounds__(256) void rownorm_sum_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms,
+                                                                  const float* __restrict__ g, const float* __restrict__ H,
+                                                                  float* __restrict__ Gx, float* __restrict__ Gg, int E, int n) {
+    __shared__ float sd[1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float gv = *g;
+    for (int e = wave; e < E; e += 4) {
+        const float nm = norms[e];
+        float d = 0.f;
+        for (int j = lane; j < n; j += 64) d += H[(int64_t)e * n + j] * x[(int64_t)e * n + j];
+        d = rn_wave_sum(d);
+        const float inv = nm > 0.f ? 1.f / nm : 0.f;
+        for (int j = lane; j < n; j += 64) {
+            const int64_t k = (int64_t)e * n + j;
+            Gx[k] = gv * (H[k] * inv - x[k] * d * inv * inv * inv);
+        }
+        if (lane == 0) sd[e] = d * inv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t += sd[e];
+        *Gg = t;
+    }
+}
+extern "C" int ix_rownorm_sum_f32(const float* x, float* norms, float* total, int E, int n, hipStream_t stream) {
+    IX_CHECK_ARG(x && norms && total && E > 0 && E <= 1024 && n > 0, "ix_rownorm_sum_f32: bad args (1..1024 rows)");
+    hipLaunchKernelGGL(rownorm_sum_kernel, dim3(1), dim3(256), 0, stream, x, norms, total, E, n);
+    IX_CHECK_LAUNCH("ix_rownorm_sum_f32");
+    return IX_OK;
+}
+extern "C" int ix_rownorm_sum_bwd_f32(const float* x, const float* norms, const float* g, float* gx, int E, int n, hipStream_t stream) {
+    IX_CHECK_ARG(x && norms && g && gx && E > 0 && n > 0, "ix_rownorm_sum_bwd_f32: bad args");
+    hipLaunchKernelGGL(rownorm_sum_bwd_kernel, dim3(ix_grid_1d((int64_t)E * n, 256)), dim3(256), 0, stream, x, norms, g, gx, E, n);
+    IX_CHECK_LAUNCH("ix_rownorm_sum_bwd_f32");
+    return IX_OK;
+}
+extern "C" int ix_rownorm_sum_bwd_bwd_f32(const float* x, const float* norms, const float* g, const float* H, float* Gx, float* Gg,
+                                          int E, int n, hipStream_t stream) {
+    IX_CHECK_ARG(x && norms && g && H && Gx && Gg && E > 0 && E <= 1024 && n > 0, "ix_rownorm_sum_bwd_bwd_f32: bad args (1..1024 rows)");
+    hipLaunchKernelGGL(rownorm_sum_bwd_bwd_kernel, dim3(1), dim3(256), 0, stream, x, norms, g, H, Gx, Gg, E, n);
+    IX_CHECK_LAUNCH("ix_rownorm_sum_bwd_bwd_f32");
+    return IX_OK;
+}
+
 // ---- FrozenBatchNorm2d folded into a per-channel affine, NHWC (channel = fastest dim) ------------------------
 __global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                                float* shift, int C, float eps) {

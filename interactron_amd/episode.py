@@ -262,7 +262,7 @@ class _Adaptive(_EpisodeModel):
                     pre = self.detector(nt)
                     pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
                     loss_map = self.fusion(pre)["loss"].reshape(E, -1)
-                    learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
+                    learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
                     grads = self._inner_grad(learned, dtheta, False)
                     set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
                 with torch.no_grad():
@@ -304,7 +304,7 @@ class _Adaptive(_EpisodeModel):
         fusion_out = self.fusion(pre)
         st.mark("2 fusion fwd")
         loss_map = fusion_out["loss"].reshape(E, -1)
-        learned = torch.stack([ops.l2_norm(loss_map[i]) for i in range(E)]).sum()
+        learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
         st.grads = grads = self._inner_grad(learned, dtheta, True)
         st.mark("3 learned-loss grad (create_graph)")
         set_parameters(self.detector, sgd_step(dtheta, grads, lr))

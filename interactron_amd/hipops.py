@@ -9,6 +9,7 @@ meta-gradient of reference models/interactron.py:99-123 -- runs entirely on thes
 No CPU fallback exists: calling any op without the built library or with CPU tensors raises.
 """
 import ctypes
+import gc as _gc
 import os
 from collections import namedtuple
 
@@ -893,6 +894,7 @@ def attn_split_multi(ops, n, H, hd, tr_form=None):
 
 
 _bias_cache = {}
+_gc_was_on = [True]
 _capture = [None]   # capture-local cache of additive key biases while a HIP-graph capture is running
 
 
@@ -900,13 +902,22 @@ def capture_begin(salt):
     """Called around a HIP-graph capture of launches from this module (graphs.ChunkGraphs).  `salt`: int64 device tensor every
     dropout kernel of the capture XORs into its seed at run time (ix_set_dropout_salt), so that a replay draws fresh masks.
     Tensors cached across calls must not be created inside a capture (their kernels only run at replay) nor evicted while a
-    graph reads them by address: the key-bias cache is replaced by a private one for the duration."""
+    graph reads them by address: the key-bias cache is replaced by a private one for the duration.
+    The cyclic garbage collector is emptied first and held off until capture_end: a dead ChunkGraphs <-> model cycle of an
+    earlier signature owns CUDAGraph objects and pool memory, and torch 2.10's torch.cuda.graph no longer collects before a
+    capture -- their destructors running on whichever thread trips the collector mid-capture abort the process
+    (gpurun_out r4r: "Fatal Python error: Aborted / Garbage-collecting" inside graphs.capture, 5 of 5 runs on one box)."""
+    _gc_was_on[0] = _gc.isenabled()
+    _gc.collect()
+    _gc.disable()
     _capture[0] = {}
     _chk(_L().ix_set_dropout_salt(salt.data_ptr() if salt is not None else None), "ix_set_dropout_salt")
 
 
 def capture_end():
     _capture[0] = None
+    if _gc_was_on[0]:
+        _gc.enable()
     _chk(_L().ix_set_dropout_salt(None), "ix_set_dropout_salt")
 
 
@@ -1334,6 +1345,56 @@ class ScaleDev(Function):
 def l2_norm(x):
     """torch.norm(x): sqrt(sum x^2).  The 1-element sqrt stays a torch scalar op (plumbing)."""
     return torch.sqrt(Dot.call(x, x))
+
+
+class RowNormSum(Function):
+    """sum_e ||x_e||_2 over the rows of x [E, n] -> 0-d tensor, ONE launch (the learned loss of a chunk of episodes: reference
+    models/interactron.py:96 per task).  Closed under the differentiation MAML needs: its backward is RowNormSumBwd, whose
+    own backward is one more kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x)
+        E, n = x.shape
+        norms = torch.empty(E, device=x.device, dtype=torch.float32)
+        total = torch.empty((), device=x.device, dtype=torch.float32)
+        _chk(_L().ix_rownorm_sum_f32(x.data_ptr(), norms.data_ptr(), total.data_ptr(), E, n, _stream()), "ix_rownorm_sum_f32")
+        ctx.save_for_backward(x, norms)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        x, norms = ctx.saved_tensors
+        return RowNormSumBwd.call(x, norms, g)
+
+
+class RowNormSumBwd(Function):
+    """y = g x_e / ||x_e|| (g a 0-d tensor); norms are a function of x kept as a constant operand: the backward below carries
+    their derivative (the - x <H, x> / n^3 term)."""
+
+    @staticmethod
+    def forward(ctx, x, norms, g):
+        x, g = _req(x), _req(g)
+        ctx.save_for_backward(x, norms, g)
+        out = torch.empty_like(x)
+        _chk(_L().ix_rownorm_sum_bwd_f32(x.data_ptr(), norms.data_ptr(), g.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                         _stream()), "ix_rownorm_sum_bwd_f32")
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, H):
+        x, norms, g = ctx.saved_tensors
+        H = _req(H)
+        Gx, Gg = torch.empty_like(x), torch.empty((), device=x.device, dtype=torch.float32)
+        _chk(_L().ix_rownorm_sum_bwd_bwd_f32(x.data_ptr(), norms.data_ptr(), g.data_ptr(), H.data_ptr(), Gx.data_ptr(),
+                                             Gg.data_ptr(), x.shape[0], x.shape[1], _stream()), "ix_rownorm_sum_bwd_bwd_f32")
+        return Gx, None, Gg
+
+
+def rownorm_sum(x):
+    """sum of the L2 norms of the rows of x [E, n]"""
+    return RowNormSum.call(x)
 
 
 class Relu(Function):

@@ -312,3 +312,35 @@ def test_reference_matching_replays_call_by_call_when_ordered(lib):
     with _pt.raises(AssertionError):
         with ReferenceMatching(bad, ordered=True):
             m.assign([cost], [tgt])
+
+
+def test_graph_captures_hold_the_cyclic_collector_off(lib):
+    """hipops.capture_begin / capture_end bracket every HIP-graph capture (graphs.ChunkGraphs, PredictGraph, the policy graph):
+    dead model <-> graph cycles are collected BEFORE the capture and the collector stays off until it ends -- a CUDAGraph
+    destructor running mid-capture aborts the process (round 4, gpurun_out r4r)."""
+    import gc
+    from interactron_amd import hipops as ops
+
+    class Node:
+        freed = []
+
+        def __del__(self):
+            Node.freed.append(gc.isenabled())
+
+    a, b = Node(), Node()
+    a.other, b.other = b, a
+    del a, b
+    assert gc.isenabled()
+    ops.capture_begin(None)
+    try:
+        assert Node.freed == [True, True] and not gc.isenabled()
+    finally:
+        ops.capture_end()
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        ops.capture_begin(None)
+        ops.capture_end()
+        assert not gc.isenabled()      # a caller's own setting survives
+    finally:
+        gc.enable()

@@ -81,6 +81,19 @@ def test_linear(ops, R, K, N):
              [rnd(R, K), rnd(N, K, scale=K ** -0.5), rnd(N)], name="linear %dx%dx%d" % (R, K, N))
 
 
+@pytest.mark.parametrize("E,n", [(16, 250), (2, 250), (1, 50), (37, 130)])
+def test_rownorm_sum_first_and_second_order(ops, E, n):
+    """hipops.RowNormSum (the learned loss of a chunk of episodes, sum_e ||loss_e||, in one launch) against float64 autograd:
+    value, gradient, and the gradient of a functional of the gradient w.r.t. x and the incoming cotangent (what the MAML
+    meta-gradient asks of it); a zero row has zero gradient (torch.norm's convention)."""
+    check_op(lambda x: ops.rownorm_sum(x), lambda x: x.norm(dim=1).sum(), [rnd(E, n, seed=3)], tol=2e-5, name="rownorm_sum")
+    x = rnd(E, n, seed=4)
+    x[0] = 0.0
+    xh = x.cuda().requires_grad_(True)
+    (g,) = torch.autograd.grad(ops.rownorm_sum(xh), [xh])
+    assert bool(torch.isfinite(g).all()) and float(g[0].abs().max()) == 0.0
+
+
 def test_linear_large_tile_and_splitk(ops):
     # 128x128 tile path (many tiles) and the split-K path (small output, long K)
     check_op(lambda x, w: ops.linear(x, w), lambda x, w: F.linear(x, w), [rnd(2100, 320), rnd(2048, 320, scale=0.05)],
