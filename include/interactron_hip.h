@@ -66,6 +66,12 @@ int ix_gemm_presplit_enable(int on);
  * takes runs on its h plane alone (one fp16 value of x * 2^-E per element, block exponent per 32 x 32 sub-block, ONE MFMA per
  * k-slice, fp32 accumulation).  NOT fp32-grade; process-global; never the parity path.  Returns the previous setting. */
 int ix_gemm_set_single_pass(int on);
+/* 256 x 128 x 32 tiles of the fp16x3 form (gemm_f32_f16x3_w256_kernel, csrc/gemm.hip: eight waves, 128 x 64 outputs per consumer
+ * wave) for plain contractions -- same reference operators as ix_gemm_f32_ws, bit-identical results to its 128 x 128 tiles.
+ * mode 0: never, 1 (default): where the cost model prefers it, 2: every eligible contraction.  Returns the previous mode.
+ * ix_gemm_w256_launches: launches taken so far (tests / bench). */
+int ix_gemm_set_w256(int mode);
+int ix_gemm_w256_launches(int64_t* out);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls);
 int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3); /* by form: fp32 / bf16x6 / fp16x3 */ /* profiled ix_gemm_f32_ws calls on the fp16x3 path */
 /* ALGORITHMIC HBM bytes of the profiled contraction launches by the same three forms: 4 (M K + K N + M N) per batch slice -- each

@@ -608,31 +608,34 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = KC ? row_of(tid, i) : (tid >> 3) * 4 + i;
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-            f32x2 x0, x1;
-            x0.x = e[i][0] * sc; x0.y = e[i][1] * sc; x1.x = e[i][2] * sc; x1.y = e[i][3] * sc;
-            const f16x2 h0 = __builtin_convertvector(x0, f16x2), h1 = __builtin_convertvector(x1, f16x2);
+            // two instructions per element (round 4, as in gemm_wp.hip): h = f16(x * sc) by v_fma_mixlo/hi_f16 (the product with a
+            // power of two is exact: one rounding, the same bits as v_mul + v_cvt), l = f16(x * sc - h) by the same instruction
+            // reading h's half directly (the fp32 residual is exact, so rounding the fused result once gives the same bits as
+            // v_fma_mix_f32 + v_cvt) -- 2 instead of 3 instructions per element, and no separate pack
+            unsigned hb0, hb1;
+            asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                : "=&v"(hb0) : "v"(e[i][0]), "v"(e[i][1]), "v"(sc));
+            asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+                : "=&v"(hb1) : "v"(e[i][2]), "v"(e[i][3]), "v"(sc));
             if (ONE) {   // single-pass form: the rounded value is the operand
                 u32x2 ph1;
-                ph1.x = __builtin_bit_cast(unsigned, h0); ph1.y = __builtin_bit_cast(unsigned, h1);
+                ph1.x = hb0; ph1.y = hb1;
                 *(lds_u2*)(planes + row * X6_ROWB + (tid & 7) * 8) = ph1;
                 continue;
             }
-            // residual x * sc - float(h) in ONE instruction per element (v_fma_mix_f32 reads the fp16 half directly; exact: the
-            // scale is a power of two and a float minus its own fp16 rounding is representable), instead of a conversion
-            // back plus a packed fma
-            f32x2 r0, r1;
-            const unsigned hb0 = __builtin_bit_cast(unsigned, h0), hb1 = __builtin_bit_cast(unsigned, h1);
-            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0.x) : "v"(e[i][0]), "v"(sc), "v"(hb0));
-            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r0.y) : "v"(e[i][1]), "v"(sc), "v"(hb0));
-            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r1.x) : "v"(e[i][2]), "v"(sc), "v"(hb1));
-            asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1.y) : "v"(e[i][3]), "v"(sc), "v"(hb1));
-            const f16x2 l0 = __builtin_convertvector(r0, f16x2), l1 = __builtin_convertvector(r1, f16x2);
+            unsigned lb0, lb1;
+            asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                : "=&v"(lb0) : "v"(e[i][0]), "v"(e[i][1]), "v"(sc), "v"(hb0));
+            asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+                "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                : "=&v"(lb1) : "v"(e[i][2]), "v"(e[i][3]), "v"(sc), "v"(hb1));
             unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
             u32x2 ph, pl;
-            ph.x = __builtin_bit_cast(unsigned, h0); ph.y = __builtin_bit_cast(unsigned, h1);
-            pl.x = __builtin_bit_cast(unsigned, l0); pl.y = __builtin_bit_cast(unsigned, l1);
+            ph.x = hb0; ph.y = hb1;
+            pl.x = lb0; pl.y = lb1;
             *(lds_u2*)(dst) = ph;
             *(lds_u2*)(dst + PLANE) = pl;
         }
@@ -878,7 +881,7 @@ struct X6Item {
     int m0, n0, kbeg, kend, nk, ks;
 };
 
-template <int BN>
+template <int BN, int BM = X6_BT>
 __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     X6Item it;
     const int nt = p.tiles_m * p.tiles_n, per_batch = nt * p.split_k;
@@ -888,7 +891,7 @@ __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     const int group_size = GROUP_M * p.tiles_n;
     const int first_m = (tile / group_size) * GROUP_M;
     const int gm = min(p.tiles_m - first_m, GROUP_M);
-    it.m0 = (first_m + (tile % group_size) % gm) * X6_BT;
+    it.m0 = (first_m + (tile % group_size) % gm) * BM;
     it.n0 = ((tile % group_size) / gm) * BN;
     const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
     it.A = p.A + bo * p.sAo + bi * p.sAi;
@@ -1249,6 +1252,11 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     static_assert(G == 0 || (G == 1 && KC && !IS_B) || ((G == 2 || G == 3) && !KC && IS_B), "gather mode vs operand layout");
     SplitLoader<BT, KC, SWZ, X3, ONE> s0, s1, s2;
     X6_BC_DECL
+#ifndef X3_NO_SETPRIO
+    // the producers are the critical path of a K step (tools/gemm_kstep_summary.py: the consumers wait ~ 900 of ~ 2 600 clocks
+    // at the barrier): their instructions go first whenever they can issue, the matrix wave fills the rest
+    if (X3) __builtin_amdgcn_s_setprio(3);
+#endif
 #ifdef X6_DIAG_TIMING
     const int lane = pt & 63, wave = IS_B ? 100 : 4 + (pt >> 6);   // (stamps: the first A-producer wave)
     int dbgn = 0;
@@ -1663,6 +1671,182 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     }
 
     // ---------------------------------------------------- consumers ----------------------------------------------------
+#ifdef X3_M16
+    // Round-4 experiment (-DX3_M16; NOT the product build): v_mfma_f32_16x16x32_f16 instead of 32x32x16.
+    // tools/micro/mfma_valu_overlap.hip: a back-to-back stream of 32x32x16 instructions (16 result registers per 32 clocks)
+    // starves the LDS reads and global loads of the SIMD's other waves (<= 10 % of their time hidden: they run after the matrix
+    // wave), under 16x16x32 (4 result registers per 16 clocks, the same matrix-pipe time per product) 81 % of the LDS read time
+    // and 47 % of the global load time is hidden.  In THIS kernel it changes nothing (tools/w256_bench.py, 20 shapes: 2 640 us
+    // either way): the consumers are not its critical path -- tools/gemm_kstep_summary.py: they wait ~ 900 of every ~ 2 600
+    // clocks at the barrier for the producers.  Kept for the record; passes the same accuracy tests (different rounding order
+    // inside a K tile, so not bit-identical to the 32x32x16 form).  The wave's 64 x 64 outputs are 4 x 4 blocks of
+    // 16 x 16; one instruction spans the whole K tile; the tile is worked off in four quarters (A half x B half: 12
+    // instructions each) so that only 64 fragment registers are live: q1 (A0 B0) while A1, B1 of the tile are fetched, q2
+    // (A0 B1), barrier, q3 (A1 B0) while the next tile's A0 arrives, q4 (A1 B1) while its B0 arrives.
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
+    const int l16 = lane & 15, lg = lane >> 4;
+    const int lrow = lg, lcol = l16;
+    (void)lrow; (void)lcol;
+    x3_f16x8 fa[2][2][2], fb[2][2][2];   // [half of the wave's rows][plane h, l][16-row block]
+    X6_BC_DECL
+#define M16_LDA(H, BASE)                                                                                              \
+    _Pragma("unroll") for (int pl = 0; pl < (ONE ? 1 : 2); ++pl) _Pragma("unroll") for (int b = 0; b < 2; ++b)          \
+        fa[H][pl][b] = *reinterpret_cast<const x3_f16x8*>((BASE) + pl * PLANE_A + (wm + (H) * 32 + b * 16 + l16) * ROWB + lg * 16);
+#define M16_LDB(H, BASE)                                                                                              \
+    _Pragma("unroll") for (int pl = 0; pl < (ONE ? 1 : 2); ++pl) _Pragma("unroll") for (int b = 0; b < 2; ++b)          \
+        fb[H][pl][b] = *reinterpret_cast<const x3_f16x8*>((BASE) + 2 * PLANE_A + pl * PLANE_B + (wn + (H) * 32 + b * 16 + l16) * ROWB + lg * 16);
+#define M16_T(HA, HB, PA_, PB_)                                                                                       \
+    _Pragma("unroll") for (int ba = 0; ba < 2; ++ba) _Pragma("unroll") for (int bb = 0; bb < 2; ++bb)                   \
+        acc[2 * (HA) + ba][2 * (HB) + bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[HA][PA_][ba], fb[HB][PB_][bb], acc[2 * (HA) + ba][2 * (HB) + bb], 0, 0, 0);
+#define X3Q_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef X3_DIAG_NOMMA   // diagnostic build: one of the three terms (wrong numbers)
+#define M16_Q(HA, HB) M16_T(HA, HB, 0, 0) X3Q_SB
+#else
+#define M16_Q(HA, HB)                                                                                                 \
+    if (ONE) { M16_T(HA, HB, 0, 0) X3Q_SB } else { M16_T(HA, HB, 1, 0) M16_T(HA, HB, 0, 1) M16_T(HA, HB, 0, 0) X3Q_SB }
+#endif
+#define X3Q_EXPO(B_)                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) eA[i] = __builtin_amdgcn_readfirstlane(expo[B_][wm / 32 + i]);    \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) eB[j] = __builtin_amdgcn_readfirstlane(expo[B_][4 + wn / 32 + j]);
+    int buf = 0;
+    int eA[TM], eB[TN];
+    x6_lds_barrier();   // flat tile 0 is visible
+    X3Q_EXPO(0)
+    M16_LDA(0, lds[0]) M16_LDB(0, lds[0])
+    int dbgn = 0;
+    (void)dbgn;
+    for (; w < last; w += stride) {
+        X6_STAMP(0, 10)
+        const X6Item it = x6_item<BN>(p, w);
+        x6_f32x4 acc[4][4];
+        int U[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) U[i][j] = -1000;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = x6_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < it.nk; ++kt) {
+            // the tile about to be added is expressed in 2^(eA + eB): bring the sums there first (never upwards)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int E = eA[i] + eB[j];
+                    if (E != U[i][j]) {   // wave-uniform; rare: first tile of an item, or a sub-block maximum that grew
+                        const int d = max(U[i][j] - E, -400);
+#pragma unroll
+                        for (int ba = 0; ba < 2; ++ba)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    acc[2 * i + ba][2 * j + bb][r] = __builtin_amdgcn_ldexpf(acc[2 * i + ba][2 * j + bb][r], d);
+                        U[i][j] = E;
+                    }
+                }
+            X3Q_SB
+            M16_LDB(1, lds[buf]) M16_LDA(1, lds[buf]) X3Q_SB
+            M16_Q(0, 0)
+            M16_Q(0, 1)
+            const bool more = kt + 1 < it.nk || w + stride < last;
+            X6_STAMP(0, 12)
+            if (more) x6_lds_barrier();   // (every read of this tile has returned: the producers may overwrite it)
+            X6_STAMP(0, 13)
+            const int nbuf = more ? buf ^ 1 : buf;
+            const unsigned char* nb = lds[nbuf];
+            X3Q_EXPO(nbuf)
+            X3Q_SB
+            M16_LDA(0, nb) X3Q_SB
+            M16_Q(1, 0)
+            M16_LDB(0, nb) X3Q_SB
+            M16_Q(1, 1)
+            X6_STAMP(0, 15)
+            buf ^= 1;
+        }
+        X6_STAMP(0, 14)
+        const bool add_bias = it.bias != nullptr && it.ks == 0;
+        if (staged) {
+            float* ct = cstrip[wave];
+            constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;   // float4 chunks per strip row / per lane
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int cl = wn + jb * 16 + l16;
+                    const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
+                    const int u = max(U[i][jb >> 1], -400);
+#pragma unroll
+                    for (int ba = 0; ba < 2; ++ba)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ct[(ba * 16 + 4 * lg + r) * CP + jb * 16 + l16] = p.alpha * __builtin_amdgcn_ldexpf(acc[2 * i + ba][jb][r], u) + bv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int r0 = it.m0 + wm + i * 32, c0 = it.n0 + wn;
+                if (r0 + 32 <= p.M && c0 + WN <= p.N) {
+                    float4 v[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        v[q] = *reinterpret_cast<const float4*>(&ct[(c / CPR) * CP + (c % CPR) * 4]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        *reinterpret_cast<float4*>(it.C + (int64_t)(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        const int row = c / CPR, col = (c % CPR) * 4;
+                        const int gr = r0 + row, gc = c0 + col;
+                        if (gr >= p.M || gc >= p.N) continue;
+                        const float* src = &ct[row * CP + col];
+                        float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                        dst[0] = src[0];
+                        if (gc + 1 < p.N) dst[1] = src[1];
+                        if (gc + 2 < p.N) dst[2] = src[2];
+                        if (gc + 3 < p.N) dst[3] = src[3];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const int col = it.n0 + wn + jb * 16 + l16;
+                    if (col >= p.N) continue;
+                    const float bv = add_bias ? it.bias[col] : 0.f;
+                    const int u = max(U[ib >> 1][jb >> 1], -400);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = it.m0 + wm + ib * 16 + 4 * lg + r;
+                        if (row < p.M) {
+                            const float v = p.alpha * __builtin_amdgcn_ldexpf(acc[ib][jb][r], u) + bv;
+                            float* dst = it.C + (int64_t)row * p.ldc + col;
+                            if (p.atomic)
+                                unsafeAtomicAdd(dst, v);
+                            else
+                                *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef M16_LDA
+#undef M16_LDB
+#undef M16_T
+#undef M16_Q
+#undef X3Q_SB
+#undef X3Q_EXPO
+#else   // the product build: 32x32x16 consumers (round 3)
     const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
     const int lrow = lane >> 5, lcol = lane & 31;
     const int ko0 = lrow * 16, ko1 = (2 + lrow) * 16;
@@ -1829,6 +2013,347 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
 #undef X3Q_SB
 #undef X3Q_SLICE
 #undef X3Q_EXPO
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 256 x 128 x 32 tiles of the fp16x3 form (round 4): EIGHT waves, two per SIMD -- four consumers of 128 x 64 outputs
+// each (TM = 4, TN = 2: 48 matrix instructions per K step and wave) and four producers that each own three 32 x 32
+// sub-blocks per K step (two of A, one of B).  Round 4's measurements (profiles/README.md, "What bounds a 128 x 128
+// contraction tile") say the 128 x 128 kernel runs out of bytes in flight, not of LDS bandwidth or matrix cycles: this
+// tile needs 48 KB of operands per K step for TWICE the products (0.75x the bytes per matrix instruction), keeps three
+// register stages x 48 KB in flight per CU, reads 0.75x the LDS bytes per product, and pays one workgroup barrier per
+// 96 matrix instructions per SIMD instead of one per 24.  The operand image of a stage is three independent 128-row
+// images (A rows 0-127, A rows 128-255, B) of two fp16 planes each, so SplitLoader<128, ., ., X3> serves all three with
+// the producer thread index it already expects.  Same arithmetic, same exponents, same epilogue as the 12-wave kernel:
+// bit-identical results (tests/test_ops_gpu.py::test_w256_kernel_*).  Plain contractions only (no gathers).
+// ------------------------------------------------------------------------------------------------------------
+#define W2_WAIT_ASM(S, CNT)                                                                                              \
+    asm volatile("s_waitcnt vmcnt(" #CNT ")"                                                                             \
+                 : "+v"(S##a0.v[0]), "+v"(S##a0.v[1]), "+v"(S##a0.v[2]), "+v"(S##a0.v[3]), "+v"(S##a1.v[0]), "+v"(S##a1.v[1]), \
+                   "+v"(S##a1.v[2]), "+v"(S##a1.v[3]), "+v"(S##b.v[0]), "+v"(S##b.v[1]), "+v"(S##b.v[2]), "+v"(S##b.v[3])::"memory");
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int pt, int* expo0) {
+    constexpr int BK = X6_BK, IMG = 2 * X6_PLANE, BUF = 3 * IMG;
+    typedef SplitLoader<128, A_KC, false, true, false> LA;
+    typedef SplitLoader<128, B_KC, false, true, false> LB;
+    static_assert(LA::NI == 4 && LB::NI == 4, "ring stage = 12 loads");
+    LA s0a0, s0a1, s1a0, s1a1, s2a0, s2a1;
+    LB s0b, s1b, s2b;
+    X6_BC_DECL
+#ifndef X3_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    int eA0 = -1000, eA1 = -1000, eB = -1000;      // running sub-block exponents of the item (store_x3)
+    int* const expo = expo0 + (pt >> 6);           // image words: A rows 0-127: 0-3, A rows 128-255: 4-7, B: 8-11
+    const int lda = (int)p.lda, ldb = (int)p.ldb;
+    const int extA = (int)(p.extA * 4), extB = (int)(p.extB * 4);
+    X6Item itL = x6_item<128, 256>(p, w), itS = itL;
+    int wL = w, tL = 0, wS = w, tS = 0, buf = 0;
+    bool moreL = true, moreS = true;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, extA, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, extB, 0x00020000);
+    constexpr bool RSUM = !A_KC;   // row sums of an m-contiguous A (see x6q_produce)
+    x6_f32x4 rsum0 = {0.f, 0.f, 0.f, 0.f}, rsum1 = {0.f, 0.f, 0.f, 0.f};
+#define W2_RSUM_ACC(S)                                                                                      \
+    if (RSUM && itS.rowsum) {                                                                               \
+        const int gk = itS.kbeg + tS * BK + (pt & 7) * 4;                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (gk + i < itS.kend) { rsum0 += S##a0.v[i]; rsum1 += S##a1.v[i]; } \
+    }
+#define W2_RSUM_FLUSH1(RS, MOFF)                                                                            \
+    {                                                                                                       \
+        _Pragma("unroll") for (int o = 1; o < 8; o <<= 1) {                                                 \
+            RS.x += __shfl_xor(RS.x, o); RS.y += __shfl_xor(RS.y, o);                                       \
+            RS.z += __shfl_xor(RS.z, o); RS.w += __shfl_xor(RS.w, o);                                       \
+        }                                                                                                   \
+        if ((pt & 7) == 0) {                                                                                \
+            const int m = itS.m0 + (MOFF) + (pt >> 3) * 4;                                                  \
+            float* dst = itS.rowsum + m;                                                                    \
+            if (p.atomic) {                                                                                 \
+                if (m + 0 < p.M) unsafeAtomicAdd(dst + 0, RS.x);                                            \
+                if (m + 1 < p.M) unsafeAtomicAdd(dst + 1, RS.y);                                            \
+                if (m + 2 < p.M) unsafeAtomicAdd(dst + 2, RS.z);                                            \
+                if (m + 3 < p.M) unsafeAtomicAdd(dst + 3, RS.w);                                            \
+            } else {                                                                                        \
+                if (m + 0 < p.M) dst[0] = RS.x;                                                             \
+                if (m + 1 < p.M) dst[1] = RS.y;                                                             \
+                if (m + 2 < p.M) dst[2] = RS.z;                                                             \
+                if (m + 3 < p.M) dst[3] = RS.w;                                                             \
+            }                                                                                               \
+        }                                                                                                   \
+        RS = x6_f32x4{0.f, 0.f, 0.f, 0.f};                                                                  \
+    }
+#define W2_LD(S)                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    S##a0.load(rsA, lda, itL.m0, itL.kbeg + tL * BK, p.M, itL.kend, pt, moreL);                             \
+    S##a1.load(rsA, lda, itL.m0 + 128, itL.kbeg + tL * BK, p.M, itL.kend, pt, moreL);                       \
+    S##b.load(rsB, ldb, itL.n0, itL.kbeg + tL * BK, p.N, itL.kend, pt, moreL);                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if (++tL >= itL.nk) {                                                                                   \
+        tL = 0;                                                                                             \
+        wL += stride;                                                                                       \
+        moreL = wL < last;                                                                                  \
+        itL = x6_item<128, 256>(p, moreL ? wL : last - 1);                                                  \
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, extA, 0x00020000);                         \
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, extB, 0x00020000);                         \
+    }
+#define W2_STEP(S)                                                                                          \
+    W2_WAIT_ASM(S, 24)   /* the oldest ring stage has landed: two younger stages (24 loads) stay in flight */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    S##a0.store_x3(lds0 + buf * BUF, pt, itS.kbeg + tS * BK, itS.kend, eA0, expo + buf * 12);               \
+    S##a1.store_x3(lds0 + buf * BUF + IMG, pt, itS.kbeg + tS * BK, itS.kend, eA1, expo + buf * 12 + 4);     \
+    S##b.store_x3(lds0 + buf * BUF + 2 * IMG, pt, itS.kbeg + tS * BK, itS.kend, eB, expo + buf * 12 + 8);   \
+    W2_RSUM_ACC(S)                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    buf ^= 1;                                                                                               \
+    if (++tS >= itS.nk) {                                                                                   \
+        if (RSUM && itS.rowsum) { W2_RSUM_FLUSH1(rsum0, 0) W2_RSUM_FLUSH1(rsum1, 128) }                     \
+        eA0 = eA1 = eB = -1000;                                                                             \
+        tS = 0;                                                                                             \
+        wS += stride;                                                                                       \
+        moreS = wS < last;                                                                                  \
+        if (moreS) itS = x6_item<128, 256>(p, wS);                                                          \
+    }                                                                                                       \
+    W2_LD(S)                                                                                                \
+    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */
+    W2_LD(s0)
+    W2_LD(s1)
+    W2_LD(s2)
+    for (;;) {
+        W2_STEP(s0)
+        if (!moreS) break;
+        W2_STEP(s1)
+        if (!moreS) break;
+        W2_STEP(s2)
+        if (!moreS) break;
+    }
+#undef W2_LD
+#undef W2_STEP
+#undef W2_RSUM_ACC
+#undef W2_RSUM_FLUSH1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may be in flight when the wave ends
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 1) void gemm_f32_f16x3_w256_kernel(GemmArgs p, int total_items) {
+    constexpr int ROWB = X6_ROWB, PLANE = X6_PLANE, IMG = 2 * PLANE, BUF = 3 * IMG;
+    constexpr int TM = 4, TN = 2, WN = 64, CP = WN + 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
+    __shared__ __attribute__((aligned(16))) float cstrip[4][32 * CP];
+    __shared__ int expo[2][12];   // [image][A rows 0-127: 0-3, A rows 128-255: 4-7, B: 8-11]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_xcd = (total_items + 7) >> 3, xcd = blockIdx.x & 7;
+    const int stride = gridDim.x >> 3, last = min(total_items, (xcd + 1) * per_xcd);
+    int w = xcd * per_xcd + (blockIdx.x >> 3);
+    if (w >= last) return;
+    const bool staged = !p.atomic && p.c_vec;
+
+    if (wave >= 4) {
+        w2_produce<A_KC, B_KC>(p, w, stride, last, &lds[0][0], tid - 256, &expo[0][0]);
+        return;
+    }
+
+    // ---------------------------------------------------- consumers ----------------------------------------------------
+    const int img = wave >> 1, wn = (wave & 1) * WN;   // A image (rows 128 img .. + 127 of the tile), B rows wn .. wn + 63
+    const int lrow = lane >> 5, lcol = lane & 31;
+    const int ko0 = lrow * 16, ko1 = (2 + lrow) * 16;
+    x3_f16x8 ahx[TM], ahy[TM], al[TM], bhx[TN], bhy[TN], bl[TN];
+    X6_BC_DECL
+#define W2_LDA(DST, PL, BASE, S)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) DST[i] = *reinterpret_cast<const x3_f16x8*>(                      \
+        (BASE) + img * IMG + (PL) * PLANE + (i * 32 + lcol) * ROWB + ((S) ? ko1 : ko0));
+#define W2_LDB(DST, PL, BASE, S)                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) DST[j] = *reinterpret_cast<const x3_f16x8*>(                      \
+        (BASE) + 2 * IMG + (PL) * PLANE + (wn + j * 32 + lcol) * ROWB + ((S) ? ko1 : ko0));
+#define W2_MM(FA, FB)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] =         \
+        __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+#define W2_SB __builtin_amdgcn_sched_barrier(0);
+    // one k-slice on (A0C, al, B0C, bl); meanwhile the next slice's fragments are fetched (as in the 12-wave kernel)
+#ifdef X3_DIAG_NOMMA   // diagnostic build (tools/w256_diag.py): one of the three terms (wrong numbers)
+#define W2_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                      \
+    W2_LDA(A0N, 0, NBASE, NS) W2_LDB(B0N, 0, NBASE, NS) W2_SB                                                        \
+    W2_LDA(al, 1, NBASE, NS) W2_SB W2_LDB(bl, 1, NBASE, NS) W2_SB                                                    \
+    W2_MM(A0C, B0C) W2_SB
+#else
+#define W2_SLICE(A0C, B0C, A0N, B0N, NBASE, NS)                                                                      \
+    W2_LDA(A0N, 0, NBASE, NS) W2_LDB(B0N, 0, NBASE, NS) W2_SB                                                        \
+    W2_MM(al, B0C) W2_SB W2_LDA(al, 1, NBASE, NS) W2_SB                                                              \
+    W2_MM(A0C, bl) W2_SB W2_LDB(bl, 1, NBASE, NS) W2_SB                                                              \
+    W2_MM(A0C, B0C) W2_SB
+#endif
+#define W2_EXPO(B_)                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) eA[i] = __builtin_amdgcn_readfirstlane(expo[B_][4 * img + i]);    \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) eB[j] = __builtin_amdgcn_readfirstlane(expo[B_][8 + wn / 32 + j]);
+    int buf = 0;
+    int eA[TM], eB[TN];
+    x6_lds_barrier();   // flat tile 0 is visible
+    W2_EXPO(0)
+    W2_LDA(ahx, 0, lds[0], 0) W2_LDB(bhx, 0, lds[0], 0)
+    W2_LDA(al, 1, lds[0], 0) W2_LDB(bl, 1, lds[0], 0)
+    for (; w < last; w += stride) {
+        const X6Item it = x6_item<128, 256>(p, w);
+        f32x16 acc[TM][TN];
+        int U[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                U[i][j] = -1000;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            }
+        for (int kt = 0; kt < it.nk; ++kt) {
+            // the tile about to be added is expressed in 2^(eA + eB): bring the sums there first (never upwards)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int E = eA[i] + eB[j];
+                    if (E != U[i][j]) {   // wave-uniform; rare: first tile of an item, or a sub-block maximum that grew
+                        const int d = max(U[i][j] - E, -400);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = __builtin_amdgcn_ldexpf(acc[i][j][r], d);
+                        U[i][j] = E;
+                    }
+                }
+            W2_SB
+            W2_SLICE(ahx, bhx, ahy, bhy, lds[buf], 1)
+            const bool more = kt + 1 < it.nk || w + stride < last;
+            if (more) x6_lds_barrier();
+            const int nbuf = more ? buf ^ 1 : buf;
+            const unsigned char* nb = lds[nbuf];
+            W2_EXPO(nbuf)
+            W2_SB
+            W2_SLICE(ahy, bhy, ahx, bhx, nb, 0)
+            buf ^= 1;
+        }
+        const bool add_bias = it.bias != nullptr && it.ks == 0;
+        if (staged) {
+            float* ct = cstrip[wave];
+            constexpr int CPR = WN / 4, NQ = 32 * CPR / 64;   // float4 chunks per strip row / per lane
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int cl = wn + j * 32 + lcol;
+                    const float bv = (add_bias && it.n0 + cl < p.N) ? it.bias[it.n0 + cl] : 0.f;
+                    const int u = max(U[i][j], -400);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        ct[((r & 3) + 8 * (r >> 2) + 4 * lrow) * CP + j * 32 + lcol] =
+                            p.alpha * __builtin_amdgcn_ldexpf(acc[i][j][r], u) + bv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const int r0 = it.m0 + img * 128 + i * 32, c0 = it.n0 + wn;
+                if (r0 + 32 <= p.M && c0 + WN <= p.N) {
+                    float4 v[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        v[q] = *reinterpret_cast<const float4*>(&ct[(c / CPR) * CP + (c % CPR) * 4]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        *reinterpret_cast<float4*>(it.C + (int64_t)(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
+                    }
+                } else if (r0 < p.M && c0 < p.N) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        const int row = c / CPR, col = (c % CPR) * 4;
+                        const int gr = r0 + row, gc = c0 + col;
+                        if (gr >= p.M || gc >= p.N) continue;
+                        const float* src = &ct[row * CP + col];
+                        float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                        dst[0] = src[0];
+                        if (gc + 1 < p.N) dst[1] = src[1];
+                        if (gc + 2 < p.N) dst[2] = src[2];
+                        if (gc + 3 < p.N) dst[3] = src[3];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = it.n0 + wn + j * 32 + lcol;
+                    if (col >= p.N) continue;
+                    const float bv = add_bias ? it.bias[col] : 0.f;
+                    const int u = max(U[i][j], -400);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = it.m0 + img * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lrow;
+                        if (row < p.M) {
+                            const float v = p.alpha * __builtin_amdgcn_ldexpf(acc[i][j][r], u) + bv;
+                            float* dst = it.C + (int64_t)row * p.ldc + col;
+                            if (p.atomic)
+                                unsafeAtomicAdd(dst, v);
+                            else
+                                *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#undef W2_LDA
+#undef W2_LDB
+#undef W2_MM
+#undef W2_SB
+#undef W2_SLICE
+#undef W2_EXPO
+}
+
+// 0: never; 1 (default): where the cost model prefers it; 2: every eligible contraction (tests).  IX_GEMM_W256 / ix_gemm_set_w256.
+static int g_w256 = -1;
+static int w256_mode() {
+    if (g_w256 < 0) {
+        const char* e = getenv("IX_GEMM_W256");
+        g_w256 = e ? atoi(e) : 1;
+        if (g_w256 < 0 || g_w256 > 2) g_w256 = 1;
+    }
+    return g_w256;
+}
+extern "C" int ix_gemm_set_w256(int mode) {
+    const int old = w256_mode();
+    g_w256 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return old;
+}
+// cost of a 256 x 128 x 32 step in units of the 12-wave kernel's 128 x 128 x 32 step (IX_W256_RATIO overrides: tuning runs)
+static double w256_step_ratio() {
+    static double r = -1.0;
+    if (r < 0) {
+        const char* e = getenv("IX_W256_RATIO");
+        r = e ? atof(e) : 0.0;   // 0: the fitted per-layout ratios of gemm_impl
+        if (r < 0.5 || r > 4.0) r = 0.0;
+    }
+    return r;
+}
+static int64_t g_w256_launches = 0;
+extern "C" int ix_gemm_w256_launches(int64_t* out) {
+    if (out) *out = g_w256_launches;
+    return IX_OK;
+}
+
+static void launch_w256(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    const dim3 grid(g);
+    g_w256_launches += 1;
+    if (a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_w256_kernel<true, true>), grid, dim3(512), 0, stream, a, items);
+    else if (a_kc && !b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_w256_kernel<true, false>), grid, dim3(512), 0, stream, a, items);
+    else if (!a_kc && b_kc)
+        hipLaunchKernelGGL((gemm_f32_f16x3_w256_kernel<false, true>), grid, dim3(512), 0, stream, a, items);
+    else
+        hipLaunchKernelGGL((gemm_f32_f16x3_w256_kernel<false, false>), grid, dim3(512), 0, stream, a, items);
 }
 
 // Opt-in (IX_GEMM_KERNEL=x3, or ix_gemm_set_x3 from the tests).  Measured on the step's 24 heaviest shapes: 93.4 vs 108.4 ms
@@ -2670,6 +3195,22 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     a.tiles_n = ix_div_up(N, bn);
     a.split_k = split;
     a.k_per_split = plan.kps;
+    // 256 x 128 tiles (gemm_f32_f16x3_w256_kernel) where they finish sooner: rounds of 256 workgroups x K steps x the
+    // measured cost of a K step (w256_step_ratio() x the 128 x 128 kernel's for twice the products)
+    bool use_w2 = false;
+    if (use_x6 && bn == 128 && x3k_enabled() && g_x6 == 3 && !g_single_pass && w256_mode() > 0 &&
+        (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30)) {
+        const int tm2 = ix_div_up(M, 256);
+        const int64_t it1 = (int64_t)a.tiles_m * a.tiles_n * nbatch * split, it2 = (int64_t)tm2 * a.tiles_n * nbatch * split;
+        const double r1 = (double)(((it1 + 7) / 8 + 31) / 32), r2 = (double)(((it2 + 7) / 8 + 31) / 32);
+        const double ks = (double)ix_div_up(plan.kps, 32);
+        // fitted on tools/w256_bench.py (alternating best-of-3, profiles/r4z_w256_bench_fair.txt): a 256 x 128 K step costs 1.94 of
+        // a 128 x 128 one with a k-contiguous A (0.97 per product), 2.15 with an m-contiguous A (its row sums and 4 x 4 register
+        // transposes ride on ONE producer wave per SIMD); short-K, C-store-bound shapes (K < 128) gain nothing
+        const double ratio = w256_step_ratio() > 0.0 ? w256_step_ratio() : (a_kcontig ? 1.94 : 2.15);
+        use_w2 = w256_mode() == 2 || (K >= 128 && r2 * (ks * ratio + 1.0) < 0.97 * r1 * (ks + 1.5));
+        if (use_w2) a.tiles_m = tm2;
+    }
     bool rowsum_in_kernel = false;
     if (rowsum) {
         if (use_x6 && !a_kcontig && batch_inner == 1 && g_x6 == 3) {
@@ -2717,7 +3258,9 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         launch_x6(a, bn, a_kcontig, b_kcontig, grid, stream);
     else
 #endif
-    if (use_x3)
+    if (use_w2)
+        launch_w256(a, a_kcontig, b_kcontig, items, stream);
+    else if (use_x3)
         launch_x3q(a, a_kcontig, b_kcontig, items, stream);
     else if (use_x6)
         launch_x6q<false>(a, bn, a_kcontig, b_kcontig, items, stream);

@@ -692,6 +692,92 @@ def test_f16x3_kernel_is_fp32_grade(ops, akc, bkc):
         assert errs[1] <= 2.5 * errs[0] + 1e-7, (M, N, K, kind, errs)
 
 
+def _w256_count(lib):
+    import ctypes
+    n = ctypes.c_int64(0)
+    assert lib.ix_gemm_w256_launches(ctypes.byref(n)) == 0
+    return n.value
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_w256_kernel_equals_the_128_tiles_bit_for_bit(ops, akc, bkc):
+    """gemm_f32_f16x3_w256_kernel (256 x 128 x 32 tiles, eight waves, round 4) against the 12-wave kernel's 128 x 128 tiles of
+    the same fp16x3 form: same sub-blocks, same exponents, same order of products => IDENTICAL bits -- every operand layout,
+    ragged M / N / K (a last tile with one valid row; an upper half-tile entirely outside), two batch levels, bias, alpha,
+    split-K planes and atomics, a strided C, magnitudes ramping along K (exponent changes inside an item), and the fused
+    row sums of an m-contiguous A; plus float64 as the anchor.  ix_gemm_set_w256(2) must really take the route."""
+    import ctypes
+    from interactron_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    # (M, N multiples of 4: the 16-byte loads of the 16-bit-plane kernels; other shapes stay on the exact-fp32 kernel)
+    cases = [(516, 260, 256, 2, 1, 1, 0, "plain"), (1804, 384, 1808, 1, 2, 3, 0, "plain"), (132, 128, 512, 3, 1, 1, 0, "plain"),
+             (640, 132, 2048, 1, 1, 1, 3, "ramp_up"), (1000, 256, 4000, 1, 1, 4, 0, "ramp_down"), (260, 132, 96, 2, 2, 1, 0, "rows")]
+    for (M, N, K, bo, bi, split, ldc_pad, kind) in cases:
+        b = bo * bi
+        a, w = rnd(b, M, K, seed=1), rnd(b, K, N, seed=3)
+        if kind == "rows":
+            a = a * (2.0 * rnd(b, M, 1, seed=2)).exp()
+        if kind.startswith("ramp"):
+            a = a * torch.exp2(torch.linspace(-20, 20, K) * (1 if kind == "ramp_up" else -1))[None, None, :]
+        a, w = a.cuda(), w.cuda()
+        bias = rnd(bo, N, seed=4).cuda()
+        A = a if akc else a.transpose(1, 2).contiguous()
+        B = w.transpose(1, 2).contiguous() if bkc else w
+        lda, ldb, ldc = (K if akc else M), (K if bkc else N), N + ldc_pad
+        nws = ctypes.c_size_t(0)
+        assert lib.ix_workspace_bytes_gemm_f32(M, N, K, akc, bkc, lda, ldb, bo, bi, bi * M * K, bi * K * N, A.data_ptr(),
+                                               B.data_ptr(), 1128, split, ctypes.byref(nws)) == 0
+        ws = torch.zeros(max(nws.value, 1 << 17), dtype=torch.uint8, device="cuda")
+        outs = {}
+        for mode in (0, 2):
+            old = lib.ix_gemm_set_w256(mode)
+            before = _w256_count(lib)
+            try:
+                C = torch.full((b, M, ldc), float("nan"), device="cuda")
+                rc = lib.ix_gemm_f32_ws(A.data_ptr(), B.data_ptr(), C.data_ptr(), bias.data_ptr(), M, N, K, akc, bkc, lda, ldb, ldc,
+                                        bo, bi, bi * M * K, M * K, bi * K * N, K * N, bi * M * ldc, M * ldc, N, 0.75, 1128, split,
+                                        ws.data_ptr(), ws.numel(), stream)
+                assert rc == 0, lib.ix_last_error()
+                torch.cuda.synchronize()
+            finally:
+                lib.ix_gemm_set_w256(old)
+            assert (_w256_count(lib) > before) == (mode == 2), (M, N, K, mode)
+            if ldc_pad:
+                assert bool(torch.isnan(C[:, :, N:]).all()), "wrote outside its rows"
+            outs[mode] = C[:, :, :N].clone()
+        assert torch.equal(outs[0], outs[2]), (M, N, K, kind, float((outs[0] - outs[2]).abs().max()))
+        ref = 0.75 * (a.double() @ w.double()) + bias.double().repeat_interleave(bi, 0)[:, None, :]
+        scale = 0.75 * (a.double().abs() @ w.double().abs()) + bias.double().abs().repeat_interleave(bi, 0)[:, None, :] + 1e-300
+        err = float(((outs[2].double() - ref).abs() / scale).max())
+        assert err <= (1.5e-6 if kind.startswith("ramp") else 6e-7), (M, N, K, kind, err)
+    if not akc:   # the bias gradient riding on the weight-gradient contraction (ix_gemm_rowsum_f32), with and without split-K
+        for (M, N, K, b) in [(512, 512, 32960, 1), (2048, 256, 1805, 4), (1236, 256, 1250, 2)]:
+            dy = (rnd(b, K, M, seed=1) + 0.25).cuda()
+            x = rnd(b, K, N, seed=2).cuda()
+            Bm = x.transpose(1, 2).contiguous() if bkc else x
+            nws = ctypes.c_size_t(0)
+            assert lib.ix_workspace_bytes_gemm_f32(M, N, K, 0, bkc, M, K if bkc else N, b, 1, K * M, K * N, dy.data_ptr(),
+                                                   Bm.data_ptr(), 0, 0, ctypes.byref(nws)) == 0
+            ws = torch.zeros(max(nws.value, 1 << 17), dtype=torch.uint8, device="cuda")
+            outs = {}
+            for mode in (0, 2):
+                old = lib.ix_gemm_set_w256(mode)
+                try:
+                    C = torch.full((b, M, N), float("nan"), device="cuda")
+                    rs = torch.full((b, M), float("nan"), device="cuda")
+                    rc = lib.ix_gemm_rowsum_f32(dy.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K, 0, bkc, M, K if bkc else N, N, b,
+                                                K * M, K * N, M * N, 1.0, rs.data_ptr(), M, ws.data_ptr(), ws.numel(), stream)
+                    assert rc == 0, lib.ix_last_error()
+                    torch.cuda.synchronize()
+                finally:
+                    lib.ix_gemm_set_w256(old)
+                outs[mode] = (C.clone(), rs.clone())
+            assert torch.equal(outs[0][0], outs[2][0]), (M, N, K, "product")
+            assert torch.equal(outs[0][1], outs[2][1]), (M, N, K, "row sums")
+            assert float(((outs[2][1].double() - dy.double().sum(1)).abs() / dy.double().abs().sum(1)).max()) < 2e-6
+
+
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_single_pass_contraction_is_16_bit_grade(ops, akc, bkc):
     """MODEL.COMPUTE_DTYPE: bf16 / fp16 (ix_gemm_set_single_pass): the h plane of the fp16x3 form alone, one MFMA per k-slice.
