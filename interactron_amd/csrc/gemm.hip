@@ -431,6 +431,34 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         }
     }
 
+    // Plain loads with the per-item part of the address hoisted out of the K loop (round 4: the producers are the kernel's
+    // critical path, csrc DESIGN 4.1c; load() spends 4 x (add, min, quarter-rate mul, add) per K step on values that only
+    // change with the item).  rb[]: KC -- element offset of this thread's i-th (clamped) tile row plus its k chunk; !KC --
+    // element offset of k line (tid & 7) * 4 + i plus the column chunk.  `valid` false is expressed by a zero-length
+    // buffer descriptor (every offset then returns zeros), not by a per-load select.
+    struct PlainRows {
+        int rb[NI];
+        __device__ __forceinline__ void setup(int ld, int t0, int tmax, int tid) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                rb[i] = KC ? min(t0 + row_of(tid, i), tmax - 1) * ld + (tid & 7) * 4 : ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4;
+        }
+    };
+    __device__ __forceinline__ void load_plain(__amdgpu_buffer_rsrc_t rsrc, int ld, const PlainRows& pr, int t0, int k0, int kmax, int tid) {
+        const bool tail = !KC && k0 + X6_BK > kmax;   // (wave-uniform) !KC: k lines past the K range are clamped to the last one
+        const int kl = KC ? k0 : k0 * ld;             // (uniform: a scalar multiply)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int off = pr.rb[i] + kl;
+            if (tail) off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
+            off *= 4;
+#ifdef X3_DIAG_NOLOAD
+            off = 0x7ffffff0;
+#endif
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
+
     // ---- implicit-GEMM gathers (ConvGather) ----
     // mode 1 (KC): this thread's NI pixel rows, decomposed once per item: image base (pixels), tap-0 source coordinates
     struct PixRows {
@@ -1262,6 +1290,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     int dbgn = 0;
 #endif
     typename SplitLoader<BT, KC, SWZ, X3, ONE>::PixRows pr;   // (mode 1 only; dead otherwise)
+    typename SplitLoader<BT, KC, SWZ, X3, ONE>::PlainRows plr;   // (plain operands only)
     int erun = -1000;                                    // fp16x3 form: running sub-block exponent of the item (store_x3)
     int* const expo = expo0 + (IS_B ? 4 : 0) + (pt >> 6);   // this wave's word in image 0 (image 1: + 8)
     const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
@@ -1271,6 +1300,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
     if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);
+    if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);
     // Row sums of an m-contiguous A operand (the bias gradient riding on the weight-gradient contraction): this thread
     // holds the same four rows (pt >> 3) * 4 .. + 3 in every K tile, so it keeps four running sums over its k lines; at
     // the end of an item the eight threads of a row group are combined and one of them adds the result to rowsum[m].
@@ -1313,15 +1343,17 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     else if (G == 3)                                                                                        \
         S.load_kremap(rs, p.cg, ld, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                       \
     else                                                                                                    \
-        S.load(rs, ld, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, tmax, itL.kend, pt, moreL);              \
+        S.load_plain(rs, ld, plr, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, itL.kend, pt);                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (++tL >= itL.nk) {                                                                                   \
         tL = 0;                                                                                             \
         wL += stride;                                                                                       \
         moreL = wL < last;                                                                                  \
         itL = x6_item<BN>(p, moreL ? wL : last - 1);                                                        \
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);          \
+        /* past the last item: a zero-length descriptor (plain loads return zeros without a per-load select) */ \
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, (G == 0 && !moreL) ? 0 : ext, 0x00020000); \
         if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);                                                       \
+        if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);                                        \
     }
 #define X6Q_STEP(S)                                                                                         \
     X6_STAMP(1, 0)                                                                                          \
@@ -1342,7 +1374,8 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         tS = 0;                                                                                             \
         wS += stride;                                                                                       \
         moreS = wS < last;                                                                                  \
-        if (moreS) itS = x6_item<BN>(p, wS);                                                                \
+        /* the load cursor runs three K tiles ahead: it normally sits in the item the store cursor enters */  \
+        if (moreS) { if (wS == wL) itS = itL; else itS = x6_item<BN>(p, wS); }                              \
     }                                                                                                       \
     X6Q_LD(S)                                                                                               \
     X6_STAMP(1, 3)                                                                                          \
@@ -2054,6 +2087,11 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, extA, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, extB, 0x00020000);
+    typename LA::PlainRows ra0, ra1;   // per-item row bases of the loads (SplitLoader::load_plain)
+    typename LB::PlainRows rb0;
+    ra0.setup(lda, itL.m0, p.M, pt);
+    ra1.setup(lda, itL.m0 + 128, p.M, pt);
+    rb0.setup(ldb, itL.n0, p.N, pt);
     constexpr bool RSUM = !A_KC;   // row sums of an m-contiguous A (see x6q_produce)
     x6_f32x4 rsum0 = {0.f, 0.f, 0.f, 0.f}, rsum1 = {0.f, 0.f, 0.f, 0.f};
 #define W2_RSUM_ACC(S)                                                                                      \
@@ -2086,17 +2124,20 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
     }
 #define W2_LD(S)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    S##a0.load(rsA, lda, itL.m0, itL.kbeg + tL * BK, p.M, itL.kend, pt, moreL);                             \
-    S##a1.load(rsA, lda, itL.m0 + 128, itL.kbeg + tL * BK, p.M, itL.kend, pt, moreL);                       \
-    S##b.load(rsB, ldb, itL.n0, itL.kbeg + tL * BK, p.N, itL.kend, pt, moreL);                              \
+    S##a0.load_plain(rsA, lda, ra0, itL.m0, itL.kbeg + tL * BK, itL.kend, pt);                              \
+    S##a1.load_plain(rsA, lda, ra1, itL.m0 + 128, itL.kbeg + tL * BK, itL.kend, pt);                        \
+    S##b.load_plain(rsB, ldb, rb0, itL.n0, itL.kbeg + tL * BK, itL.kend, pt);                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (++tL >= itL.nk) {                                                                                   \
         tL = 0;                                                                                             \
         wL += stride;                                                                                       \
         moreL = wL < last;                                                                                  \
         itL = x6_item<128, 256>(p, moreL ? wL : last - 1);                                                  \
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, extA, 0x00020000);                         \
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, extB, 0x00020000);                         \
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)itL.A, 0, moreL ? extA : 0, 0x00020000);             \
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)itL.B, 0, moreL ? extB : 0, 0x00020000);             \
+        ra0.setup(lda, itL.m0, p.M, pt);                                                                    \
+        ra1.setup(lda, itL.m0 + 128, p.M, pt);                                                              \
+        rb0.setup(ldb, itL.n0, p.N, pt);                                                                    \
     }
 #define W2_STEP(S)                                                                                          \
     W2_WAIT_ASM(S, 24)   /* the oldest ring stage has landed: two younger stages (24 loads) stay in flight */ \
@@ -2113,7 +2154,7 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
         tS = 0;                                                                                             \
         wS += stride;                                                                                       \
         moreS = wS < last;                                                                                  \
-        if (moreS) itS = x6_item<128, 256>(p, wS);                                                          \
+        if (moreS) { if (wS == wL) itS = itL; else itS = x6_item<128, 256>(p, wS); }                        \
     }                                                                                                       \
     W2_LD(S)                                                                                                \
     x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */
