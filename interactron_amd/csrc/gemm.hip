@@ -1271,7 +1271,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_bf16x6_persistent_kernel(Gemm
 
 // One operand's producer waves (256 threads): flat stream of K tiles over the workgroup's items, as in the 8-wave
 // kernel, for the A operand (IS_B false: BT = 128 rows of M) or the B operand (BT = BN rows of N).
-template <int BN, int BT, bool KC, bool IS_B, bool SWZ, int G = 0, bool X3 = false, bool ONE = false>
+// PIPE3 (fp16x3 kernel, -DX3_PIPE3): THREE LDS images and delayed visibility -- a producer does not wait for its plane
+// writes before the barrier of the step that issued them (LDS writes run at ~ 80 B / clock / CU, tools/micro/
+// mfma_valu_overlap.hip: the 32 KB of a K step drain for 400+ clocks) but before its NEXT writes; barrier #j therefore
+// publishes tile j - 1, the consumers run one barrier behind, and one extra barrier at the end publishes the last tile.
+template <int BN, int BT, bool KC, bool IS_B, bool SWZ, int G = 0, bool X3 = false, bool ONE = false, bool PIPE3 = false>
 __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride, int last, unsigned char* lds0, int buf_bytes,
                                             int plane_off, int pt, int* expo0 = nullptr) {
     constexpr int BK = X6_BK;
@@ -1358,6 +1362,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 #define X6Q_STEP(S)                                                                                         \
     X6_STAMP(1, 0)                                                                                          \
     X6Q_WAIT_STAGE(S)                                                                                       \
+    if (PIPE3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the previous tile's plane writes have landed */ \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     X6_STAMP(1, 1)                                                                                          \
     if (X3)                                                                                                 \
@@ -1367,7 +1372,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     X6Q_RSUM_ACC(S)                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     X6_STAMP(1, 2)                                                                                          \
-    buf ^= 1;                                                                                               \
+    if (PIPE3) buf = buf == 2 ? 0 : buf + 1; else buf ^= 1;                                                 \
     if (++tS >= itS.nk) {                                                                                   \
         X6Q_RSUM_FLUSH                                                                                      \
         erun = -1000;                                                                                       \
@@ -1379,7 +1384,12 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     }                                                                                                       \
     X6Q_LD(S)                                                                                               \
     X6_STAMP(1, 3)                                                                                          \
-    x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */           \
+    if (PIPE3) {        /* flat tile g - 1 is visible (waited for above); tile g's writes stay in flight */  \
+        asm volatile("" ::: "memory");                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                       \
+        asm volatile("" ::: "memory");                                                                      \
+    } else                                                                                                  \
+        x6_lds_barrier();   /* flat tile g is visible; the consumers are done reading tile g - 1 */       \
     X6_STAMP(1, 4)
     X6Q_LD(s0)
     X6Q_LD(s1)
@@ -1392,6 +1402,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         X6Q_STEP(s2)
         if (!moreS) break;
     }
+    if (PIPE3) x6_lds_barrier();   // the last tile's writes have landed: the extra barrier publishes it
 #undef X6Q_LD
 #undef X6Q_STEP
 #undef X6Q_RSUM_ACC
@@ -1681,10 +1692,16 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     constexpr int BN = 128, BM = X6_BT, ROWB = X6_ROWB, NC = 4;
     constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 2 * (PLANE_A + PLANE_B);
     constexpr int WN = 64, WM = 64, TM = 2, TN = 2, NWN = 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][BUF];
+#ifdef X3_PIPE3
+    constexpr bool PIPE3 = true;
+#else
+    constexpr bool PIPE3 = false;
+#endif
+    constexpr int NIMG = PIPE3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NIMG][BUF];
     constexpr int CP = WN + 4;
     __shared__ __attribute__((aligned(16))) float cstrip[NC][32 * CP];
-    __shared__ int expo[2][8];   // [image][A sub-blocks 0-3, B sub-blocks 4-7]
+    __shared__ int expo[NIMG][8];   // [image][A sub-blocks 0-3, B sub-blocks 4-7]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_xcd = (total_items + 7) >> 3, xcd = blockIdx.x & 7;
@@ -1694,12 +1711,12 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     const bool staged = !p.atomic && p.c_vec;
 
     if (wave >= NC + 4) {
-        x6q_produce<BN, BN, B_KC, true, false, GB, true, ONE>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
-                                                              &expo[0][0]);
+        x6q_produce<BN, BN, B_KC, true, false, GB, true, ONE, PIPE3>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
+                                                                     &expo[0][0]);
         return;
     }
     if (wave >= NC) {
-        x6q_produce<BN, BM, A_KC, false, false, GA, true, ONE>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64, &expo[0][0]);
+        x6q_produce<BN, BM, A_KC, false, false, GA, true, ONE, PIPE3>(p, w, stride, last, &lds[0][0], BUF, 0, tid - NC * 64, &expo[0][0]);
         return;
     }
 
@@ -1744,6 +1761,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     int buf = 0;
     int eA[TM], eB[TN];
     x6_lds_barrier();   // flat tile 0 is visible
+    if (PIPE3) x6_lds_barrier();   // (... one barrier later: see x6q_produce)
     X3Q_EXPO(0)
     M16_LDA(0, lds[0]) M16_LDB(0, lds[0])
     int dbgn = 0;
@@ -1788,7 +1806,8 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
             X6_STAMP(0, 12)
             if (more) x6_lds_barrier();   // (every read of this tile has returned: the producers may overwrite it)
             X6_STAMP(0, 13)
-            const int nbuf = more ? buf ^ 1 : buf;
+            const int nxt = PIPE3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
+            const int nbuf = more ? nxt : buf;
             const unsigned char* nb = lds[nbuf];
             X3Q_EXPO(nbuf)
             X3Q_SB
@@ -1797,7 +1816,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
             M16_LDB(0, nb) X3Q_SB
             M16_Q(1, 1)
             X6_STAMP(0, 15)
-            buf ^= 1;
+            buf = nxt;
         }
         X6_STAMP(0, 14)
         const bool add_bias = it.bias != nullptr && it.ks == 0;
@@ -1921,6 +1940,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     int buf = 0;
     int eA[TM], eB[TN];
     x6_lds_barrier();   // flat tile 0 is visible
+    if (PIPE3) x6_lds_barrier();   // (... one barrier later: see x6q_produce)
     X3Q_EXPO(0)
     X3Q_LDA(ahx, 0, lds[0], 0) X3Q_LDB(bhx, 0, lds[0], 0)
     if (!ONE) { X3Q_LDA(al, 1, lds[0], 0) X3Q_LDB(bl, 1, lds[0], 0) }
@@ -1959,13 +1979,14 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
             X6_STAMP(0, 12)
             if (more) x6_lds_barrier();
             X6_STAMP(0, 13)
-            const int nbuf = more ? buf ^ 1 : buf;
+            const int nxt = PIPE3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
+            const int nbuf = more ? nxt : buf;
             const unsigned char* nb = lds[nbuf];
             X3Q_EXPO(nbuf)
             X3Q_SB
             X3Q_SLICE(ahy, bhy, ahx, bhx, nb, 0)
             X6_STAMP(0, 15)
-            buf ^= 1;
+            buf = nxt;
         }
         X6_STAMP(0, 14)
         const bool add_bias = it.bias != nullptr && it.ks == 0;

@@ -105,6 +105,14 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, int roles, long
             acc += v0 + v7;
         }
         out[blockIdx.x * 1024 + threadIdx.x] = acc.x;
+    } else if (roles & 512) {   // ds_write_b128: 8 x 1 KB per iteration
+        unsigned a = (unsigned)(size_t)(lds + (wave - 4) * 4096 + lane * 16);
+        f32x4 v = {1.f * lane, 2.f, 3.f, 4.f};
+        for (int i = 0; i < iters; ++i) {
+            asm volatile("ds_write_b128 %0, %1\n ds_write_b128 %0, %1 offset:1024\n ds_write_b128 %0, %1 offset:2048\n ds_write_b128 %0, %1 offset:3072\n"
+                         "ds_write_b128 %0, %1\n ds_write_b128 %0, %1 offset:1024\n ds_write_b128 %0, %1 offset:2048\n ds_write_b128 %0, %1 offset:3072\n"
+                         "s_waitcnt lgkmcnt(0)" ::"v"(a), "v"(v) : "memory");
+        }
     } else if (roles & 8) {
         unsigned a = (unsigned)(size_t)(lds + (wave - 4) * 4096 + lane * 8);
         float v0 = lane, v1 = 1.f;
@@ -137,13 +145,13 @@ static double run(int threads, int iters, int roles) {
 
 int main() {
     const int iters = 4000;
-    for (int form : {0, 16, 64, 128}) {
-        for (int other : {2, 4, 8, 32, 256}) {
+    for (int form : {0, 64}) {
+        for (int other : {2, 4, 8, 512, 32, 256}) {
             for (int threads : {512, 768}) {
                 const double tm = run(256, iters, 1 | form), to = run(threads, iters, other), tb = run(threads, iters, 1 | form | other);
                 long long c[32];
                 hipMemcpy(c, clk, 32 * 8, hipMemcpyDeviceToHost);   // (of the "together" run: the last launch)
-                const char* nm = other == 2 ? "VALU (fma_mix)" : other == 4 ? "LDS read b128" : other == 8 ? "LDS write b64" : other == 32 ? "global load x4" : "global->LDS x4";
+                const char* nm = other == 2 ? "VALU (fma_mix)" : other == 4 ? "LDS read b128" : other == 8 ? "LDS write b64" : other == 512 ? "LDS write b128" : other == 32 ? "global load x4" : "global->LDS x4";
                 const char* fm = form == 0 ? "32x32x16 acc VGPR" : form == 16 ? "32x32x16 acc AGPR" : form == 64 ? "16x16x32         " : "32x32x16 + s_nop 7";
                 printf("%s | %-15s %d other wave(s)/SIMD: MFMA alone %7.1f us, other alone %7.1f us, together %7.1f us -> %3.0f %% hidden | in workgroup 0 the MFMA wave took %7.1f us, the other %7.1f us\n",
                        fm, nm, (threads / 64 - 4) / 4, tm, to, tb, 100.0 * (tm + to - tb) / (tm < to ? tm : to), c[16] * 0.01, c[20] * 0.01);
