@@ -346,6 +346,12 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         res["roofline"]["algorithmic_bytes_per_launch"] = (cby[1] + cby[2]) / max(1, en)
         t = res["roofline"]["traffic"]
         res["roofline"]["traffic_over_algorithmic"] = (t / res["roofline"]["algorithmic_bytes_per_launch"]) if t and en else None
+        # what the matrix pipe of THIS box sustains (ix_diag_mfma_rate_f16: back-to-back v_mfma_f32_32x32x16_f16 on every SIMD,
+        # measured live): the data-sheet `peak` assumes 2.4 GHz, an all-CU matrix load runs at ~ 1.8.  `frac` stays against `peak`.
+        sus, scratch = ctypes.c_double(0.0), torch.zeros(4, device=dev)
+        if lib.ix_diag_mfma_rate_f16(ctypes.byref(sus), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0 and sus.value > 0:
+            res["roofline"]["sustained_mfma_tflops_measured"] = sus.value
+            res["roofline"]["frac_of_sustained"] = res["roofline"]["achieved"] / sus.value
 
     bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
     assert not bad, "non-finite losses after the timed steps: %s" % bad

@@ -71,6 +71,9 @@ int ix_gemm_set_single_pass(int on);
  * mode 0: never, 1 (default): where the cost model prefers it, 2: every eligible contraction.  Returns the previous mode.
  * ix_gemm_w256_launches: launches taken so far (tests / bench). */
 int ix_gemm_set_w256(int mode);
+/* Measurement aid (bench.py roofline): the dense fp16 MFMA rate this GPU sustains under an all-CU matrix load (TFLOP/s; the
+ * data-sheet 2 500 assumes 2.4 GHz).  scratch4: >= 4 bytes of device memory.  Synchronises `stream`. */
+int ix_diag_mfma_rate_f16(double* tflops, void* scratch4, ix_stream_t stream);
 int ix_gemm_w256_launches(int64_t* out);
 int ix_prof_x3(double* ms, double* flops, int64_t* calls);
 int ix_prof_contractions(double* ms3, double* flops3, double* mfma_flops3, int64_t* launches3); /* by form: fp32 / bf16x6 / fp16x3 */ /* profiled ix_gemm_f32_ws calls on the fp16x3 path */

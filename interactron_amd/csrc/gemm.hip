@@ -2612,6 +2612,51 @@ static std::vector<ProfRec> g_rec;
 static double g_flash_flops = 0.0;
 static int64_t g_flash_launches = 0;
 
+// Measurement aid of bench.py's roofline object: the dense fp16 matrix rate this GPU SUSTAINS -- one wave per SIMD of every CU
+// issuing back-to-back v_mfma_f32_32x32x16_f16 on four independent accumulators (32.0 shader clocks per instruction:
+// tools/micro/mfma_valu_overlap.hip), timed with events on `stream`.  The data-sheet peak (2.5 PFLOP/s) assumes 2.4 GHz; under
+// this load the part clocks ~ 1.8 GHz.  Not part of the compute surface.
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float* out, int iters) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(lane * 0.01f + i); b[i] = (_Float16)(i - lane * 0.02f); }
+    f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+        }
+    }
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.678f) out[0] = 1.f;   // (keeps the loop; never true)
+}
+extern "C" int ix_diag_mfma_rate_f16(double* tflops, void* scratch4, hipStream_t stream) {
+    IX_CHECK_ARG(tflops && scratch4, "ix_diag_mfma_rate_f16: null pointer");
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        ix_set_error("ix_diag_mfma_rate_f16: no device");
+        return IX_ERR_LAUNCH;
+    }
+    const int iters = 3000;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return IX_ERR_LAUNCH;
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3(cus), dim3(256), 0, stream, (float*)scratch4, 200);   // warm-up: clocks settle
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3(cus), dim3(256), 0, stream, (float*)scratch4, iters);
+    hipEventRecord(e0, stream);
+    hipLaunchKernelGGL(mfma_rate_kernel, dim3(cus), dim3(256), 0, stream, (float*)scratch4, iters);
+    hipEventRecord(e1, stream);
+    float ms = 0.f;
+    const bool ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0.f;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (!ok) { ix_set_error("ix_diag_mfma_rate_f16: timing failed"); return IX_ERR_LAUNCH; }
+    *tflops = (double)cus * 4.0 * iters * 32.0 * (2.0 * 32 * 32 * 16) / (ms * 1e-3) / 1e12;
+    return IX_OK;
+}
+
 extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3);
 extern "C" int ix_gemm_stats(double* flops, int64_t* launches, int reset) {
     if (flops) *flops = g_flops;

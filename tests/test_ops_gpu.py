@@ -1381,3 +1381,16 @@ def test_flash_forward_fp8(ops, n, H, L, S, hd, masked):
     # and it really is a different arithmetic: the fp32-grade kernel is three orders of magnitude closer
     out32, _, _ = ops.flash_forward(q.cuda(), k.cuda(), v.cuda(), g, mask.cuda() if masked else None, 0.0, 0, need_backward=False)
     assert float((out32.cpu().double() - ref).norm()) < 1e-2 * float(err.norm())
+
+
+def test_sustained_mfma_rate_probe(ops):
+    """ix_diag_mfma_rate_f16 (bench.py's `roofline.sustained_mfma_tflops_measured`): back-to-back fp16 matrix instructions on every
+    SIMD.  An MI355X sustains 1.7-2.0 PFLOP/s of its 2.5 PFLOP/s data-sheet peak (the shader clock drops to ~ 1.8 GHz under this
+    load: profiles/r4w_mfma_overlap_microbench.txt); anything outside [1.0, 2.6] PFLOP/s means the probe is broken."""
+    import ctypes
+    from interactron_amd import _lib
+    lib = _lib.load()
+    rate, scratch = ctypes.c_double(0.0), torch.zeros(4, device="cuda")
+    assert lib.ix_diag_mfma_rate_f16(ctypes.byref(rate), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0, lib.ix_last_error()
+    assert 1000.0 < rate.value < 2600.0, rate.value
+    assert float(scratch.abs().sum()) == 0.0
