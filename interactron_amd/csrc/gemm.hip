@@ -603,11 +603,18 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                 e[i][2] = i == 0 ? v[2].x : i == 1 ? v[2].y : i == 2 ? v[2].z : v[2].w;
                 e[i][3] = i == 0 ? v[3].x : i == 1 ? v[3].y : i == 2 ? v[3].z : v[3].w;
             }
-            if (tail) {
-                const int gk = k0 + (tid & 7) * 4;
+        }
+        if (tail) {   // (wave-uniform, last K tile of an item only) zero the elements past the K range
+            int km = kmax;
+            asm volatile("" : "+s"(km));   // keeps the mask arithmetic INSIDE the branch (hoisted, it cost 8 instructions per K step)
+            const int gk = k0 + (tid & 7) * 4;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) e[i][c] = gk + c < kmax ? e[i][c] : 0.f;
-            }
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[i][c] = gk + c < km ? e[i][c] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
             // |.| as source modifiers of v_max3_f32: 8 instructions for the 16 elements (the compiler's own lowering of
             // fmaxf(fabsf) spends 28: it canonicalises every |x| with a v_max of its own)
             asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][0]), "v"(e[i][1]));
