@@ -87,7 +87,17 @@ struct GemmArgs {
     float* rowsum;          // optional side output (bf16x6 kernel, A stored m-contiguous): rowsum[bo][m] = sum_k A(m, k)
     int64_t sRowsum;
     int64_t sSplitRowsum;   // plane stride of the per-split partial row sums (0 with atomics)
+    // item decoding of the persistent kernels (x6_item) without integer divisions: by tiles_m * tiles_n * split_k, by
+    // tiles_m * tiles_n, by 8 * tiles_n, by batch_inner (set_item_divs, host)
+    FastDiv fd_per_batch, fd_nt, fd_group, fd_bi;
 };
+static void set_item_divs(GemmArgs& a) {
+    const unsigned nt = (unsigned)a.tiles_m * (unsigned)a.tiles_n;
+    a.fd_per_batch = make_fastdiv(nt * (unsigned)a.split_k);
+    a.fd_nt = make_fastdiv(nt);
+    a.fd_group = make_fastdiv(8u * (unsigned)a.tiles_n);
+    a.fd_bi = make_fastdiv((unsigned)(a.batch_inner > 0 ? a.batch_inner : 1));
+}
 
 // XCD-aware, bijective remap: consecutive logical tiles land on the same XCD (same L2).
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -919,16 +929,20 @@ struct X6Item {
 template <int BN, int BM = X6_BT>
 __device__ __forceinline__ X6Item x6_item(const GemmArgs& p, int w) {
     X6Item it;
+    // (divisions by launch constants as multiply-high + shift: this runs once per item on every wave, and on the producer
+    //  waves -- the kernel's critical path -- a generic 32-bit division is ~ 20 scalar instructions, five of them per item)
     const int nt = p.tiles_m * p.tiles_n, per_batch = nt * p.split_k;
-    const int zb = w / per_batch, rem = w - zb * per_batch;
-    const int ks = rem / nt, tile = rem - ks * nt;
+    const int zb = fd_div(w, p.fd_per_batch), rem = w - zb * per_batch;
+    const int ks = fd_div(rem, p.fd_nt), tile = rem - ks * nt;
     constexpr int GROUP_M = 8;
     const int group_size = GROUP_M * p.tiles_n;
-    const int first_m = (tile / group_size) * GROUP_M;
+    const int grp = fd_div(tile, p.fd_group), first_m = grp * GROUP_M, r = tile - grp * group_size;
     const int gm = min(p.tiles_m - first_m, GROUP_M);
-    it.m0 = (first_m + (tile % group_size) % gm) * BM;
-    it.n0 = ((tile % group_size) / gm) * BN;
-    const int bo = zb / p.batch_inner, bi = zb % p.batch_inner;
+    int rm, rn;
+    if (gm == GROUP_M) { rm = r & (GROUP_M - 1); rn = r >> 3; } else { rn = r / gm; rm = r - rn * gm; }   // (last, partial group only)
+    it.m0 = (first_m + rm) * BM;
+    it.n0 = rn * BN;
+    const int bo = fd_div(zb, p.fd_bi), bi = zb - bo * p.batch_inner;
     it.A = p.A + bo * p.sAo + bi * p.sAi;
     it.B = p.B + bo * p.sBo + bi * p.sBi;
     it.C = p.C + bo * p.sCo + bi * p.sCi + ks * p.sSplit;
@@ -3357,6 +3371,7 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
         r.mfma_flops = r.flops * (use_x3 ? (g_single_pass ? 1.0 : 3.0) : (use_x6 ? 6.0 : 1.0));   // matrix instructions issued per fp32 multiply-add
         g_rec.push_back(r);
     }
+    set_item_divs(a);
     prof_mark(stream);
     const bool persistent_ok = (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30);
     const int items = a.tiles_m * a.tiles_n * nbatch * split;
@@ -3579,6 +3594,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         r.mfma_flops = fl * (conv_x3 ? (g_single_pass ? 1.0 : 3.0) : 6.0);
         g_rec.push_back(r);
     }
+    set_item_divs(a);
     prof_mark(stream);
     const SplitEpi sep = epi_place(a, real);
     if (bn == 128) launch_conv_bn<128>(a, kind, items, stream, conv_x3);
