@@ -397,6 +397,20 @@ typedef float x6_f32x4 __attribute__((ext_vector_type(4)));
 // k-contiguous operands the rows are dealt per wave instead of per pass (row_of).
 // ONE (with X3): the single-pass 16-bit form -- only the h plane is written (no residual), the consumers issue one MFMA per
 // k-slice (MODEL.COMPUTE_DTYPE: bf16 / fp16, never the parity path).
+// Running sub-block exponent of a producer wave within an item (fp16x3 form, SplitLoader::store_x3) with the two values
+// derived from it -- the overflow threshold 2^(15 + e) and the scale 2^-e -- kept beside it: they only change when e does
+// (first tile of an item, or a sub-block maximum that grew), not once per K step.  All three are wave-uniform (scalar registers).
+struct X3Expo {
+    int e;
+    float lim, sc;
+    __device__ __forceinline__ void reset() { e = -1000; lim = 0.f; sc = 1.f; }
+    __device__ __forceinline__ void set(int v) {
+        e = v;
+        lim = v <= -1000 ? 0.f : __uint_as_float((unsigned)(142 + v) << 23);   // 2^(15 + e)
+        sc = v <= -1000 ? 1.f : __uint_as_float((unsigned)(127 - v) << 23);    // 2^-e
+    }
+};
+
 template <int BT, bool KC, bool SWZ = false, bool X3 = false, bool ONE = false>
 struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) -> registers -> three bf16 planes in LDS
     static constexpr int NI = KC ? BT / 32 : 4;       // float4 per thread
@@ -581,7 +595,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
     // scale their accumulators DOWN, exactly, when E grows -- a later tile with smaller values keeps the larger E and is
     // resolved to 2^-25 of the running maximum, which is what its products are worth next to the earlier ones.
     // `expo` = the LDS word of this wave's sub-block in the image being written.
-    __device__ __forceinline__ void store_x3(unsigned char* __restrict__ planes, int tid, int k0, int kmax, int& erun,
+    __device__ __forceinline__ void store_x3(unsigned char* __restrict__ planes, int tid, int k0, int kmax, X3Expo& ex,
                                              int* __restrict__ expo) const {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         typedef __attribute__((address_space(3))) u32x2 lds_u2;
@@ -597,7 +611,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             *(lds_u2*)(dst) = ph;
             *(lds_u2*)(dst + PLANE) = pl;
         }
-        (void)k0; (void)kmax; (void)erun;
+        (void)k0; (void)kmax; (void)ex;
         return;
 #endif
         float e[NI][4];
@@ -634,8 +648,8 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         // pattern of a non-negative float orders like an integer; DPP row shifts, then row broadcasts; lane 63 has it
         // E only has to change when some value would leave [0, 2^15) under the running scale -- one compare and a vote;
         // the reduction itself (six dependent DPP steps + a readlane) then runs once per item and whenever the data grows
-        const float lim = erun <= -1000 ? 0.f : __uint_as_float((unsigned)(142 + erun) << 23);   // 2^(15 + erun)
-        if (__ballot(mx >= lim) != 0) {
+        if (__ballot(mx >= ex.lim) != 0) {
+            const int erun = ex.e;
             int mi = (int)__float_as_uint(mx);
             mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x111, 0xf, 0xf, false));   // row_shr:1
             mi = max(mi, __builtin_amdgcn_update_dpp(mi, mi, 0x112, 0xf, 0xf, false));   // row_shr:2
@@ -646,10 +660,10 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             const int eb = (__builtin_amdgcn_readlane(mi, 63) >> 23) & 0xff;
             // zero / denormal / inf sub-block: keep the running exponent (its values convert to 0 / inf whatever the scale)
             const int E = (eb < 16 || eb > 250) ? erun : eb - 141;   // x * 2^-E has its maximum in [2^14, 2^15)
-            erun = max(erun, E);
+            ex.set(max(erun, E));
         }
-        const float sc = erun <= -1000 ? 1.f : __uint_as_float((unsigned)(127 - erun) << 23);
-        if ((tid & 63) == 0) *expo = erun;
+        const float sc = ex.sc;   // (a scalar register: the conversion instructions take it as their one scalar operand)
+        if ((tid & 63) == 0) *expo = ex.e;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int row = KC ? row_of(tid, i) : (tid >> 3) * 4 + i;
@@ -660,10 +674,10 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             unsigned hb0, hb1;
             asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
-                : "=&v"(hb0) : "v"(e[i][0]), "v"(e[i][1]), "v"(sc));
+                : "=&v"(hb0) : "v"(e[i][0]), "v"(e[i][1]), "s"(sc));
             asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
-                : "=&v"(hb1) : "v"(e[i][2]), "v"(e[i][3]), "v"(sc));
+                : "=&v"(hb1) : "v"(e[i][2]), "v"(e[i][3]), "s"(sc));
             if (ONE) {   // single-pass form: the rounded value is the operand
                 u32x2 ph1;
                 ph1.x = hb0; ph1.y = hb1;
@@ -673,10 +687,10 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             unsigned lb0, lb1;
             asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                : "=&v"(lb0) : "v"(e[i][0]), "v"(e[i][1]), "v"(sc), "v"(hb0));
+                : "=&v"(lb0) : "v"(e[i][0]), "v"(e[i][1]), "s"(sc), "v"(hb0));
             asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
                 "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                : "=&v"(lb1) : "v"(e[i][2]), "v"(e[i][3]), "v"(sc), "v"(hb1));
+                : "=&v"(lb1) : "v"(e[i][2]), "v"(e[i][3]), "s"(sc), "v"(hb1));
             unsigned char* dst = planes + row * X6_ROWB + (tid & 7) * 8;
             u32x2 ph, pl;
             ph.x = hb0; ph.y = hb1;
@@ -1316,7 +1330,8 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 #endif
     typename SplitLoader<BT, KC, SWZ, X3, ONE>::PixRows pr;   // (mode 1 only; dead otherwise)
     typename SplitLoader<BT, KC, SWZ, X3, ONE>::PlainRows plr;   // (plain operands only)
-    int erun = -1000;                                    // fp16x3 form: running sub-block exponent of the item (store_x3)
+    X3Expo erun;                                         // fp16x3 form: running sub-block exponent of the item (store_x3)
+    erun.reset();
     int* const expo = expo0 + (IS_B ? 4 : 0) + (pt >> 6);   // this wave's word in image 0 (image 1: + 8)
     const int ld = (int)(IS_B ? p.ldb : p.lda), tmax = IS_B ? p.N : p.M;
     const int ext = (int)((IS_B ? p.extB : p.extA) * 4);
@@ -1396,7 +1411,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     if (PIPE3) buf = buf == 2 ? 0 : buf + 1; else buf ^= 1;                                                 \
     if (++tS >= itS.nk) {                                                                                   \
         X6Q_RSUM_FLUSH                                                                                      \
-        erun = -1000;                                                                                       \
+        erun.reset();                                                                                       \
         tS = 0;                                                                                             \
         wS += stride;                                                                                       \
         moreS = wS < last;                                                                                  \
@@ -2120,7 +2135,8 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
 #ifndef X3_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    int eA0 = -1000, eA1 = -1000, eB = -1000;      // running sub-block exponents of the item (store_x3)
+    X3Expo eA0, eA1, eB;                           // running sub-block exponents of the item (store_x3)
+    eA0.reset(); eA1.reset(); eB.reset();
     int* const expo = expo0 + (pt >> 6);           // image words: A rows 0-127: 0-3, A rows 128-255: 4-7, B: 8-11
     const int lda = (int)p.lda, ldb = (int)p.ldb;
     const int extA = (int)(p.extA * 4), extB = (int)(p.extB * 4);
@@ -2192,7 +2208,7 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
     buf ^= 1;                                                                                               \
     if (++tS >= itS.nk) {                                                                                   \
         if (RSUM && itS.rowsum) { W2_RSUM_FLUSH1(rsum0, 0) W2_RSUM_FLUSH1(rsum1, 128) }                     \
-        eA0 = eA1 = eB = -1000;                                                                             \
+        eA0.reset(); eA1.reset(); eB.reset();                                                               \
         tS = 0;                                                                                             \
         wS += stride;                                                                                       \
         moreS = wS < last;                                                                                  \
