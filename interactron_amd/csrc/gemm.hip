@@ -517,6 +517,53 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
+    // mode 1 with the per-TAP part of the address hoisted out of the K loop (round 4: load_pixrows spends ~ 45 vector
+    // instructions per K step on values that change once per tap, i.e. every sC / 32 K steps): byte offset of this thread's
+    // 16-byte chunk at channel 0 of tap `tap` for each of its NI pixel rows, or a sentinel that stays out of range when the
+    // channel offset (< 8 KB) is added (ix_conv_gemm_supported keeps every tensor below 2^31 - 16 640 bytes).
+    struct PixTap {
+        int off[NI];
+        int tap, c0;   // (wave-uniform) the load cursor's tap and channel offset within it
+        __device__ __forceinline__ void setup(const ConvGather& g, const PixRows& pr, int tid) {
+            const int ky = fd_div(tap, g.dKW), kx = tap - ky * g.KW;
+            const int ty = ky * g.d, tx = kx * g.d, qm = (1 << g.qs) - 1;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int sy = pr.ys[i] + ty, sx = pr.xs[i] + tx;
+                bool ok = ((sy | sx) & qm) == 0;
+                sy >>= g.qs;
+                sx >>= g.qs;
+                ok = ok && (unsigned)sy < (unsigned)g.sH && (unsigned)sx < (unsigned)g.sW;
+                off[i] = ok ? ((pr.base[i] + sy * g.sW + sx) * g.sC + (tid & 7) * 4) * 4 : 0x7fffc000;
+            }
+        }
+        __device__ __forceinline__ void start(const ConvGather& g, const PixRows& pr, int k0, int tid) {
+            tap = fd_div(k0, g.dC);
+            c0 = k0 - tap * g.sC;
+            setup(g, pr, tid);
+        }
+        // after a K tile: the next one lies 32 channels on, or at channel 0 of the next tap
+        __device__ __forceinline__ void advance(const ConvGather& g, const PixRows& pr, int tid) {
+            c0 += X6_BK;
+            if (c0 >= g.sC) {   // (wave-uniform; every sC / 32 K steps)
+                c0 = 0;
+                ++tap;
+                setup(g, pr, tid);
+            }
+        }
+    };
+    __device__ __forceinline__ void load_taps(__amdgpu_buffer_rsrc_t rsrc, const PixTap& pt_) {
+        static_assert(KC || NI == 4, "");
+        const int cb = pt_.c0 * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int off = pt_.off[i] + cb;
+#ifdef X3_DIAG_NOLOAD
+            off = 0x7ffffff0;
+#endif
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
     // mode 2 (!KC): this thread's four k rows are pixels (decomposed per tile), the tile's n range lies inside tap (ty, tx)
     __device__ __forceinline__ void load_pixk(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int t0, int k0, int kmax, int tid,
                                               bool valid) {
@@ -1330,6 +1377,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
 #endif
     typename SplitLoader<BT, KC, SWZ, X3, ONE>::PixRows pr;   // (mode 1 only; dead otherwise)
     typename SplitLoader<BT, KC, SWZ, X3, ONE>::PlainRows plr;   // (plain operands only)
+    typename SplitLoader<BT, KC, SWZ, X3, ONE>::PixTap ptap;     // (mode 1 only)
     X3Expo erun;                                         // fp16x3 form: running sub-block exponent of the item (store_x3)
     erun.reset();
     int* const expo = expo0 + (IS_B ? 4 : 0) + (pt >> 6);   // this wave's word in image 0 (image 1: + 8)
@@ -1339,7 +1387,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     int wL = w, tL = 0, wS = w, tS = 0, buf = 0;
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
-    if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);
+    if (G == 1) { pr.setup(p.cg, itL.m0, tmax, pt); ptap.start(p.cg, pr, itL.kbeg, pt); }
     if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);
     // Row sums of an m-contiguous A operand (the bias gradient riding on the weight-gradient contraction): this thread
     // holds the same four rows (pt >> 3) * 4 .. + 3 in every K tile, so it keeps four running sums over its k lines; at
@@ -1376,9 +1424,10 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     }
 #define X6Q_LD(S)                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (G == 1)                                                                                             \
-        S.load_pixrows(rs, p.cg, pr, itL.kbeg + tL * BK, pt, moreL);                                        \
-    else if (G == 2)                                                                                        \
+    if (G == 1) {                                                                                           \
+        S.load_taps(rs, ptap);                                                                              \
+        if (tL + 1 < itL.nk) ptap.advance(p.cg, pr, pt);                                                    \
+    } else if (G == 2)                                                                                        \
         S.load_pixk(rs, p.cg, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                             \
     else if (G == 3)                                                                                        \
         S.load_kremap(rs, p.cg, ld, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                       \
@@ -1391,8 +1440,8 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         moreL = wL < last;                                                                                  \
         itL = x6_item<BN>(p, moreL ? wL : last - 1);                                                        \
         /* past the last item: a zero-length descriptor (plain loads return zeros without a per-load select) */ \
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, (G == 0 && !moreL) ? 0 : ext, 0x00020000); \
-        if (G == 1) pr.setup(p.cg, itL.m0, tmax, pt);                                                       \
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, (G <= 1 && !moreL) ? 0 : ext, 0x00020000); \
+        if (G == 1) { pr.setup(p.cg, itL.m0, tmax, pt); ptap.start(p.cg, pr, itL.kbeg, pt); }                \
         if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);                                        \
     }
 #define X6Q_STEP(S)                                                                                         \
@@ -3487,7 +3536,7 @@ extern "C" int ix_conv_gemm_supported(int groups, int imgs, int H, int W, int Ci
     if (g_x6 == 0) return 0;
     if (groups < 1 || imgs < 1 || (Cin % 64) || (Cout % 64) || (stride != 1 && stride != 2 && stride != 4)) return 0;
     if (KH < 1 || KW < 1 || pad < 0 || dil < 1) return 0;
-    const int64_t lim = ((int64_t)1 << 31) / 4 - 64;
+    const int64_t lim = ((int64_t)1 << 31) / 4 - 4160;   // (bytes < 2^31 - 16 640: SplitLoader::PixTap's out-of-range sentinel + 8 KB)
     if ((int64_t)imgs * H * W * Cin >= lim || (int64_t)imgs * OH * OW * Cout >= lim || (int64_t)Cout * KH * KW * Cin >= lim) return 0;
     if ((int64_t)imgs * H * W >= ((int64_t)1 << 30) || (int64_t)groups > 65535) return 0;
     return 1;
