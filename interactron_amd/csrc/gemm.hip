@@ -483,6 +483,22 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         }
     }
 
+    // mode 3 through the same hoisted rows (PlainRows of a !KC operand: pr.rb[i] = ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4):
+    // a K tile of 32 lies inside one tap (bmod % 32 == 0), so line k of the tile sits at (k - tap * bmod) * ld + tap * btap --
+    // a wave-uniform term (scalar arithmetic) on top of the per-item rows.  K = taps * bmod has no tail.
+    __device__ __forceinline__ void load_kremap_plain(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, const PlainRows& pr, int k0) {
+        const int tap = fd_div(k0, g.dBmod);   // (only ever called for a !KC operand: see x6q_produce's static_assert)
+        const int kl = (k0 - tap * g.bmod) * ld + tap * g.btap;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int off = (pr.rb[i] + kl) * 4;
+#ifdef X3_DIAG_NOLOAD
+            off = 0x7ffffff0;
+#endif
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
+        }
+    }
+
     // ---- implicit-GEMM gathers (ConvGather) ----
     // mode 1 (KC): this thread's NI pixel rows, decomposed once per item: image base (pixels), tap-0 source coordinates
     struct PixRows {
@@ -499,25 +515,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             }
         }
     };
-    __device__ __forceinline__ void load_pixrows(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, const PixRows& pr, int k0,
-                                                 int tid, bool valid) {
-        static_assert(KC || NI == 4, "");
-        const int tap = fd_div(k0, g.dC), c0 = k0 - tap * g.sC;
-        const int ky = fd_div(tap, g.dKW), kx = tap - ky * g.KW;
-        const int ty = ky * g.d, tx = kx * g.d, qm = (1 << g.qs) - 1;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            int sy = pr.ys[i] + ty, sx = pr.xs[i] + tx;
-            bool ok = valid && ((sy | sx) & qm) == 0;
-            sy >>= g.qs;
-            sx >>= g.qs;
-            ok = ok && (unsigned)sy < (unsigned)g.sH && (unsigned)sx < (unsigned)g.sW;
-            int off = ((pr.base[i] + sy * g.sW + sx) * g.sC + c0 + (tid & 7) * 4) * 4;
-            off = ok ? off : 0x7ffffff0;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
-        }
-    }
-    // mode 1 with the per-TAP part of the address hoisted out of the K loop (round 4: load_pixrows spends ~ 45 vector
+    // mode 1 with the per-TAP part of the address hoisted out of the K loop (round 4: the per-step form spent ~ 45 vector
     // instructions per K step on values that change once per tap, i.e. every sC / 32 K steps): byte offset of this thread's
     // 16-byte chunk at channel 0 of tap `tap` for each of its NI pixel rows, or a sentinel that stays out of range when the
     // channel offset (< 8 KB) is added (ix_conv_gemm_supported keeps every tensor below 2^31 - 16 640 bytes).
@@ -585,19 +583,6 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
-    // mode 3 (!KC): k rows (tap, co) of the data gradient's weight operand, stored [co][tap][c]
-    __device__ __forceinline__ void load_kremap(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, int t0, int k0, int kmax,
-                                                int tid, bool valid) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int k = min(k0 + (tid & 7) * 4 + i, kmax - 1);
-            const int tap = fd_div(k, g.dBmod);
-            int off = ((k - tap * g.bmod) * ld + tap * g.btap + t0 + (tid >> 3) * 4) * 4;
-            off = valid ? off : 0x7ffffff0;
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
-        }
-    }
-
     // k0 / kmax of the tile held in v[]: elements with k >= kmax are zeroed here (selects), not at load time
     __device__ __forceinline__ void store(unsigned char* __restrict__ planes, int tid, int k0, int kmax) const {
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -1388,7 +1373,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     bool moreL = true, moreS = true;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, ext, 0x00020000);
     if (G == 1) { pr.setup(p.cg, itL.m0, tmax, pt); ptap.start(p.cg, pr, itL.kbeg, pt); }
-    if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);
+    if (G == 0 || G == 3) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);
     // Row sums of an m-contiguous A operand (the bias gradient riding on the weight-gradient contraction): this thread
     // holds the same four rows (pt >> 3) * 4 .. + 3 in every K tile, so it keeps four running sums over its k lines; at
     // the end of an item the eight threads of a row group are combined and one of them adds the result to rowsum[m].
@@ -1430,7 +1415,7 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     } else if (G == 2)                                                                                        \
         S.load_pixk(rs, p.cg, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                             \
     else if (G == 3)                                                                                        \
-        S.load_kremap(rs, p.cg, ld, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                       \
+        S.load_kremap_plain(rs, p.cg, ld, plr, itL.kbeg + tL * BK);                                         \
     else                                                                                                    \
         S.load_plain(rs, ld, plr, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, itL.kend, pt);                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -1440,9 +1425,9 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
         moreL = wL < last;                                                                                  \
         itL = x6_item<BN>(p, moreL ? wL : last - 1);                                                        \
         /* past the last item: a zero-length descriptor (plain loads return zeros without a per-load select) */ \
-        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, (G <= 1 && !moreL) ? 0 : ext, 0x00020000); \
+        rs = __builtin_amdgcn_make_buffer_rsrc((void*)(IS_B ? itL.B : itL.A), 0, (G != 2 && !moreL) ? 0 : ext, 0x00020000); \
         if (G == 1) { pr.setup(p.cg, itL.m0, tmax, pt); ptap.start(p.cg, pr, itL.kbeg, pt); }                \
-        if (G == 0) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);                                        \
+        if (G == 0 || G == 3) plr.setup(ld, IS_B ? itL.n0 : itL.m0, tmax, pt);                              \
     }
 #define X6Q_STEP(S)                                                                                         \
     X6_STAMP(1, 0)                                                                                          \
