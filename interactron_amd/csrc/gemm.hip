@@ -461,41 +461,49 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
     // element offset of k line (tid & 7) * 4 + i plus the column chunk.  `valid` false is expressed by a zero-length
     // buffer descriptor (every offset then returns zeros), not by a per-load select.
     struct PlainRows {
-        int rb[NI];
+        int rb[NI];   // BYTE offsets
         __device__ __forceinline__ void setup(int ld, int t0, int tmax, int tid) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
-                rb[i] = KC ? min(t0 + row_of(tid, i), tmax - 1) * ld + (tid & 7) * 4 : ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4;
+                rb[i] = (KC ? min(t0 + row_of(tid, i), tmax - 1) * ld + (tid & 7) * 4 : ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4) * 4;
         }
     };
+    // The K-tile term of the address is wave-uniform: it rides in the load's SCALAR offset (no vector instruction per load and
+    // K step).  Only where the tile lies inside the K range: the buffer bounds check covers the vector offset, not the scalar
+    // one, and the tail tile of the tensor's last row would reach past the allocation -- tail tiles (one per item at most)
+    // keep the vector form, whose out-of-range bytes read as zeros.
     __device__ __forceinline__ void load_plain(__amdgpu_buffer_rsrc_t rsrc, int ld, const PlainRows& pr, int t0, int k0, int kmax, int tid) {
-        const bool tail = !KC && k0 + X6_BK > kmax;   // (wave-uniform) !KC: k lines past the K range are clamped to the last one
-        const int kl = KC ? k0 : k0 * ld;             // (uniform: a scalar multiply)
+#ifndef X3_DIAG_NOLOAD
+        if (k0 + X6_BK <= kmax) {   // (wave-uniform)
+            const int soff = (KC ? k0 : k0 * ld) * 4;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v[i]) : "v"(pr.rb[i]), "s"(rsrc), "s"(soff));
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int off = pr.rb[i] + kl;
-            if (tail) off = min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4;
-            off *= 4;
+            int off = KC ? pr.rb[i] + k0 * 4 : (min(k0 + (tid & 7) * 4 + i, kmax - 1) * ld + t0 + (tid >> 3) * 4) * 4;
 #ifdef X3_DIAG_NOLOAD
             off = 0x7ffffff0;
 #endif
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
-
     // mode 3 through the same hoisted rows (PlainRows of a !KC operand: pr.rb[i] = ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4):
     // a K tile of 32 lies inside one tap (bmod % 32 == 0), so line k of the tile sits at (k - tap * bmod) * ld + tap * btap --
     // a wave-uniform term (scalar arithmetic) on top of the per-item rows.  K = taps * bmod has no tail.
     __device__ __forceinline__ void load_kremap_plain(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, const PlainRows& pr, int k0) {
         const int tap = fd_div(k0, g.dBmod);   // (only ever called for a !KC operand: see x6q_produce's static_assert)
-        const int kl = (k0 - tap * g.bmod) * ld + tap * g.btap;
+        const int soff = ((k0 - tap * g.bmod) * ld + tap * g.btap) * 4;   // (K = taps * bmod: every tile lies inside the K range)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int off = (pr.rb[i] + kl) * 4;
 #ifdef X3_DIAG_NOLOAD
-            off = 0x7ffffff0;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(0x7ffffff0), "s"(rsrc));
+#else
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v[i]) : "v"(pr.rb[i]), "s"(rsrc), "s"(soff));
 #endif
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(off), "s"(rsrc));
         }
     }
 
@@ -647,7 +655,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         return;
 #endif
         float e[NI][4];
-        float mx = 0.f;
+        float mx;
         const bool tail = k0 + X6_BK > kmax;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -669,13 +677,18 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
 #pragma unroll
                 for (int c = 0; c < 4; ++c) e[i][c] = gk + c < km ? e[i][c] : 0.f;
         }
+        // |.| as source modifiers of v_max3_f32: 8 instructions for the 16 elements (the compiler's own lowering of
+        // fmaxf(fabsf) spends 28: it canonicalises every |x| with a v_max of its own)
+        // (seeded by the first three elements: no zero to load; 1 + 2 (NI - 1) + 1 = 8 instructions for NI = 4)
+        asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(mx) : "v"(e[0][0]), "v"(e[0][1]), "v"(e[0][2]));
+        float carry = e[0][3];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            // |.| as source modifiers of v_max3_f32: 8 instructions for the 16 elements (the compiler's own lowering of
-            // fmaxf(fabsf) spends 28: it canonicalises every |x| with a v_max of its own)
-            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][0]), "v"(e[i][1]));
-            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][2]), "v"(e[i][3]));
+        for (int i = 1; i < NI; ++i) {
+            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(carry), "v"(e[i][0]));
+            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(e[i][1]), "v"(e[i][2]));
+            carry = e[i][3];
         }
+        asm("v_max_f32 %0, %0, |%1|" : "+v"(mx) : "v"(carry));
         // wave maximum without the LDS crossbar (six ds_bpermute shuffles cost the producers 8 % of the kernel): the bit
         // pattern of a non-negative float orders like an integer; DPP row shifts, then row broadcasts; lane 63 has it
         // E only has to change when some value would leave [0, 2^15) under the running scale -- one compare and a vote;
