@@ -469,12 +469,13 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
         }
     };
     // The K-tile term of the address is wave-uniform: it rides in the load's SCALAR offset (no vector instruction per load and
-    // K step).  Only where the tile lies inside the K range: the buffer bounds check covers the vector offset, not the scalar
-    // one, and the tail tile of the tensor's last row would reach past the allocation -- tail tiles (one per item at most)
-    // keep the vector form, whose out-of-range bytes read as zeros.
-    __device__ __forceinline__ void load_plain(__amdgpu_buffer_rsrc_t rsrc, int ld, const PlainRows& pr, int t0, int k0, int kmax, int tid) {
+    // K step).  Only where the whole tile lies inside the tensor: the buffer bounds check is only relied upon for the vector
+    // offset, and a K-tail tile (or, for an m-contiguous operand, a tile overhanging the last row / column) would reach past
+    // the allocation from its last line -- those tiles keep the vector form, whose out-of-range bytes read as zeros.
+    __device__ __forceinline__ void load_plain(__amdgpu_buffer_rsrc_t rsrc, int ld, const PlainRows& pr, int t0, int tmax, int k0, int kmax,
+                                               int tid) {
 #ifndef X3_DIAG_NOLOAD
-        if (k0 + X6_BK <= kmax) {   // (wave-uniform)
+        if (k0 + X6_BK <= kmax && (KC || t0 + BT <= tmax)) {   // (wave-uniform)
             const int soff = (KC ? k0 : k0 * ld) * 4;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -494,15 +495,20 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
     // mode 3 through the same hoisted rows (PlainRows of a !KC operand: pr.rb[i] = ((tid & 7) * 4 + i) * ld + t0 + (tid >> 3) * 4):
     // a K tile of 32 lies inside one tap (bmod % 32 == 0), so line k of the tile sits at (k - tap * bmod) * ld + tap * btap --
     // a wave-uniform term (scalar arithmetic) on top of the per-item rows.  K = taps * bmod has no tail.
-    __device__ __forceinline__ void load_kremap_plain(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, const PlainRows& pr, int k0) {
+    __device__ __forceinline__ void load_kremap_plain(__amdgpu_buffer_rsrc_t rsrc, const ConvGather& g, int ld, const PlainRows& pr, int t0,
+                                                      int tmax, int k0) {
         const int tap = fd_div(k0, g.dBmod);   // (only ever called for a !KC operand: see x6q_produce's static_assert)
         const int soff = ((k0 - tap * g.bmod) * ld + tap * g.btap) * 4;   // (K = taps * bmod: every tile lies inside the K range)
+        const bool inside = t0 + BT <= tmax;   // (wave-uniform) else: vector offsets, bounds-checked (see load_plain)
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
 #ifdef X3_DIAG_NOLOAD
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(0x7ffffff0), "s"(rsrc));
 #else
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v[i]) : "v"(pr.rb[i]), "s"(rsrc), "s"(soff));
+            if (inside)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v[i]) : "v"(pr.rb[i]), "s"(rsrc), "s"(soff));
+            else
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v[i]) : "v"(pr.rb[i] + soff), "s"(rsrc));
 #endif
         }
     }
@@ -1428,9 +1434,9 @@ __device__ __forceinline__ void x6q_produce(const GemmArgs& p, int w, int stride
     } else if (G == 2)                                                                                        \
         S.load_pixk(rs, p.cg, itL.n0, itL.kbeg + tL * BK, itL.kend, pt, moreL);                             \
     else if (G == 3)                                                                                        \
-        S.load_kremap_plain(rs, p.cg, ld, plr, itL.kbeg + tL * BK);                                         \
+        S.load_kremap_plain(rs, p.cg, ld, plr, itL.n0, tmax, itL.kbeg + tL * BK);                           \
     else                                                                                                    \
-        S.load_plain(rs, ld, plr, IS_B ? itL.n0 : itL.m0, itL.kbeg + tL * BK, itL.kend, pt);                \
+        S.load_plain(rs, ld, plr, IS_B ? itL.n0 : itL.m0, tmax, itL.kbeg + tL * BK, itL.kend, pt);          \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (++tL >= itL.nk) {                                                                                   \
         tL = 0;                                                                                             \
@@ -2229,9 +2235,9 @@ __device__ __forceinline__ void w2_produce(const GemmArgs& p, int w, int stride,
     }
 #define W2_LD(S)                                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    S##a0.load_plain(rsA, lda, ra0, itL.m0, itL.kbeg + tL * BK, itL.kend, pt);                              \
-    S##a1.load_plain(rsA, lda, ra1, itL.m0 + 128, itL.kbeg + tL * BK, itL.kend, pt);                        \
-    S##b.load_plain(rsB, ldb, rb0, itL.n0, itL.kbeg + tL * BK, itL.kend, pt);                               \
+    S##a0.load_plain(rsA, lda, ra0, itL.m0, p.M, itL.kbeg + tL * BK, itL.kend, pt);                         \
+    S##a1.load_plain(rsA, lda, ra1, itL.m0 + 128, p.M, itL.kbeg + tL * BK, itL.kend, pt);                   \
+    S##b.load_plain(rsB, ldb, rb0, itL.n0, p.N, itL.kbeg + tL * BK, itL.kend, pt);                          \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     if (++tL >= itL.nk) {                                                                                   \
         tL = 0;                                                                                             \
