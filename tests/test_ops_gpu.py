@@ -226,7 +226,8 @@ def test_conv2d_nhwc(ops, cin, cout, k, stride, pad, dil, hw):
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,dil,hw,n", [(64, 128, 3, 1, 1, 1, 19, 2), (128, 64, 3, 2, 1, 1, 20, 3),
                                                              (64, 64, 3, 1, 2, 2, 13, 2), (128, 256, 1, 2, 0, 1, 15, 2),
-                                                             (256, 128, 3, 2, 1, 1, 9, 1), (64, 64, 3, 1, 1, 1, 38, 5)])
+                                                             (256, 128, 3, 2, 1, 1, 9, 1), (64, 64, 3, 1, 1, 1, 38, 5),
+                                                             (192, 320, 3, 1, 1, 1, 12, 2)])   # (N tiles that overhang 192 / 320 channels)
 @pytest.mark.usefixtures("kernel_form")
 def test_implicit_gemm_conv(ops, cin, cout, k, stride, pad, dil, hw, n):
     """ix_conv_gemm_f32 (the bf16x6 producers gather the taps; no patch matrix): forward, both gradients and the gradients
