@@ -339,6 +339,12 @@ int ix_flash_bwd_bwd_f32(const struct ix_attn_planes* q, const struct ix_attn_pl
                          float p_drop, uint64_t seed, void* workspace, size_t workspace_bytes, ix_stream_t stream);
 int ix_workspace_bytes_flash_bwd_bwd(int n, int H, int L, size_t* out_host);
 int ix_flash_dropmask_f32(float* m, int BH, int L, int S, float p_drop, uint64_t seed, ix_stream_t stream);
+/* Head dim 64 in tr form 1 runs the 16x16x32 passes of csrc/flash16.hip: eight waves per workgroup, 16 owner rows per wave, the
+ * streamed operand staged once in row layout and read both ways (ds_read_b128 / ds_read_b64_tr_b16) -- such calls need ROW
+ * planes only (v included, in the forward pass too) and never read tr planes.  ix_flash_set_m16(0 / 1) switches the family
+ * off / on for the process (any other value: query), returns the previous setting; IX_FLASH_M16=0 in the environment starts
+ * with it off. */
+int ix_flash_set_m16(int on);
 
 /* fp8 forward (opt-in, BASELINE.json configs[4] "fp8 MFMA attention"): q k^T and P v of the forward pass on
  * v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, fp32 accumulate, fp32 softmax / output / lse).

@@ -39,59 +39,7 @@
 //   tr  layout  [3 planes][batch*head][hd][Rp]   bf16   rows permuted within 16-groups          (contraction over rows)
 //        form 1 [2 planes][batch*head][hd][Rp]   fp16   the row planes' values, transposed and permuted likewise
 //   Rp = R rounded up to 128 (zero rows); keys are walked in tiles of 32 up to ceil(S / 32) * 32.
-#include "common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// v_exp_f32 directly: exp2f() wraps it in denormal-range handling (4 more instructions per element), and every use here
-// either has a non-positive argument or is multiplied into a sum where a flushed 2^-126 does not matter
-#define fl_exp2(X) __builtin_amdgcn_exp2f(X)
-#define FL_LOG2E 1.4426950408889634f
-#define FL_LN2 0.6931471805599453f
-
-__device__ __forceinline__ unsigned fl_pack(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE), a in the low half
-    f32x2 v;
-    v.x = a;
-    v.y = b;
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-
-// (x0, x1) -> packed bf16 pairs of the three planes, exact: x = h + m + l
-__device__ __forceinline__ void fl_split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = fl_pack(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = fl_pack(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
-    l = fl_pack(s0, s1);
-}
-
-__device__ __forceinline__ f32x16 fl_mfma(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 fl_mfma_h(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// (x0, x1), already scaled into fp16 range -> packed fp16 pairs of the two planes: x = h + l up to 2^-22 relative
-__device__ __forceinline__ void fl_split2h(float x0, float x1, unsigned& h, unsigned& l) {
-    f32x2 v;
-    v.x = x0; v.y = x1;
-    const f16x2 hh = __builtin_convertvector(v, f16x2);
-    const f32x2 back = __builtin_convertvector(hh, f32x2);
-    f32x2 r;
-    r.x = x0 - back.x; r.y = x1 - back.y;
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
-}
-
-// position of row r (0..15) of a 16-group in the tr layout: bits 2 and 3 swapped
-__device__ __host__ __forceinline__ int fl_perm16(int r) { return (r & 3) | ((r & 4) << 1) | ((r & 8) >> 1); }
+#include "flash_common.h"
 
 // ------------------------------------------------------------------------------------------------------------
 // split kernel: fp32 [n][R][ld] (head h at columns off + h*hd) -> fp16 row planes (+ block unscale factors) and
@@ -250,20 +198,6 @@ extern "C" int ix_attn_bias_f32(const uint8_t* mask, float* bias, int n, int S, 
     return IX_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// dropout mask of the flash kernels: a pure function of (seed, row id = (batch*head)*L + query, key), one 32-bit hash
-// per PAIR of neighbouring keys (two 16-bit draws), so forward, backward and double backward regenerate the same mask
-// whichever way their tiles are oriented.  keep <=> draw >= thr16, thr16 = round(p * 65536).
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned fl_hash(unsigned seed_lo, unsigned seed_hi, unsigned rid, unsigned kpair) {
-    // one multiply-fold round on (row term) ^ (key-pair term): in the kernels one of the two terms is invariant per lane
-    // and the other advances by a wave-uniform amount per tile, so a draw costs an add, an xor, the 32 x 32 -> 64-bit
-    // product and a fold (the earlier two-multiply xorshift mix was a third of the forward kernel's vector instructions)
-    const unsigned a = (rid * 0x9E3779B1u) ^ seed_lo;
-    const unsigned b = kpair * 0x85EBCA77u + seed_hi;
-    const unsigned long long m = (unsigned long long)(a ^ b) * 0xD6E8FEB9ull;
-    return (unsigned)m ^ (unsigned)(m >> 32);
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // common machinery of the six kernels
@@ -384,7 +318,6 @@ struct FlSeg {
         const float c_ = (US) * F;                                                                                     \
         _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) X[r_] *= c_;                                                 \
     }
-#define FL_F0 1152921504606846976.f   // 2^60: where a running factor starts
 // LLVM's instruction-group scheduling strategies as a hint at the top of a tile loop (scheduling only): measured per kernel
 // at L = S = 12 755, hd 64 (tools/flash_ab.sh): strategy 0 -7.8 % on the dq / ddO pass and -2.8 % on the forward, +50 % on the
 // statistics pass; strategy 2 (MFMA / exp interleave) -10.8 % on the statistics pass, -4.4 % on dq / ddO; the key-owning
@@ -401,28 +334,6 @@ struct FlSeg {
         *reinterpret_cast<f32x4*>((DSTPTR) + db_ * 32 + 8 * g_) = v_;                                                  \
     }
 
-// One argument block for all kernels.  Operand planes: *_row = fp16 row planes [2][BH][Rp][hd], *_us = their block
-// unscale factors [BH][Rp / 32], *_tr = bf16 tr planes [3][BH][hd][Rp].  Query side: q, dO (do_), hq; key side: k, v, hk, hv.
-struct FlashArgs {
-    const unsigned short *q_row, *do_row, *hq_row, *q_tr, *do_tr, *hq_tr;
-    const float *q_us, *do_us, *hq_us;
-    const unsigned short *k_row, *v_row, *hk_row, *hv_row, *k_tr, *v_tr, *hk_tr, *hv_tr;
-    const float *k_us, *v_us, *hk_us, *hv_us;
-    const float* bias;     // [n][Sp] additive key bias (0 / -inf)
-    float* lse;            // [BH][Lp] natural-log row normalisers (+inf beyond L)
-    const float* delta;    // [BH][Lp] t_i = dO_i . O_i
-    float *u, *w;          // [BH][Lp] second-order row statistics (workspace)
-    float *o1, *o2, *o3, *o4;   // outputs: fwd out | gq gk gv | dq dk dv ddo; [n][L|S][ld] with head h at off + h*hd
-    int64_t ld1, ld2, ld3, ld4;
-    int off1, off2, off3, off4;
-    int H, L, Lp, S, Sp;
-    int64_t q_plane, k_plane;   // elements per plane
-    float scale, scale_log2e;
-    unsigned thr16;             // dropout threshold (0 = no dropout)
-    float inv_keep;
-    unsigned seed_lo, seed_hi;
-    const unsigned* salt;       // optional device word XORed into the seed when the kernel runs (ix_set_dropout_salt)
-};
 
 // dropout keep flags of the 16 accumulator registers of a tile whose lane holds ONE row id and whose registers walk the
 // OTHER index in accumulator order (PAIRS: registers 2i, 2i+1 are the two keys of one hash).  bool, not float: the
@@ -1160,6 +1071,26 @@ struct ix_attn_planes {
 // second-stage matrix instructions per algorithmic product: 6 (three bf16 planes) or 3 (two fp16 planes)
 #define FL_S2(FORM) ((FORM) == 1 ? 3 : 6)
 
+// head dim 64, fp16 form: the 16x16x32 passes of flash16.hip (eight waves per workgroup, row planes only).  Process-wide
+// switch for A/B runs and for the tests that pin both kernel families (ix_flash_set_m16; IX_FLASH_M16=0 in the environment).
+void fl16_launch_fwd(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bwd_q(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bwd_kv(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_kv(const FlashArgs& a, dim3 grid, hipStream_t stream);
+static int fl_m16_default() {
+    const char* e = getenv("IX_FLASH_M16");
+    return !(e && e[0] == '0');
+}
+static int g_fl_m16 = fl_m16_default();
+extern "C" int ix_flash_set_m16(int on) {
+    const int old = g_fl_m16;
+    if (on == 0 || on == 1) g_fl_m16 = on;
+    return old;
+}
+static inline bool fl_m16(int hd, int form) { return g_fl_m16 && hd == 64 && form == 1; }
+
 static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, int H, int L, int Lp, int S, int Sp, int hd,
                      float scale, float p_drop, uint64_t seed) {
     IX_CHECK_ARG(bias != nullptr, "%s: null key bias", who);
@@ -1199,7 +1130,8 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
                                 int off_out, float scale, float p_drop, uint64_t seed, hipStream_t stream) {
     if (n <= 0 || L <= 0) return IX_OK;
     IX_CHECK_ARG(q && k && q->row && q->unscale && k->row && k->unscale && lse, "ix_flash_fwd_f32: null pointer");
-    IX_CHECK_ARG(!out || (v && v->tr), "ix_flash_fwd_f32: v tr planes missing");
+    const bool m16 = out && v && fl_m16(hd, v->tr_form);
+    IX_CHECK_ARG(!out || (v && (m16 ? v->row != nullptr : v->tr != nullptr)), "ix_flash_fwd_f32: v planes missing (%s)", m16 ? "row" : "tr");
     IX_CHECK_ARG(FL_OUT_OK(ld_out, off_out) && ((uintptr_t)out & 15) == 0, "ix_flash_fwd_f32: output rows must be 16-byte aligned");
     FlashArgs a;
     const int rc = fl_common(a, "ix_flash_fwd_f32", bias, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
@@ -1207,6 +1139,7 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     a.q_row = (const unsigned short*)q->row; a.q_us = q->unscale;
     a.k_row = (const unsigned short*)k->row; a.k_us = k->unscale;
     a.v_tr = out ? (const unsigned short*)v->tr : nullptr;
+    a.v_row = out ? (const unsigned short*)v->row : nullptr;
     const int form = out ? v->tr_form : 0;
     IX_CHECK_ARG(form == 0 || (form == 1 && v->unscale), "ix_flash_fwd_f32: v tr planes of form %d lack their unscale factors", form);
     a.v_us = out ? v->unscale : nullptr;
@@ -1221,7 +1154,9 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
         return IX_OK;
     }
     ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 1);
-    if (hd == 64) {
+    if (m16) {
+        fl16_launch_fwd(a, grid, stream);
+    } else if (hd == 64) {
         if (form == 1) { FL_DISPATCH_FWD(64, 2) } else { FL_DISPATCH_FWD(64, 3) }
     } else {
         if (form == 1) { FL_DISPATCH_FWD(32, 2) } else { FL_DISPATCH_FWD(32, 3) }
@@ -1237,8 +1172,10 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
                                 int off_q, int64_t ld_k, int off_k, int64_t ld_v, int off_v, float scale, float p_drop,
                                 uint64_t seed, hipStream_t stream) {
     if (n <= 0 || L <= 0 || S <= 0) return IX_OK;
-    IX_CHECK_ARG(q && k && v && d_out && q->row && q->unscale && q->tr && k->row && k->unscale && k->tr && v->row && v->unscale &&
-                 d_out->row && d_out->unscale && d_out->tr && lse && delta, "ix_flash_bwd_f32: null operand");
+    IX_CHECK_ARG(q && k && v && d_out && q->row && q->unscale && k->row && k->unscale && v->row && v->unscale &&
+                 d_out->row && d_out->unscale && lse && delta, "ix_flash_bwd_f32: null operand");
+    const bool m16 = fl_m16(hd, q->tr_form);
+    IX_CHECK_ARG(m16 || (q->tr && k->tr && d_out->tr), "ix_flash_bwd_f32: tr planes missing");
     IX_CHECK_ARG(gq || (gk && gv), "ix_flash_bwd_f32: no output requested");
     IX_CHECK_ARG(FL_OUT_OK(ld_q, off_q) && FL_OUT_OK(ld_k, off_k) && FL_OUT_OK(ld_v, off_v), "ix_flash_bwd_f32: output rows must be 16-byte aligned");
     FlashArgs a;
@@ -1259,13 +1196,15 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
         ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 2);
-        FL_DISPATCH(flash_bwd_q_kernel, grid, form)
+        if (m16) fl16_launch_bwd_q(a, grid, stream);
+        else { FL_DISPATCH(flash_bwd_q_kernel, grid, form) }
         ix_prof_end(stream);
     }
     if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
         ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * FL_S2(form)) * FL_PRODUCT_FLOPS, 3);
-        FL_DISPATCH(flash_bwd_kv_kernel, grid, form)
+        if (m16) fl16_launch_bwd_kv(a, grid, stream);
+        else { FL_DISPATCH(flash_bwd_kv_kernel, grid, form) }
         ix_prof_end(stream);
     }
     IX_CHECK_LAUNCH("ix_flash_bwd_f32");
@@ -1282,8 +1221,10 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     if (n <= 0 || L <= 0 || S <= 0) return IX_OK;
     const ix_attn_planes* ops[7] = {q, k, v, d_out, hq, hk, hv};
     for (int i = 0; i < 7; ++i)
-        IX_CHECK_ARG(ops[i] && ops[i]->row && ops[i]->unscale && ops[i]->tr, "ix_flash_bwd_bwd_f32: operand %d lacks planes", i);
+        IX_CHECK_ARG(ops[i] && ops[i]->row && ops[i]->unscale, "ix_flash_bwd_bwd_f32: operand %d lacks planes", i);
     const int form = q->tr_form;
+    const bool m16 = fl_m16(hd, form);
+    for (int i = 0; i < 7; ++i) IX_CHECK_ARG(m16 || ops[i]->tr, "ix_flash_bwd_bwd_f32: operand %d lacks tr planes", i);
     for (int i = 0; i < 7; ++i)
         IX_CHECK_ARG((form == 0 || form == 1) && ops[i]->tr_form == form, "ix_flash_bwd_bwd_f32: operand %d was split with another tr form", i);
     IX_CHECK_ARG(lse && delta && dq && dk && dv && ddo, "ix_flash_bwd_bwd_f32: null pointer");
@@ -1320,7 +1261,17 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
     hipLaunchKernelGGL((flash_bb_kv_kernel<HD_, DR_, TP_>), gk, blk, 0, stream, a);                    \
     ix_prof_end(stream);
 #define FL_BB_LAUNCH(HD_, DR_) if (form == 1) { FL_BB_LAUNCH2(HD_, DR_, 2) } else { FL_BB_LAUNCH2(HD_, DR_, 3) }
-    if (hd == 64) {
+    if (m16) {
+        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);
+        fl16_launch_bb_stats(a, gq, stream);
+        ix_prof_end(stream);
+        ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 3) * FL_PRODUCT_FLOPS, 5);
+        fl16_launch_bb_q(a, gq, stream);
+        ix_prof_end(stream);
+        ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 3) * FL_PRODUCT_FLOPS, 6);
+        fl16_launch_bb_kv(a, gk, stream);
+        ix_prof_end(stream);
+    } else if (hd == 64) {
         if (a.thr16) { FL_BB_LAUNCH(64, true) } else { FL_BB_LAUNCH(64, false) }
     } else {
         if (a.thr16) { FL_BB_LAUNCH(32, true) } else { FL_BB_LAUNCH(32, false) }

@@ -1,0 +1,757 @@
+// Head-dim-64 attention passes on v_mfma_f32_16x16x32_f16: forward, backward and double backward of
+//     O = dropout(softmax(scale Q K^T + key bias)) V
+// for the fp16 form of csrc/flash.hip (same algebra, same operand planes, same dropout mask, same accuracy class; reference
+// models/gpt.py:39-57 and its autograd derivatives as taken by models/interactron.py:99-123).  Why a second set of kernels:
+// the 32x32x16 passes of flash.hip need 370-430 registers and 115-148 KB of LDS at head dim 64 -- ONE wave per SIMD, whose
+// matrix and vector work (96-108 matrix instructions against ~1 000 vector instructions per 32 x 32 tile) then simply add up.
+// Here a workgroup is EIGHT waves (two per SIMD, <= 256 registers), each owning 16 rows of the owner side:
+//
+//   * tiles are [32 streamed rows] x [16 owner rows] = two 16 x 16 accumulator blocks (4 registers each); lane
+//     (n = lane & 15, g = lane >> 4) holds owner row n and streamed rows 16 blk + 4 g + r: eight elements per lane per tile
+//     instead of sixteen, a quarter of the accumulator registers per tile kind;
+//   * all four owner-side operands stay in registers as B fragments (16 registers each);
+//   * the streamed side is staged ONCE, in row layout only ([2 planes][32 rows][128 B], 16-byte chunk c of row r at
+//     c ^ (r & 6)): products that contract over the head dim read it with ds_read_b128 (A fragment = 8 consecutive d of one
+//     row), products that contract over the streamed rows read THE SAME image with ds_read_b64_tr_b16 (the hardware
+//     transpose: lane (d, g) receives rows 4 g .. 4 g + 3 and 16 + 4 g .. of column d), so no tr planes are read, staged or
+//     even written for head dim 64 -- half the LDS footprint, half the staging traffic.  The swizzle is conflict-free for
+//     both access kinds (16-lane groups of ds_read_b128 as listed in MI355X_MICROARCH "LDS"; 32-lane halves of the
+//     transpose read), tools/micro/m16_layout.hip checks the layout facts on the device;
+//   * the accumulator registers of a tile ARE the B fragment (k = 8 g + e <-> streamed rows 4 g + e | 16 + 4 g + e - 4) of
+//     the products that contract over the streamed rows: no [L, S] value passes through LDS;
+//   * two LDS buffers, ONE barrier per tile; the next tile's rows are requested before the tile's arithmetic and written to
+//     the other buffer after it.
+// Two waves of a SIMD de-phase by themselves between barriers (one is in its matrix burst while the other splits
+// accumulators), and 16x16x32 instructions leave the LDS-read return path usable next to a matrix burst
+// (profiles/r4w_mfma_overlap_microbench.txt).
+#include "flash_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+#define M16_OPB 8192   // one streamed operand tile in LDS: 2 planes x 32 rows x 128 bytes
+#define M16_PLB 4096
+#define M16_HALF 2048  // rows 16 .. 31
+
+__device__ __forceinline__ f32x4 m16_mma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 m16_ld128(const unsigned char* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x2 m16_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p)));
+}
+
+// A fragments (planes h, l) of k-slice offset OA, row block BLK of the operand tile at OP
+#define M16_AFRAG(DST, OP, OA, BLK)                                            \
+    DST[0] = m16_ld128((OP) + (BLK) * M16_HALF + (OA));                        \
+    DST[1] = m16_ld128((OP) + M16_PLB + (BLK) * M16_HALF + (OA));
+
+// (x0, x1) * sc -> packed fp16 pair h; then l = fp16(x * sc - h): one rounding each (v_fma_mix*_f16 take fp32 and fp16 sources)
+__device__ __forceinline__ unsigned m16_cvt_h(float x0, float x1, float sc) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(d) : "v"(x0), "v"(x1), "v"(sc));
+    return d;
+}
+__device__ __forceinline__ unsigned m16_cvt_l(float x0, float x1, float sc, unsigned h) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, -%4 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %3, -%4 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(d) : "v"(x0), "v"(x1), "v"(sc), "v"(h));
+    return d;
+}
+
+// The running power-of-two factor F of an output accumulator (tr form 1 of flash.hip: F only ever decreases; when the
+// tile's magnitude bound MXUS = max|x| . unscale times F would reach 2^15, F drops to put it into [2^14, 2^15) and the
+// accumulator is rescaled exactly).  The four lanes (g = 0..3) of an owner row feed the same output elements and must agree
+// on F: the common path decides on each lane's OWN eight values (no exchange: if nobody's product leaves the range nothing
+// changes), the rare path takes the maximum over the four lanes first.
+template <bool EXCHANGE>
+__device__ __forceinline__ void m16_fit(float mxus, float& F, f32x4 (&acc)[4]) {
+    if (__builtin_amdgcn_ballot_w64(mxus * F >= 32768.f)) {
+        if (EXCHANGE) {
+            mxus = fmaxf(mxus, __shfl_xor(mxus, 16, 64));
+            mxus = fmaxf(mxus, __shfl_xor(mxus, 32, 64));
+        }
+        const unsigned e = (__float_as_uint(mxus) >> 23) & 0xffu;
+        const float fn = mxus * F >= 32768.f ? __uint_as_float(min(268u - e, 187u) << 23) : F;
+        const int d = (int)(__float_as_uint(fn) >> 23) - (int)(__float_as_uint(F) >> 23) + 127;
+        const float rs = d > 0 ? __uint_as_float((unsigned)d << 23) : 0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) acc[db] *= rs;
+        F = fn;
+    }
+}
+// x (this lane's 2 x 4 values of one tile column) . c -> B fragments (h, l); the empty statement keeps the matrix
+// instructions that read them behind the conversions' wait states
+__device__ __forceinline__ void m16_split(u32x4 (&bf)[2], const f32x4 (&x)[2], float c) {
+    unsigned h0 = m16_cvt_h(x[0][0], x[0][1], c), h1 = m16_cvt_h(x[0][2], x[0][3], c);
+    unsigned h2 = m16_cvt_h(x[1][0], x[1][1], c), h3 = m16_cvt_h(x[1][2], x[1][3], c);
+    unsigned l0 = m16_cvt_l(x[0][0], x[0][1], c, h0), l1 = m16_cvt_l(x[0][2], x[0][3], c, h1);
+    unsigned l2 = m16_cvt_l(x[1][0], x[1][1], c, h2), l3 = m16_cvt_l(x[1][2], x[1][3], c, h3);
+    asm volatile("s_nop 1" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+    bf[0][0] = h0; bf[0][1] = h1; bf[0][2] = h2; bf[0][3] = h3;
+    bf[1][0] = l0; bf[1][1] = l1; bf[1][2] = l2; bf[1][3] = l3;
+}
+__device__ __forceinline__ float m16_absmax(const f32x4 (&x)[2]) {
+    float a = fmaxf(fmaxf(fabsf(x[0][0]), fabsf(x[0][1])), fmaxf(fabsf(x[0][2]), fabsf(x[0][3])));
+    float b = fmaxf(fmaxf(fabsf(x[1][0]), fabsf(x[1][1])), fmaxf(fabsf(x[1][2]), fabsf(x[1][3])));
+    return fmaxf(a, b);
+}
+// values of unknown range / values in [0, bound]
+#define M16_FIT_SPLIT(BF, X, US, F, ACC)                                       \
+    { m16_fit<true>(m16_absmax(X) * (US), F, ACC); m16_split(BF, X, (US) * F); }
+#define M16_FIT_SPLIT_BOUNDED(BF, X, BOUND, US, F, ACC)                        \
+    { m16_fit<false>((BOUND) * (US), F, ACC); m16_split(BF, X, (US) * F); }
+
+// acc[db] (16 d x 16 owner rows) += X^T[d, streamed rows] . bf[streamed rows, owner] for the operand tile at OP: the A
+// fragment of d block db comes out of the row-layout image by two transpose reads per plane (rows 4 g + e, 16 + 4 g + e)
+__device__ __forceinline__ void m16_stage2(f32x4 (&acc)[4], const unsigned char* op, int offT, const u32x4 (&bf)[2]) {
+    u32x4 ah[4], al[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int o = offT ^ (db << 5);
+        const u32x2 h0 = m16_tr(op + o), h1 = m16_tr(op + M16_HALF + o);
+        const u32x2 l0 = m16_tr(op + M16_PLB + o), l1 = m16_tr(op + M16_PLB + M16_HALF + o);
+        ah[db][0] = h0[0]; ah[db][1] = h0[1]; ah[db][2] = h1[0]; ah[db][3] = h1[1];
+        al[db][0] = l0[0]; al[db][1] = l0[1]; al[db][2] = l1[0]; al[db][3] = l1[1];
+    }
+#pragma unroll
+    for (int db = 0; db < 4; ++db) acc[db] = m16_mma(al[db], bf[0], acc[db]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) acc[db] = m16_mma(ah[db], bf[1], acc[db]);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) acc[db] = m16_mma(ah[db], bf[0], acc[db]);
+}
+
+// per-thread staging geometry of one operand tile (512 threads: one 16-byte chunk per plane-row-chunk)
+#define M16_STAGE_GEOMETRY                                                                                   \
+    const int st_pl = tid >> 8, st_idx = tid & 255, st_row = st_idx >> 3, st_c = st_idx & 7;                 \
+    const int st_dst = st_pl * M16_PLB + st_row * 128 + ((st_c ^ (st_row & 6)) << 4);
+// per-lane fragment offsets: A fragment of k-slice 0 / 1 (row n of a block), transpose-read base (rows 4 g + (n >> 2))
+#define M16_LANE_GEOMETRY                                                                                    \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;             \
+    const int offA0 = n * 128 + ((g ^ (n & 6)) << 4), offA1 = offA0 ^ 64;                                    \
+    const int rj_ = 4 * g + (n >> 2), m_ = n & 3;                                                            \
+    const int offT = rj_ * 128 + (((rj_ & 6) | (m_ >> 1)) << 4) + ((m_ & 1) << 3);                           \
+    (void)offA1; (void)offT;
+// resident B fragments of owner row ROW (element offset of its first d) from row planes PTR
+#define M16_BFRAGS(DST, PTR, ELEM, PLANE)                                                                    \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)   \
+        DST[ks_][pl_] = *reinterpret_cast<const u32x4*>((PTR) + (ELEM) + pl_ * (PLANE) + ks_ * 32);
+#define M16_ZERO4(A) _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) A[db_] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define M16_STORE_ROW(ACC, DST, MUL)                                                                         \
+    _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) *reinterpret_cast<f32x4*>((DST) + 16 * db_) = ACC[db_] * (MUL);
+
+// dropout keep flags (bool: lane masks in scalar registers).  Query-owning: the lane's query RID, keys in registers (pairs
+// r = 2 i, 2 i + 1 share a hash); key-owning: the lane's key, queries in registers.
+#define M16_MASK_KEYS(KP, RID, T0)                                                                           \
+    _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) { \
+        const int key_ = (T0) + 16 * blk_ + 4 * g + 2 * i_;                                                  \
+        const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (RID), (unsigned)key_ >> 1);                     \
+        KP[blk_][2 * i_] = (hsh_ & 0xffffu) >= p.thr16;                                                      \
+        KP[blk_][2 * i_ + 1] = (hsh_ >> 16) >= p.thr16;                                                      \
+    }
+#define M16_MASK_QUERIES(KP, KEY, T0)                                                                        \
+    _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) { \
+        const int q_ = (T0) + 16 * blk_ + 4 * g + r_;                                                        \
+        const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q_), (unsigned)(KEY) >> 1); \
+        KP[blk_][r_] = (((KEY) & 1) ? (hsh_ >> 16) : (hsh_ & 0xffffu)) >= p.thr16;                           \
+    }
+#define M16_M(B, R, X) (DROP ? (kp[B][R] ? (X) * p.inv_keep : 0.f) : (X))
+#define M16_K(B, R, X) (DROP ? (kp[B][R] ? (X) : 0.f) : (X))
+
+// ============================================================================================================
+// forward: query-owning, streams k (scores) and v (P v, transposed reads); online softmax, one query per lane quadruple
+// ============================================================================================================
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int BUFB = 2 * M16_OPB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    M16_LANE_GEOMETRY
+    M16_STAGE_GEOMETRY
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 16, q = q0 + n;
+    const int ntiles = (p.S + 31) / 32;
+    const int64_t kro = (int64_t)bh * p.Sp * 64, kbo = (int64_t)bh * (p.Sp / 32);
+    const float* bias = p.bias + (int64_t)b * p.Sp;
+    u32x4 qf[2][2];
+    M16_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    const float c2 = p.scale_log2e * p.q_us[(int64_t)bh * (p.Lp / 32) + q0 / 32];
+    const unsigned rid = (unsigned)(bh * p.L + q);
+    f32x4 o[4];
+    M16_ZERO4(o)
+    float fo = FL_F0, mrun = -1e30f, lrun = 0.f;
+
+    uint4 sk, sv;
+    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+#define F16_LOAD(T0)                                                                                         \
+    sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
+    sv = *reinterpret_cast<const uint4*>(p.v_row + st_src + (int64_t)(T0) * 64);
+#define F16_STORE(BUF)                                                                                       \
+    *reinterpret_cast<uint4*>((BUF) + st_dst) = sk; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = sv;
+    F16_LOAD(0)
+    F16_STORE(lds)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        f32x4 kb[2];
+        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
+        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        const float cs = c2 * p.k_us[kbo + t], usv = p.v_us[kbo + t];
+        F16_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        f32x4 s[2];
+        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oa = ks ? offA1 : offA0;
+            u32x4 k0f[2], k1f[2];
+            M16_AFRAG(k0f, cur, oa, 0)
+            M16_AFRAG(k1f, cur, oa, 1)
+            s[0] = m16_mma(k0f[1], qf[ks][0], s[0]); s[1] = m16_mma(k1f[1], qf[ks][0], s[1]);
+            s[0] = m16_mma(k0f[0], qf[ks][1], s[0]); s[1] = m16_mma(k1f[0], qf[ks][1], s[1]);
+            s[0] = m16_mma(k0f[0], qf[ks][0], s[0]); s[1] = m16_mma(k1f[0], qf[ks][0], s[1]);
+        }
+        f32x4 x[2];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[blk][r] = s[blk][r] * cs + kb[blk][r];
+                tmax = fmaxf(tmax, x[blk][r]);
+            }
+        {   // the query's maximum over the four lanes that share it
+            auto w16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(w16[0]), __uint_as_float(w16[1]));
+            auto w32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+            tmax = fmaxf(__uint_as_float(w32[0]), __uint_as_float(w32[1]));
+        }
+        const float mn = fmaxf(mrun, tmax);
+        const float alpha = fl_exp2(mrun - mn);
+        mrun = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[blk][r] = fl_exp2(x[blk][r] - mn);
+                ps += x[blk][r];
+            }
+        lrun = lrun * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+            for (int db = 0; db < 4; ++db) o[db] *= alpha;
+        }
+        if (DROP) {
+            bool kp[2][4];
+            M16_MASK_KEYS(kp, rid, t0)
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[blk][r] = kp[blk][r] ? x[blk][r] : 0.f;   // (1 / keep is applied once, to O)
+        }
+        u32x4 bf[2];
+        M16_FIT_SPLIT_BOUNDED(bf, x, 1.f, usv, fo, o)
+        m16_stage2(o, cur + M16_OPB, offT, bf);
+        F16_STORE(lds + ((t + 1) & 1) * BUFB)
+        __syncthreads();
+    }
+#undef F16_LOAD
+#undef F16_STORE
+    lrun += __shfl_xor(lrun, 16, 64);
+    lrun += __shfl_xor(lrun, 32, 64);
+    if (q < p.L) {
+        const float inv = p.inv_keep / (lrun * fo);
+        float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * 64 + 4 * g;
+        M16_STORE_ROW(o, dst, inv)
+        if (g == 0) p.lse[(int64_t)bh * p.Lp + q] = (mrun + log2f(lrun)) * FL_LN2;
+    } else if (g == 0) {
+        p.lse[(int64_t)bh * p.Lp + q] = INFINITY;   // padded query rows: the derivative kernels then see P = 0 there
+    }
+}
+
+// ============================================================================================================
+// backward (algebra in flash.hip): gQ from query-owning workgroups, gK and gV from key-owning ones
+// ============================================================================================================
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int BUFB = 2 * M16_OPB;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    M16_LANE_GEOMETRY
+    M16_STAGE_GEOMETRY
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 16, q = q0 + n;
+    const int ntiles = (p.S + 31) / 32;
+    const int64_t kro = (int64_t)bh * p.Sp * 64, kbo = (int64_t)bh * (p.Sp / 32);
+    const float* bias = p.bias + (int64_t)b * p.Sp;
+    u32x4 qf[2][2], df[2][2];
+    M16_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    M16_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    const int64_t qb = (int64_t)bh * (p.Lp / 32) + q0 / 32;
+    const float c2 = p.scale_log2e * p.q_us[qb], usd = p.do_us[qb];
+    const float lse2 = p.lse[(int64_t)bh * p.Lp + q] * FL_LOG2E, dl = p.delta[(int64_t)bh * p.Lp + q];
+    const unsigned rid = (unsigned)(bh * p.L + q);
+    f32x4 gq[4];
+    M16_ZERO4(gq)
+    float fq = FL_F0;
+
+    uint4 sk, sv;
+    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+#define Q16_LOAD(T0)                                                                                         \
+    sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
+    sv = *reinterpret_cast<const uint4*>(p.v_row + st_src + (int64_t)(T0) * 64);
+#define Q16_STORE(BUF)                                                                                       \
+    *reinterpret_cast<uint4*>((BUF) + st_dst) = sk; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = sv;
+    Q16_LOAD(0)
+    Q16_STORE(lds)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        f32x4 kb[2];
+        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
+        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        const float usk = p.k_us[kbo + t];
+        const float cs = c2 * usk, cg = usd * p.v_us[kbo + t];
+        Q16_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        f32x4 s[2], gd[2];
+        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0]; gd[0] = s[0]; gd[1] = s[0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oa = ks ? offA1 : offA0;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                u32x4 kf[2], vf[2];
+                M16_AFRAG(kf, cur, oa, blk)
+                M16_AFRAG(vf, cur + M16_OPB, oa, blk)
+                s[blk] = m16_mma(kf[1], qf[ks][0], s[blk]); gd[blk] = m16_mma(vf[1], df[ks][0], gd[blk]);
+                s[blk] = m16_mma(kf[0], qf[ks][1], s[blk]); gd[blk] = m16_mma(vf[0], df[ks][1], gd[blk]);
+                s[blk] = m16_mma(kf[0], qf[ks][0], s[blk]); gd[blk] = m16_mma(vf[0], df[ks][0], gd[blk]);
+            }
+        }
+        bool kp[2][4];
+        if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
+        f32x4 x[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[blk][r] = fl_exp2(s[blk][r] * cs + kb[blk][r] - lse2) * (M16_M(blk, r, gd[blk][r] * cg) - dl);
+        u32x4 bf[2];
+        M16_FIT_SPLIT(bf, x, usk, fq, gq)
+        m16_stage2(gq, cur, offT, bf);   // gQ^T[d, query] += K^T[d, key] gs^T[key, query]
+        Q16_STORE(lds + ((t + 1) & 1) * BUFB)
+        __syncthreads();
+    }
+#undef Q16_LOAD
+#undef Q16_STORE
+    if (q < p.L) {
+        float* dst = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * 64 + 4 * g;
+        const float mq = p.scale / fq;
+        M16_STORE_ROW(gq, dst, mq)
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int OFF_ST = 2 * M16_OPB, BUFB = OFF_ST + 256;   // q, dO rows + lse[32], delta[32]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    M16_LANE_GEOMETRY
+    M16_STAGE_GEOMETRY
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int k0 = blockIdx.x * 128 + wave * 16, key = k0 + n;
+    const int ntiles = (p.L + 31) / 32;
+    const int64_t qro = (int64_t)bh * p.Lp * 64, sto = (int64_t)bh * p.Lp, qbo = (int64_t)bh * (p.Lp / 32);
+    u32x4 kf[2][2], vf[2][2];
+    M16_BFRAGS(kf, p.k_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    M16_BFRAGS(vf, p.v_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    const int64_t kbk = (int64_t)bh * (p.Sp / 32) + k0 / 32;
+    const float c2 = p.scale_log2e * p.k_us[kbk], usv = p.v_us[kbk];
+    const float kbias = p.bias[(int64_t)b * p.Sp + key];
+    f32x4 gk[4], gv[4];
+    M16_ZERO4(gk)
+    M16_ZERO4(gv)
+    float fk = FL_F0, fv = FL_F0;
+
+    uint4 sq, sd;
+    float sst = 0.f;   // threads 0..31: lse (base 2), 32..63: delta of the next tile
+    const int64_t st_src = qro + st_pl * p.q_plane + st_idx * 8;
+#define K16_LOAD(T0)                                                                                         \
+    sq = *reinterpret_cast<const uint4*>(p.q_row + st_src + (int64_t)(T0) * 64);                             \
+    sd = *reinterpret_cast<const uint4*>(p.do_row + st_src + (int64_t)(T0) * 64);                            \
+    if (tid < 64) sst = tid < 32 ? p.lse[sto + (T0) + tid] * FL_LOG2E : p.delta[sto + (T0) + tid - 32];
+#define K16_STORE(BUF)                                                                                       \
+    *reinterpret_cast<uint4*>((BUF) + st_dst) = sq; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = sd; \
+    if (tid < 64) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = sst;
+    K16_LOAD(0)
+    K16_STORE(lds)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        const float usq = p.q_us[qbo + t], usd = p.do_us[qbo + t];
+        const float cs = c2 * usq, cg = usv * usd;
+        K16_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        f32x4 s[2], gd[2];
+        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0]; gd[0] = s[0]; gd[1] = s[0];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oa = ks ? offA1 : offA0;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                u32x4 qa[2], da[2];
+                M16_AFRAG(qa, cur, oa, blk)
+                M16_AFRAG(da, cur + M16_OPB, oa, blk)
+                s[blk] = m16_mma(qa[1], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[1], vf[ks][0], gd[blk]);
+                s[blk] = m16_mma(qa[0], kf[ks][1], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][1], gd[blk]);
+                s[blk] = m16_mma(qa[0], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][0], gd[blk]);
+            }
+        }
+        const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
+        f32x4 lse2[2], dl[2];
+        lse2[0] = *reinterpret_cast<const f32x4*>(st + 4 * g); lse2[1] = *reinterpret_cast<const f32x4*>(st + 16 + 4 * g);
+        dl[0] = *reinterpret_cast<const f32x4*>(st + 32 + 4 * g); dl[1] = *reinterpret_cast<const f32x4*>(st + 48 + 4 * g);
+        bool kp[2][4];
+        if (DROP) { M16_MASK_QUERIES(kp, key, t0) }
+        f32x4 pd[2], gs[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = fl_exp2(s[blk][r] * cs + kbias - lse2[blk][r]);
+                pd[blk][r] = M16_K(blk, r, pr);                                   // (x 1/keep at the end, on gV)
+                gs[blk][r] = pr * (M16_M(blk, r, gd[blk][r] * cg) - dl[blk][r]);
+            }
+        u32x4 bf[2];
+        M16_FIT_SPLIT_BOUNDED(bf, pd, 1.f, usd, fv, gv)
+        m16_stage2(gv, cur + M16_OPB, offT, bf);   // gV^T[d, key] += dO^T[d, query] Pd[query, key]
+        M16_FIT_SPLIT(bf, gs, usq, fk, gk)
+        m16_stage2(gk, cur, offT, bf);             // gK^T[d, key] += Q^T[d, query] gs[query, key]
+        K16_STORE(lds + ((t + 1) & 1) * BUFB)
+        __syncthreads();
+    }
+#undef K16_LOAD
+#undef K16_STORE
+    if (key < p.S) {
+        float* dk = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * 64 + 4 * g;
+        float* dv = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * 64 + 4 * g;
+        const float mk = p.scale / fk, mv = p.inv_keep / fv;
+        M16_STORE_ROW(gk, dk, mk)
+        M16_STORE_ROW(gv, dv, mv)
+    }
+}
+
+// ============================================================================================================
+// double backward (algebra in flash.hip): (1) row statistics u, w; (2) dq, ddO (query-owning); (3) dk, dv (key-owning)
+// ============================================================================================================
+template <bool DROP, bool STATS>
+__global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    M16_LANE_GEOMETRY
+    M16_STAGE_GEOMETRY
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int q0 = blockIdx.x * 128 + wave * 16, q = q0 + n;
+    const int ntiles = (p.S + 31) / 32;
+    const int64_t kro = (int64_t)bh * p.Sp * 64, kbo = (int64_t)bh * (p.Sp / 32);
+    const float* bias = p.bias + (int64_t)b * p.Sp;
+    u32x4 qf[2][2], hqf[2][2], df[2][2];
+    M16_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    M16_BFRAGS(hqf, p.hq_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    M16_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
+    const int64_t qb = (int64_t)bh * (p.Lp / 32) + q0 / 32;
+    const float usq = p.q_us[qb], usd = p.do_us[qb], ushq = p.hq_us[qb];
+    const int64_t so = (int64_t)bh * p.Lp + q;
+    const float lse2 = p.lse[so] * FL_LOG2E, dl = p.delta[so];
+    float uu = 0.f, ww = 0.f, aa = 0.f, bq = 0.f;
+    if (!STATS) { uu = p.u[so]; ww = p.w[so]; }
+    const unsigned rid = (unsigned)(bh * p.L + q);
+    f32x4 dq[4], ddo[4];
+    M16_ZERO4(dq)
+    M16_ZERO4(ddo)
+    float fdq = FL_F0, fddo = FL_F0;
+
+    uint4 sk, shk, sv, shv;
+    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+#define B16_LOAD(T0)                                                                                         \
+    sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
+    shk = *reinterpret_cast<const uint4*>(p.hk_row + st_src + (int64_t)(T0) * 64);                           \
+    sv = *reinterpret_cast<const uint4*>(p.v_row + st_src + (int64_t)(T0) * 64);                             \
+    shv = *reinterpret_cast<const uint4*>(p.hv_row + st_src + (int64_t)(T0) * 64);
+#define B16_STORE(BUF)                                                                                       \
+    *reinterpret_cast<uint4*>((BUF) + st_dst) = sk; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = shk; \
+    *reinterpret_cast<uint4*>((BUF) + 2 * M16_OPB + st_dst) = sv; *reinterpret_cast<uint4*>((BUF) + 3 * M16_OPB + st_dst) = shv;
+    B16_LOAD(0)
+    B16_STORE(lds)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        f32x4 kb[2];
+        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
+        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t];
+        const float cs = p.scale_log2e * usq * usk, cg = usd * usv, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk, ch = usd * ushv;
+        B16_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        // ---- the [key, query] tiles: S, gd, G (two chains: hq.k and q.hk carry different block scales), HD ----
+        f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oa = ks ? offA1 : offA0;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                u32x4 kf[2], hkf[2], vf[2], hvf[2];
+                M16_AFRAG(kf, cur, oa, blk)
+                M16_AFRAG(hkf, cur + M16_OPB, oa, blk)
+                M16_AFRAG(vf, cur + 2 * M16_OPB, oa, blk)
+                M16_AFRAG(hvf, cur + 3 * M16_OPB, oa, blk)
+#define B16_TERM(I, J)                                                                                       \
+    s[blk] = m16_mma(kf[I], qf[ks][J], s[blk]); gd[blk] = m16_mma(vf[I], df[ks][J], gd[blk]);               \
+    g1[blk] = m16_mma(kf[I], hqf[ks][J], g1[blk]); hd_[blk] = m16_mma(hvf[I], df[ks][J], hd_[blk]);         \
+    g2[blk] = m16_mma(hkf[I], qf[ks][J], g2[blk]);
+                B16_TERM(1, 0)
+                B16_TERM(0, 1)
+                B16_TERM(0, 0)
+#undef B16_TERM
+            }
+        }
+        bool kp[2][4];
+        if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
+        f32x4 pr[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[blk][r] = fl_exp2(s[blk][r] * cs + kb[blk][r] - lse2);
+                g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;   // G
+                gd[blk][r] = M16_M(blk, r, gd[blk][r] * cg);      // gy = M o gd
+                hd_[blk][r] = M16_M(blk, r, hd_[blk][r] * ch);    // M o HD
+            }
+        if (STATS) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pg = pr[blk][r] * g1[blk][r];
+                    uu += pg;
+                    aa += pg * gd[blk][r];
+                    bq += pr[blk][r] * hd_[blk][r];
+                }
+        } else {
+            f32x4 x[2];
+            u32x4 bf[2];
+            // gs = P (gy - t)                                   dq += hk^T gs
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[blk][r] = pr[blk][r] * (gd[blk][r] - dl);
+            M16_FIT_SPLIT(bf, x, ushk, fdq, dq)
+            m16_stage2(dq, cur + M16_OPB, offT, bf);
+            // HS = P (G (gy - t) - gy u + M HD - w)             dq += k^T HS
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    x[blk][r] = pr[blk][r] * (g1[blk][r] * (gd[blk][r] - dl) - gd[blk][r] * uu + hd_[blk][r] - ww);
+            M16_FIT_SPLIT(bf, x, usk, fdq, dq)
+            m16_stage2(dq, cur, offT, bf);
+            // Pd = M P                                          ddO += hv^T Pd
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r]);
+            M16_FIT_SPLIT_BOUNDED(bf, x, p.inv_keep, ushv, fddo, ddo)
+            m16_stage2(ddo, cur + 3 * M16_OPB, offT, bf);
+            // HgD = M P (G - u)                                 ddO += v^T HgD
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r] * (g1[blk][r] - uu));
+            M16_FIT_SPLIT(bf, x, usv, fddo, ddo)
+            m16_stage2(ddo, cur + 2 * M16_OPB, offT, bf);
+        }
+        B16_STORE(lds + ((t + 1) & 1) * BUFB)
+        __syncthreads();
+    }
+#undef B16_LOAD
+#undef B16_STORE
+    if (STATS) {
+        uu += __shfl_xor(uu, 16, 64); uu += __shfl_xor(uu, 32, 64);
+        aa += __shfl_xor(aa, 16, 64); aa += __shfl_xor(aa, 32, 64);
+        bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
+        if (g == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
+            p.u[so] = uu;
+            p.w[so] = aa - 2.f * dl * uu + bq;
+        }
+        return;
+    }
+    if (q < p.L) {
+        float* d1 = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * 64 + 4 * g;
+        float* d4 = p.o4 + ((int64_t)b * p.L + q) * p.ld4 + p.off4 + h * 64 + 4 * g;
+        const float m1 = p.scale / fdq, m4 = 1.f / fddo;
+        M16_STORE_ROW(dq, d1, m1)
+        M16_STORE_ROW(ddo, d4, m4)
+    }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int OFF_ST = 3 * M16_OPB, BUFB = OFF_ST + 512;   // q, hq, dO rows + lse, delta, u, w [32] each
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    M16_LANE_GEOMETRY
+    M16_STAGE_GEOMETRY
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+    const int k0 = blockIdx.x * 128 + wave * 16, key = k0 + n;
+    const int ntiles = (p.L + 31) / 32;
+    const int64_t qro = (int64_t)bh * p.Lp * 64, sto = (int64_t)bh * p.Lp, qbo = (int64_t)bh * (p.Lp / 32);
+    u32x4 kf[2][2], vf[2][2], hkf[2][2], hvf[2][2];
+    M16_BFRAGS(kf, p.k_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    M16_BFRAGS(vf, p.v_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    M16_BFRAGS(hkf, p.hk_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    M16_BFRAGS(hvf, p.hv_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
+    const int64_t kbk = (int64_t)bh * (p.Sp / 32) + k0 / 32;
+    const float usk = p.k_us[kbk], ushk = p.hk_us[kbk], usv = p.v_us[kbk], ushv = p.hv_us[kbk];
+    const float kbias = p.bias[(int64_t)b * p.Sp + key];
+    f32x4 dk[4], dv[4];
+    M16_ZERO4(dk)
+    M16_ZERO4(dv)
+    float fdk = FL_F0, fdv = FL_F0;
+
+    uint4 sq, shq, sd;
+    float sst = 0.f;   // threads 0..127 carry lse (base 2) | delta | u | w of the next tile
+    const int64_t st_src = qro + st_pl * p.q_plane + st_idx * 8;
+#define C16_LOAD(T0)                                                                                         \
+    sq = *reinterpret_cast<const uint4*>(p.q_row + st_src + (int64_t)(T0) * 64);                             \
+    shq = *reinterpret_cast<const uint4*>(p.hq_row + st_src + (int64_t)(T0) * 64);                           \
+    sd = *reinterpret_cast<const uint4*>(p.do_row + st_src + (int64_t)(T0) * 64);                            \
+    if (tid < 128) {                                                                                         \
+        const float* sp_ = tid < 32 ? p.lse : tid < 64 ? p.delta : tid < 96 ? p.u : p.w;                     \
+        sst = sp_[sto + (T0) + (tid & 31)];                                                                  \
+        if (tid < 32) sst *= FL_LOG2E;                                                                       \
+    }
+#define C16_STORE(BUF)                                                                                       \
+    *reinterpret_cast<uint4*>((BUF) + st_dst) = sq; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = shq; \
+    *reinterpret_cast<uint4*>((BUF) + 2 * M16_OPB + st_dst) = sd;                                            \
+    if (tid < 128) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = sst;
+    C16_LOAD(0)
+    C16_STORE(lds)
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        const float usq = p.q_us[qbo + t], ushq = p.hq_us[qbo + t], usd = p.do_us[qbo + t];
+        const float cs = p.scale_log2e * usq * usk, cg = usd * usv, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk, ch = usd * ushv;
+        C16_LOAD(min(t0 + 32, ntiles * 32 - 32))
+        f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int oa = ks ? offA1 : offA0;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                u32x4 qa[2], hqa[2], da[2];
+                M16_AFRAG(qa, cur, oa, blk)
+                M16_AFRAG(hqa, cur + M16_OPB, oa, blk)
+                M16_AFRAG(da, cur + 2 * M16_OPB, oa, blk)
+#define C16_TERM(I, J)                                                                                       \
+    s[blk] = m16_mma(qa[I], kf[ks][J], s[blk]); gd[blk] = m16_mma(da[I], vf[ks][J], gd[blk]);               \
+    g1[blk] = m16_mma(hqa[I], kf[ks][J], g1[blk]); hd_[blk] = m16_mma(da[I], hvf[ks][J], hd_[blk]);         \
+    g2[blk] = m16_mma(qa[I], hkf[ks][J], g2[blk]);
+                C16_TERM(1, 0)
+                C16_TERM(0, 1)
+                C16_TERM(0, 0)
+#undef C16_TERM
+            }
+        }
+        // statistics of this lane's 2 x 4 queries (rows 16 blk + 4 g + r of the tile)
+        const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
+        f32x4 lse2[2], dl[2], uu[2], ww[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            lse2[blk] = *reinterpret_cast<const f32x4*>(st + 16 * blk + 4 * g);
+            dl[blk] = *reinterpret_cast<const f32x4*>(st + 32 + 16 * blk + 4 * g);
+            uu[blk] = *reinterpret_cast<const f32x4*>(st + 64 + 16 * blk + 4 * g);
+            ww[blk] = *reinterpret_cast<const f32x4*>(st + 96 + 16 * blk + 4 * g);
+        }
+        bool kp[2][4];
+        if (DROP) { M16_MASK_QUERIES(kp, key, t0) }
+        f32x4 pr[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[blk][r] = fl_exp2(s[blk][r] * cs + kbias - lse2[blk][r]);
+                g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;   // G
+                gd[blk][r] = M16_M(blk, r, gd[blk][r] * cg);      // gy = M o gd
+                hd_[blk][r] = M16_M(blk, r, hd_[blk][r] * ch);    // M o HD
+            }
+        f32x4 x[2];
+        u32x4 bf[2];
+        // gs                                                     dk += hq^T gs
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[blk][r] = pr[blk][r] * (gd[blk][r] - dl[blk][r]);
+        M16_FIT_SPLIT(bf, x, ushq, fdk, dk)
+        m16_stage2(dk, cur + M16_OPB, offT, bf);
+        // HS                                                     dk += q^T HS
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[blk][r] = pr[blk][r] * (g1[blk][r] * (gd[blk][r] - dl[blk][r]) - gd[blk][r] * uu[blk][r] + hd_[blk][r] - ww[blk][r]);
+        M16_FIT_SPLIT(bf, x, usq, fdk, dk)
+        m16_stage2(dk, cur, offT, bf);
+        // HgD                                                    dv += dO^T HgD
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r] * (g1[blk][r] - uu[blk][r]));
+        M16_FIT_SPLIT(bf, x, usd, fdv, dv)
+        m16_stage2(dv, cur + 2 * M16_OPB, offT, bf);
+        C16_STORE(lds + ((t + 1) & 1) * BUFB)
+        __syncthreads();
+    }
+#undef C16_LOAD
+#undef C16_STORE
+    if (key < p.S) {
+        float* d2 = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * 64 + 4 * g;
+        float* d3 = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * 64 + 4 * g;
+        const float m2 = p.scale / fdk, m3 = 1.f / fdv;
+        M16_STORE_ROW(dk, d2, m2)
+        M16_STORE_ROW(dv, d3, m3)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// launchers (called from the C-ABI entry points of flash.hip when hd == 64 and the operands carry the fp16 form)
+// ------------------------------------------------------------------------------------------------------------
+#define M16_LAUNCH(KERNEL, GRID)                                                                             \
+    if (a.thr16) hipLaunchKernelGGL((KERNEL<true>), GRID, dim3(512), 0, stream, a);                          \
+    else hipLaunchKernelGGL((KERNEL<false>), GRID, dim3(512), 0, stream, a);
+#define M16_LAUNCH2(KERNEL, ST, GRID)                                                                        \
+    if (a.thr16) hipLaunchKernelGGL((KERNEL<true, ST>), GRID, dim3(512), 0, stream, a);                      \
+    else hipLaunchKernelGGL((KERNEL<false, ST>), GRID, dim3(512), 0, stream, a);
+
+void fl16_launch_fwd(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_fwd_kernel, grid) }
+void fl16_launch_bwd_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_q_kernel, grid) }
+void fl16_launch_bwd_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_kv_kernel, grid) }
+void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH2(flash16_bb_q_kernel, true, grid) }
+void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH2(flash16_bb_q_kernel, false, grid) }
+void fl16_launch_bb_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_kv_kernel, grid) }

@@ -814,6 +814,17 @@ FLASH_TR = _os.environ.get("IX_FLASH_TR", "f16")
 _TR_FORMS = {"bf16": 0, "f16": 1}
 
 
+def flash_m16(on=None):
+    """Head dim 64 in the fp16 form runs the 16x16x32 passes of csrc/flash16.hip (row planes only, no tr planes are written);
+    ``flash_m16(False)`` switches back to the 32x32x16 passes of csrc/flash.hip (A/B runs, and the tests pin both).  Returns
+    the previous setting.  Operands split under one setting must be consumed under the same one."""
+    return bool(_L().ix_flash_set_m16(-1 if on is None else int(bool(on))))
+
+
+def _rows_only(hd, form):
+    return hd == 64 and form == 1 and flash_m16()
+
+
 class AttnPlanes:
     """One attention operand as the flash kernels read it: fp16 row planes [2][n*H][Rp][hd] with their block unscale factors
     [n*H][Rp/32], and tr planes -- bf16 [3][n*H][hd][Rp] (form 0) or fp16 [2][n*H][hd][Rp] (form 1) (csrc/flash.hip);
@@ -832,6 +843,8 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
     Rp = _pad128(R)
     dev = x.device
     form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
+    if _rows_only(hd, form):
+        row, tr = row or tr, False
     rowp = torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if row else None
     us = torch.empty(n * H * (Rp // 32), dtype=torch.float32, device=dev) if row or (tr and form == 1) else None
     trp = None
@@ -877,7 +890,10 @@ def attn_split_multi(ops, n, H, hd, tr_form=None):
     form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
     cnt = len(ops)
     xs, rows, uss, trs = [], [], [], []
+    rows_only = _rows_only(hd, form)
     for x, R, ld, off, row, tr in ops:
+        if rows_only:
+            row, tr = row or tr, False
         x = _req(x, "attention operand")
         Rp, dev = _pad128(R), x.device
         xs.append(x)

@@ -49,12 +49,15 @@ def kernel_form(request):
     hipops.FLASH_TR = old_tr
 
 
-@pytest.fixture(params=["f16", "bf16"])
+@pytest.fixture(params=["f16", "bf16", "f16_32x32"])
 def flash_form(request):
     """Runs a test once per form of the flash kernels' token-contracting products: "f16" = two fp16 planes, three MFMAs per
-    k-slice, intermediates scaled into fp16 range in registers (default since round 3); "bf16" = three bf16 planes, six MFMAs
-    (IX_FLASH_TR=bf16)."""
+    k-slice, intermediates scaled into fp16 range in registers (default since round 3; at head dim 64 the 16x16x32 passes of
+    csrc/flash16.hip since round 5); "bf16" = three bf16 planes, six MFMAs (IX_FLASH_TR=bf16); "f16_32x32" = the fp16 form on
+    the 32x32x16 passes at every head dim (ix_flash_set_m16(0): the family the 16x16x32 passes replaced at head dim 64)."""
     from interactron_amd import hipops
-    old, hipops.FLASH_TR = hipops.FLASH_TR, request.param
+    old, hipops.FLASH_TR = hipops.FLASH_TR, "f16" if request.param == "f16_32x32" else request.param
+    old_m16 = hipops.flash_m16(request.param != "f16_32x32")
     yield request.param
     hipops.FLASH_TR = old
+    hipops.flash_m16(old_m16)
