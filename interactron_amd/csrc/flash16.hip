@@ -10,28 +10,55 @@
 //     (n = lane & 15, g = lane >> 4) holds owner row n and streamed rows 16 blk + 4 g + r: eight elements per lane per tile
 //     instead of sixteen, a quarter of the accumulator registers per tile kind;
 //   * all four owner-side operands stay in registers as B fragments (16 registers each);
-//   * the streamed side is staged ONCE, in row layout only ([2 planes][32 rows][128 B], 16-byte chunk c of row r at
-//     c ^ (r & 6)): products that contract over the head dim read it with ds_read_b128 (A fragment = 8 consecutive d of one
-//     row), products that contract over the streamed rows read THE SAME image with ds_read_b64_tr_b16 (the hardware
-//     transpose: lane (d, g) receives rows 4 g .. 4 g + 3 and 16 + 4 g .. of column d), so no tr planes are read, staged or
-//     even written for head dim 64 -- half the LDS footprint, half the staging traffic.  The swizzle is conflict-free for
-//     both access kinds (16-lane groups of ds_read_b128 as listed in MI355X_MICROARCH "LDS"; 32-lane halves of the
-//     transpose read), tools/micro/m16_layout.hip checks the layout facts on the device;
+//   * the streamed side is staged ONCE, as rows ([2 planes][4 panels of 16 d][32 rows][32 B]): products that contract over
+//     the head dim read it with ds_read_b128 (A fragment = 8 consecutive d of one row), products that contract over the
+//     streamed rows read THE SAME image with ds_read_b64_tr_b16 (the hardware transpose: lane (d, g) receives rows 4 g ..
+//     4 g + 3 and 16 + 4 g .. of column d), so no tr planes are read, staged or even written for head dim 64 -- half the LDS
+//     footprint, half the staging traffic.  With 32-byte rows inside a panel both access kinds are conflict-free without
+//     any swizzle (16-lane groups of ds_read_b128 as listed in MI355X_MICROARCH "LDS"; 32-lane halves of the transpose read
+//     cover 256 contiguous bytes) and every k-slice / d-block / row-block / plane / operand step is an immediate offset;
+//     tools/micro/m16_layout.hip checks the layout facts on the device;
 //   * the accumulator registers of a tile ARE the B fragment (k = 8 g + e <-> streamed rows 4 g + e | 16 + 4 g + e - 4) of
 //     the products that contract over the streamed rows: no [L, S] value passes through LDS;
 //   * two LDS buffers, ONE barrier per tile; the next tile's rows are requested before the tile's arithmetic and written to
 //     the other buffer after it.
-// Two waves of a SIMD de-phase by themselves between barriers (one is in its matrix burst while the other splits
-// accumulators), and 16x16x32 instructions leave the LDS-read return path usable next to a matrix burst
-// (profiles/r4w_mfma_overlap_microbench.txt).
+// Ping-pong (the passes that run one workgroup per CU: dk / dv, dq / ddO, gK / gV).  Left to themselves the two waves of a
+// SIMD run in lock-step -- both in their first-stage matrix burst, then both in the element-wise stretch (clock stamps:
+// tools/m16_timeline.py, profiles/r5g_m16_timeline_lockstep.txt) -- so matrix and vector work add up.  A tile is therefore
+// two segments around two barriers, M (the first-stage products) and V (element-wise arithmetic, conversions, second-stage
+// products), and waves 4..7 run one segment behind waves 0..3 (they pass one extra barrier before the loop, the others one
+// after it): at any time one wave of each SIMD is in M and its partner in V.  The staging ring is three tiles deep so that
+// both halves can write "two tiles ahead" with the same code.
 #include "flash_common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-#define M16_OPB 8192   // one streamed operand tile in LDS: 2 planes x 32 rows x 128 bytes
+// experiment switch (-DM16_PRIO_LEVEL=n): waves 0..3 (one per SIMD) at priority n, their partners at 0
+#ifdef M16_PRIO_LEVEL
+#define M16_PRIO if (__builtin_amdgcn_readfirstlane(threadIdx.x) < 256) __builtin_amdgcn_s_setprio(M16_PRIO_LEVEL);
+#else
+#define M16_PRIO
+#endif
+// diagnostic build (-DM16_DIAG, never loaded by the package): s_memtime stamps of waves 0 and 4 of workgroup (0, 0) over tiles
+// 8 .. 15 of the double-backward passes, read back through ix_diag_m16_read (tools/m16_timeline.py)
+#ifdef M16_DIAG
+__device__ unsigned long long m16_diag[2 * 8 * 16];
+#define M16_STAMP(K)                                                                                         \
+    { __builtin_amdgcn_sched_barrier(0);                                                                     \
+      if (blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && t >= 8 && t < 16 && lane == 0)            \
+          m16_diag[((wave >> 2) * 8 + (t - 8)) * 16 + (K)] = __builtin_amdgcn_s_memtime();                   \
+      __builtin_amdgcn_sched_barrier(0); }
+extern "C" int ix_diag_m16_read(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(m16_diag), sizeof(m16_diag)) == hipSuccess ? 0 : -1;
+}
+#else
+#define M16_STAMP(K)
+#endif
+#define M16_OPB 8192   // one streamed operand tile in LDS: 2 planes x 4 panels (16 d each) x 32 rows x 32 bytes
 #define M16_PLB 4096
-#define M16_HALF 2048  // rows 16 .. 31
+#define M16_PANEL 1024
+#define M16_HALF 512   // rows 16 .. 31 of a panel
 
 __device__ __forceinline__ f32x4 m16_mma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -83,40 +110,59 @@ __device__ __forceinline__ void m16_fit(float mxus, float& F, f32x4 (&acc)[4]) {
         F = fn;
     }
 }
-// x (this lane's 2 x 4 values of one tile column) . c -> B fragments (h, l); the empty statement keeps the matrix
-// instructions that read them behind the conversions' wait states
+// x (this lane's 2 x 4 values of one tile column) . c -> B fragments (h, l); the s_nop statement keeps the matrix
+// instructions that read them behind the conversions' wait states (not volatile: it must not pin LDS reads below itself)
 __device__ __forceinline__ void m16_split(u32x4 (&bf)[2], const f32x4 (&x)[2], float c) {
     unsigned h0 = m16_cvt_h(x[0][0], x[0][1], c), h1 = m16_cvt_h(x[0][2], x[0][3], c);
     unsigned h2 = m16_cvt_h(x[1][0], x[1][1], c), h3 = m16_cvt_h(x[1][2], x[1][3], c);
     unsigned l0 = m16_cvt_l(x[0][0], x[0][1], c, h0), l1 = m16_cvt_l(x[0][2], x[0][3], c, h1);
     unsigned l2 = m16_cvt_l(x[1][0], x[1][1], c, h2), l3 = m16_cvt_l(x[1][2], x[1][3], c, h3);
-    asm volatile("s_nop 1" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+    asm("s_nop 1" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
     bf[0][0] = h0; bf[0][1] = h1; bf[0][2] = h2; bf[0][3] = h3;
     bf[1][0] = l0; bf[1][1] = l1; bf[1][2] = l2; bf[1][3] = l3;
 }
-__device__ __forceinline__ float m16_absmax(const f32x4 (&x)[2]) {
-    float a = fmaxf(fmaxf(fabsf(x[0][0]), fabsf(x[0][1])), fmaxf(fabsf(x[0][2]), fabsf(x[0][3])));
-    float b = fmaxf(fmaxf(fabsf(x[1][0]), fabsf(x[1][1])), fmaxf(fabsf(x[1][2]), fabsf(x[1][3])));
-    return fmaxf(a, b);
+__device__ __forceinline__ float m16_absmax(const f32x4 (&x)[2]) {   // four instructions for eight values
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(x[0][0]), "v"(x[0][1]), "v"(x[0][2]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x[0][3]), "v"(x[1][0]));
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(x[1][1]), "v"(x[1][2]));
+    asm("v_max_f32 %0, %0, |%1|" : "+v"(m) : "v"(x[1][3]));
+    return m;
 }
 // values of unknown range / values in [0, bound]
 #define M16_FIT_SPLIT(BF, X, US, F, ACC)                                       \
     { m16_fit<true>(m16_absmax(X) * (US), F, ACC); m16_split(BF, X, (US) * F); }
 #define M16_FIT_SPLIT_BOUNDED(BF, X, BOUND, US, F, ACC)                        \
     { m16_fit<false>((BOUND) * (US), F, ACC); m16_split(BF, X, (US) * F); }
+// one second-stage product ACC += OP^T . X: the operand's transposed fragments are requested first, in program order, so that
+// they sit above the range check's branch and fly during the conversions
+#define M16_PRODUCT(ACC, OP, X, US, F)                                         \
+    { M16Tr tr_; u32x4 bf_[2]; m16_stage2_load(tr_, OP, offT);                 \
+      M16_FIT_SPLIT(bf_, X, US, F, ACC) m16_stage2_mma(ACC, tr_, bf_); }
+#define M16_PRODUCT_BOUNDED(ACC, OP, X, BOUND, US, F)                          \
+    { M16Tr tr_; u32x4 bf_[2]; m16_stage2_load(tr_, OP, offT);                 \
+      M16_FIT_SPLIT_BOUNDED(bf_, X, BOUND, US, F, ACC) m16_stage2_mma(ACC, tr_, bf_); }
 
 // acc[db] (16 d x 16 owner rows) += X^T[d, streamed rows] . bf[streamed rows, owner] for the operand tile at OP: the A
 // fragment of d block db comes out of the row-layout image by two transpose reads per plane (rows 4 g + e, 16 + 4 g + e)
-__device__ __forceinline__ void m16_stage2(f32x4 (&acc)[4], const unsigned char* op, int offT, const u32x4 (&bf)[2]) {
-    u32x4 ah[4], al[4];
+struct M16Tr {   // A fragments (planes h, l) of the four d blocks of one streamed operand, transposed
+    u32x4 h[4], l[4];
+};
+__device__ __forceinline__ void m16_stage2_load(M16Tr& a, const unsigned char* op, int offT) {
+    u32x4 (&ah)[4] = a.h;
+    u32x4 (&al)[4] = a.l;
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-        const int o = offT ^ (db << 5);
+        const int o = offT + db * M16_PANEL;
         const u32x2 h0 = m16_tr(op + o), h1 = m16_tr(op + M16_HALF + o);
         const u32x2 l0 = m16_tr(op + M16_PLB + o), l1 = m16_tr(op + M16_PLB + M16_HALF + o);
         ah[db][0] = h0[0]; ah[db][1] = h0[1]; ah[db][2] = h1[0]; ah[db][3] = h1[1];
         al[db][0] = l0[0]; al[db][1] = l0[1]; al[db][2] = l1[0]; al[db][3] = l1[1];
     }
+}
+__device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, const u32x4 (&bf)[2]) {
+    const u32x4 (&ah)[4] = a.h;
+    const u32x4 (&al)[4] = a.l;
 #pragma unroll
     for (int db = 0; db < 4; ++db) acc[db] = m16_mma(al[db], bf[0], acc[db]);
 #pragma unroll
@@ -126,16 +172,20 @@ __device__ __forceinline__ void m16_stage2(f32x4 (&acc)[4], const unsigned char*
 }
 
 // per-thread staging geometry of one operand tile (512 threads: one 16-byte chunk per plane-row-chunk)
+// (thread bits: 0 = 16-byte half of a panel row, 1-2 = row & 3, 3-4 = panel, 5-7 = row >> 2: eight consecutive lanes write 128
+// contiguous bytes of LDS, a wave reads 1 KiB of contiguous global memory)
 #define M16_STAGE_GEOMETRY                                                                                   \
-    const int st_pl = tid >> 8, st_idx = tid & 255, st_row = st_idx >> 3, st_c = st_idx & 7;                 \
-    const int st_dst = st_pl * M16_PLB + st_row * 128 + ((st_c ^ (st_row & 6)) << 4);
+    const int st_pl = tid >> 8, st_idx = tid & 255;                                                          \
+    const int st_row = ((st_idx >> 5) << 2) | ((st_idx >> 1) & 3), st_c = (((st_idx >> 3) & 3) << 1) | (st_idx & 1); \
+    const int st_dst = st_pl * M16_PLB + (st_c >> 1) * M16_PANEL + st_row * 32 + ((st_c & 1) << 4);          \
+    const int st_off = st_row * 64 + st_c * 8;   /* element offset of the chunk inside the tile's 32 x 64 rows */
 // per-lane fragment offsets: A fragment of k-slice 0 / 1 (row n of a block), transpose-read base (rows 4 g + (n >> 2))
 #define M16_LANE_GEOMETRY                                                                                    \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;             \
-    const int offA0 = n * 128 + ((g ^ (n & 6)) << 4), offA1 = offA0 ^ 64;                                    \
-    const int rj_ = 4 * g + (n >> 2), m_ = n & 3;                                                            \
-    const int offT = rj_ * 128 + (((rj_ & 6) | (m_ >> 1)) << 4) + ((m_ & 1) << 3);                           \
-    (void)offA1; (void)offT;
+    const int offA0 = (g >> 1) * M16_PANEL + n * 32 + ((g & 1) << 4), offA1 = offA0 + 2 * M16_PANEL;        \
+    const int offT = (4 * g + (n >> 2)) * 32 + ((n & 3) << 3);                                               \
+    (void)offA1; (void)offT;                                                                                 \
+    M16_PRIO
 // resident B fragments of owner row ROW (element offset of its first d) from row planes PTR
 #define M16_BFRAGS(DST, PTR, ELEM, PLANE)                                                                    \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_)   \
@@ -159,8 +209,10 @@ __device__ __forceinline__ void m16_stage2(f32x4 (&acc)[4], const unsigned char*
         const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q_), (unsigned)(KEY) >> 1); \
         KP[blk_][r_] = (((KEY) & 1) ? (hsh_ >> 16) : (hsh_ & 0xffffu)) >= p.thr16;                           \
     }
-#define M16_M(B, R, X) (DROP ? (kp[B][R] ? (X) * p.inv_keep : 0.f) : (X))
-#define M16_K(B, R, X) (DROP ? (kp[B][R] ? (X) : 0.f) : (X))
+// Dropout enters every formula through pm = keep ? P : 0 (one select per element); the 1 / keep of M = keep / (1 - p) is folded
+// into wave-uniform constants: gy = M o gd -> P o gy = pm (gd cg / keep), M o HD likewise, and products whose whole [L, S]
+// operand carries an M (Pd, HgD) take 1 / keep in their conversion scale.
+#define M16_PM(B, R, X) (DROP ? (kp[B][R] ? (X) : 0.f) : (X))
 
 // ============================================================================================================
 // forward: query-owning, streams k (scores) and v (P v, transposed reads); online softmax, one query per lane quadruple
@@ -186,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
     float fo = FL_F0, mrun = -1e30f, lrun = 0.f;
 
     uint4 sk, sv;
-    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+    const int64_t st_src = kro + st_pl * p.k_plane + st_off;
 #define F16_LOAD(T0)                                                                                         \
     sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
     sv = *reinterpret_cast<const uint4*>(p.v_row + st_src + (int64_t)(T0) * 64);
@@ -255,9 +307,7 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[blk][r] = kp[blk][r] ? x[blk][r] : 0.f;   // (1 / keep is applied once, to O)
         }
-        u32x4 bf[2];
-        M16_FIT_SPLIT_BOUNDED(bf, x, 1.f, usv, fo, o)
-        m16_stage2(o, cur + M16_OPB, offT, bf);
+        M16_PRODUCT_BOUNDED(o, cur + M16_OPB, x, 1.f, usv, fo)
         F16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
     }
@@ -302,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
     float fq = FL_F0;
 
     uint4 sk, sv;
-    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+    const int64_t st_src = kro + st_pl * p.k_plane + st_off;
 #define Q16_LOAD(T0)                                                                                         \
     sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
     sv = *reinterpret_cast<const uint4*>(p.v_row + st_src + (int64_t)(T0) * 64);
@@ -319,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
         kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
         kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
         const float usk = p.k_us[kbo + t];
-        const float cs = c2 * usk, cg = usd * p.v_us[kbo + t];
+        const float cs = c2 * usk, cgk = usd * p.v_us[kbo + t] * p.inv_keep;
         Q16_LOAD(min(t0 + 32, ntiles * 32 - 32))
         f32x4 s[2], gd[2];
         s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0]; gd[0] = s[0]; gd[1] = s[0];
@@ -342,11 +392,11 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                x[blk][r] = fl_exp2(s[blk][r] * cs + kb[blk][r] - lse2) * (M16_M(blk, r, gd[blk][r] * cg) - dl);
-        u32x4 bf[2];
-        M16_FIT_SPLIT(bf, x, usk, fq, gq)
-        m16_stage2(gq, cur, offT, bf);   // gQ^T[d, query] += K^T[d, key] gs^T[key, query]
+            for (int r = 0; r < 4; ++r) {   // gs = P o (M o gd - t) = pm gd' - P t
+                const float pr = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));
+                x[blk][r] = M16_PM(blk, r, pr) * (gd[blk][r] * cgk) - pr * dl;
+            }
+        M16_PRODUCT(gq, cur, x, usk, fq)   // gQ^T[d, query] += K^T[d, key] gs^T[key, query]
         Q16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
     }
@@ -359,16 +409,32 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
     }
 }
 
+// ---- split-phase passes (one workgroup per CU: gK / gV, dq / ddO, dk / dv) ---------------------------------------------
+// A wave issues in order: a matrix instruction that finds the SIMD's matrix pipe taken by its partner wave blocks every
+// vector instruction behind it, so two waves whose streams both mix matrix and vector work take about the SUM of their
+// times (measured: lock-stepped phases and de-phased ones alike, profiles/r5*_m16_*.txt).  These passes therefore
+// separate the two kinds of work in time: a tile is a V segment -- element-wise arithmetic, range checks and fp16
+// conversions of tile t, no matrix instruction -- and an M segment -- the second-stage products of tile t out of the converted
+// fragments, then the first-stage products of tile t + 1, (almost) no vector instruction -- with a barrier after each, and
+// waves 4..7 run one segment behind waves 0..3 (one extra barrier before their loop, the others one after theirs): at any
+// time one wave of a SIMD streams matrix instructions while its partner issues vector instructions.  Products that go
+// into the same accumulator share one range check (their fragments are converted before either product runs).  The
+// staging ring is four tiles deep: tile t is read in M(t) (first stage) and M(t + 1) (second stage) by both halves, and
+// tile t + 2 is written at the end of V(t).
+#define M16_LAG_IF(COND) if (COND) __syncthreads();
+#define M16_UPPER_HALF (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
+#define M16_NSLOT 4
+
 template <bool DROP>
 __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 2 * M16_OPB, BUFB = OFF_ST + 256;   // q, dO rows + lse[32], delta[32]
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
     M16_LANE_GEOMETRY
     M16_STAGE_GEOMETRY
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int k0 = blockIdx.x * 128 + wave * 16, key = k0 + n;
-    const int ntiles = (p.L + 31) / 32;
+    const int ntiles = (p.L + 31) / 32, last = ntiles * 32 - 32;
     const int64_t qro = (int64_t)bh * p.Lp * 64, sto = (int64_t)bh * p.Lp, qbo = (int64_t)bh * (p.Lp / 32);
     u32x4 kf[2][2], vf[2][2];
     M16_BFRAGS(kf, p.k_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
@@ -382,40 +448,46 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     float fk = FL_F0, fv = FL_F0;
 
     uint4 sq, sd;
-    float sst = 0.f;   // threads 0..31: lse (base 2), 32..63: delta of the next tile
-    const int64_t st_src = qro + st_pl * p.q_plane + st_idx * 8;
+    float sst = 0.f;   // threads 0..31: lse, 32..63: delta of the staged tile
+    const int64_t st_src = qro + st_pl * p.q_plane + st_off;
 #define K16_LOAD(T0)                                                                                         \
     sq = *reinterpret_cast<const uint4*>(p.q_row + st_src + (int64_t)(T0) * 64);                             \
     sd = *reinterpret_cast<const uint4*>(p.do_row + st_src + (int64_t)(T0) * 64);                            \
-    if (tid < 64) sst = tid < 32 ? p.lse[sto + (T0) + tid] * FL_LOG2E : p.delta[sto + (T0) + tid - 32];
+    if (tid < 64) sst = tid < 32 ? p.lse[sto + (T0) + tid] : p.delta[sto + (T0) + tid - 32];
 #define K16_STORE(BUF)                                                                                       \
     *reinterpret_cast<uint4*>((BUF) + st_dst) = sq; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = sd; \
-    if (tid < 64) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = sst;
+    if (tid < 64) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = tid < 32 ? sst * FL_LOG2E : sst;
+    // first stage of the tile at BUF: S[query, key] = Q K^T, gd = dO V^T
+#define K16_PHASE1(BUF)                                                                                      \
+    s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0]; gd[0] = s[0]; gd[1] = s[0];                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+        const int oa = ks ? offA1 : offA0;                                                                   \
+        _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) {                                                \
+            u32x4 qa[2], da[2];                                                                              \
+            M16_AFRAG(qa, (BUF), oa, blk)                                                                    \
+            M16_AFRAG(da, (BUF) + M16_OPB, oa, blk)                                                          \
+            s[blk] = m16_mma(qa[1], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[1], vf[ks][0], gd[blk]);       \
+            s[blk] = m16_mma(qa[0], kf[ks][1], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][1], gd[blk]);       \
+            s[blk] = m16_mma(qa[0], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][0], gd[blk]);       \
+        }                                                                                                    \
+    }
     K16_LOAD(0)
     K16_STORE(lds)
+    K16_LOAD(min(32, last))
+    K16_STORE(lds + BUFB)
+    __syncthreads();
+    M16_LAG_IF(M16_UPPER_HALF)
+    f32x4 s[2], gd[2];
+    K16_PHASE1(lds)
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* cur = lds + (t & 1) * BUFB;
+    for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
+        const unsigned char* cur = lds + slot * BUFB;
         const int t0 = t * 32;
+        // ---- V(t) ----
         const float usq = p.q_us[qbo + t], usd = p.do_us[qbo + t];
-        const float cs = c2 * usq, cg = usv * usd;
-        K16_LOAD(min(t0 + 32, ntiles * 32 - 32))
-        f32x4 s[2], gd[2];
-        s[0] = f32x4{0.f, 0.f, 0.f, 0.f}; s[1] = s[0]; gd[0] = s[0]; gd[1] = s[0];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int oa = ks ? offA1 : offA0;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                u32x4 qa[2], da[2];
-                M16_AFRAG(qa, cur, oa, blk)
-                M16_AFRAG(da, cur + M16_OPB, oa, blk)
-                s[blk] = m16_mma(qa[1], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[1], vf[ks][0], gd[blk]);
-                s[blk] = m16_mma(qa[0], kf[ks][1], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][1], gd[blk]);
-                s[blk] = m16_mma(qa[0], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][0], gd[blk]);
-            }
-        }
+        const float cs = c2 * usq, cgk = usv * usd * p.inv_keep;
+        K16_LOAD(min(t0 + 64, last))
         const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
         f32x4 lse2[2], dl[2];
         lse2[0] = *reinterpret_cast<const f32x4*>(st + 4 * g); lse2[1] = *reinterpret_cast<const f32x4*>(st + 16 + 4 * g);
@@ -427,20 +499,30 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = fl_exp2(s[blk][r] * cs + kbias - lse2[blk][r]);
-                pd[blk][r] = M16_K(blk, r, pr);                                   // (x 1/keep at the end, on gV)
-                gs[blk][r] = pr * (M16_M(blk, r, gd[blk][r] * cg) - dl[blk][r]);
+                const float pr = fl_exp2(s[blk][r] * cs + (kbias - lse2[blk][r]));
+                pd[blk][r] = M16_PM(blk, r, pr);                                  // (x 1/keep at the end, on gV)
+                gs[blk][r] = pd[blk][r] * (gd[blk][r] * cgk) - pr * dl[blk][r];   // gs = P o (M o gd - t)
             }
-        u32x4 bf[2];
-        M16_FIT_SPLIT_BOUNDED(bf, pd, 1.f, usd, fv, gv)
-        m16_stage2(gv, cur + M16_OPB, offT, bf);   // gV^T[d, key] += dO^T[d, query] Pd[query, key]
-        M16_FIT_SPLIT(bf, gs, usq, fk, gk)
-        m16_stage2(gk, cur, offT, bf);             // gK^T[d, key] += Q^T[d, query] gs[query, key]
-        K16_STORE(lds + ((t + 1) & 1) * BUFB)
+        u32x4 bfv[2], bfk[2];
+        M16_FIT_SPLIT_BOUNDED(bfv, pd, 1.f, usd, fv, gv)
+        M16_FIT_SPLIT(bfk, gs, usq, fk, gk)
+        K16_STORE(lds + ((slot + 2) & 3) * BUFB)
+        __syncthreads();
+        // ---- M(t + 1) ----
+        {
+            M16Tr ta, tb;
+            m16_stage2_load(ta, cur + M16_OPB, offT);
+            m16_stage2_load(tb, cur, offT);
+            m16_stage2_mma(gv, ta, bfv);   // gV^T[d, key] += dO^T[d, query] Pd[query, key]
+            m16_stage2_mma(gk, tb, bfk);   // gK^T[d, key] += Q^T[d, query] gs[query, key]
+        }
+        if (t + 1 < ntiles) { K16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         __syncthreads();
     }
+    M16_LAG_IF(!M16_UPPER_HALF)
 #undef K16_LOAD
 #undef K16_STORE
+#undef K16_PHASE1
     if (key < p.S) {
         float* dk = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * 64 + 4 * g;
         float* dv = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * 64 + 4 * g;
@@ -453,36 +535,27 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
 // ============================================================================================================
 // double backward (algebra in flash.hip): (1) row statistics u, w; (2) dq, ddO (query-owning); (3) dk, dv (key-owning)
 // ============================================================================================================
-template <bool DROP, bool STATS>
-__global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
-    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
-    constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
-    M16_LANE_GEOMETRY
-    M16_STAGE_GEOMETRY
-    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
-    const int q0 = blockIdx.x * 128 + wave * 16, q = q0 + n;
-    const int ntiles = (p.S + 31) / 32;
-    const int64_t kro = (int64_t)bh * p.Sp * 64, kbo = (int64_t)bh * (p.Sp / 32);
-    const float* bias = p.bias + (int64_t)b * p.Sp;
-    u32x4 qf[2][2], hqf[2][2], df[2][2];
-    M16_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
-    M16_BFRAGS(hqf, p.hq_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
-    M16_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)
-    const int64_t qb = (int64_t)bh * (p.Lp / 32) + q0 / 32;
-    const float usq = p.q_us[qb], usd = p.do_us[qb], ushq = p.hq_us[qb];
-    const int64_t so = (int64_t)bh * p.Lp + q;
-    const float lse2 = p.lse[so] * FL_LOG2E, dl = p.delta[so];
-    float uu = 0.f, ww = 0.f, aa = 0.f, bq = 0.f;
-    if (!STATS) { uu = p.u[so]; ww = p.w[so]; }
-    const unsigned rid = (unsigned)(bh * p.L + q);
-    f32x4 dq[4], ddo[4];
-    M16_ZERO4(dq)
-    M16_ZERO4(ddo)
-    float fdq = FL_F0, fddo = FL_F0;
-
-    uint4 sk, shk, sv, shv;
-    const int64_t st_src = kro + st_pl * p.k_plane + st_idx * 8;
+// common to (1) and (2): the query-owning setup and the first stage of a key tile
+#define B16_SETUP                                                                                            \
+    M16_LANE_GEOMETRY                                                                                        \
+    M16_STAGE_GEOMETRY                                                                                       \
+    const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;                                                   \
+    const int q0 = blockIdx.x * 128 + wave * 16, q = q0 + n;                                                 \
+    const int ntiles = (p.S + 31) / 32, last = ntiles * 32 - 32;                                             \
+    const int64_t kro = (int64_t)bh * p.Sp * 64, kbo = (int64_t)bh * (p.Sp / 32);                            \
+    const float* bias = p.bias + (int64_t)b * p.Sp;                                                          \
+    u32x4 qf[2][2], hqf[2][2], df[2][2];                                                                     \
+    M16_BFRAGS(qf, p.q_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)                                \
+    M16_BFRAGS(hqf, p.hq_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)                              \
+    M16_BFRAGS(df, p.do_row, ((int64_t)bh * p.Lp + q) * 64 + 8 * g, p.q_plane)                               \
+    const int64_t qb = (int64_t)bh * (p.Lp / 32) + q0 / 32;                                                  \
+    const float usq = p.q_us[qb], usd = p.do_us[qb], ushq = p.hq_us[qb];                                     \
+    const int64_t so = (int64_t)bh * p.Lp + q;                                                               \
+    const float lse2 = p.lse[so] * FL_LOG2E, dl = p.delta[so];                                               \
+    const unsigned rid = (unsigned)(bh * p.L + q);                                                           \
+    (void)b; (void)h; (void)last;                                                                            \
+    uint4 sk, shk, sv, shv;                                                                                  \
+    const int64_t st_src = kro + st_pl * p.k_plane + st_off;
 #define B16_LOAD(T0)                                                                                         \
     sk = *reinterpret_cast<const uint4*>(p.k_row + st_src + (int64_t)(T0) * 64);                             \
     shk = *reinterpret_cast<const uint4*>(p.hk_row + st_src + (int64_t)(T0) * 64);                           \
@@ -491,113 +564,151 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
 #define B16_STORE(BUF)                                                                                       \
     *reinterpret_cast<uint4*>((BUF) + st_dst) = sk; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = shk; \
     *reinterpret_cast<uint4*>((BUF) + 2 * M16_OPB + st_dst) = sv; *reinterpret_cast<uint4*>((BUF) + 3 * M16_OPB + st_dst) = shv;
-    B16_LOAD(0)
-    B16_STORE(lds)
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* cur = lds + (t & 1) * BUFB;
-        const int t0 = t * 32;
-        f32x4 kb[2];
-        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
-        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
-        const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t];
-        const float cs = p.scale_log2e * usq * usk, cg = usd * usv, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk, ch = usd * ushv;
-        B16_LOAD(min(t0 + 32, ntiles * 32 - 32))
-        // ---- the [key, query] tiles: S, gd, G (two chains: hq.k and q.hk carry different block scales), HD ----
-        f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int oa = ks ? offA1 : offA0;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                u32x4 kf[2], hkf[2], vf[2], hvf[2];
-                M16_AFRAG(kf, cur, oa, blk)
-                M16_AFRAG(hkf, cur + M16_OPB, oa, blk)
-                M16_AFRAG(vf, cur + 2 * M16_OPB, oa, blk)
-                M16_AFRAG(hvf, cur + 3 * M16_OPB, oa, blk)
+// the [key, query] tiles: S, gd, G (two chains: hq.k and q.hk carry different block scales), HD
+#define B16_PHASE1(BUF)                                                                                      \
+    _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; } \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+        const int oa = ks ? offA1 : offA0;                                                                   \
+        _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) {                                                \
+            u32x4 kf[2], hkf[2], vf[2], hvf[2];                                                              \
+            M16_AFRAG(kf, (BUF), oa, blk)                                                                    \
+            M16_AFRAG(hkf, (BUF) + M16_OPB, oa, blk)                                                         \
+            M16_AFRAG(vf, (BUF) + 2 * M16_OPB, oa, blk)                                                      \
+            M16_AFRAG(hvf, (BUF) + 3 * M16_OPB, oa, blk)                                                     \
+            B16_TERM(1, 0) B16_TERM(0, 1) B16_TERM(0, 0)                                                     \
+        }                                                                                                    \
+    }
 #define B16_TERM(I, J)                                                                                       \
     s[blk] = m16_mma(kf[I], qf[ks][J], s[blk]); gd[blk] = m16_mma(vf[I], df[ks][J], gd[blk]);               \
     g1[blk] = m16_mma(kf[I], hqf[ks][J], g1[blk]); hd_[blk] = m16_mma(hvf[I], df[ks][J], hd_[blk]);         \
     g2[blk] = m16_mma(hkf[I], qf[ks][J], g2[blk]);
-                B16_TERM(1, 0)
-                B16_TERM(0, 1)
-                B16_TERM(0, 0)
-#undef B16_TERM
-            }
-        }
-        bool kp[2][4];
-        if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
-        f32x4 pr[2];
+// element-wise part common to (1) and (2): pr = P, pm = keep ? P : 0, g1 = G, gd = gd cg / keep, hd_ = HD ch / keep
+// (P o gy = pm gd, P o M o HD = pm hd_)
+#define B16_ELEMENTWISE                                                                                      \
+    f32x4 kb[2];                                                                                             \
+    kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);                                              \
+    kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);                                         \
+    const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t]; \
+    const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk,     \
+                c3 = p.scale * usq * ushk, chk = usd * ushv * p.inv_keep;                                    \
+    bool kp[2][4];                                                                                           \
+    if (DROP) { M16_MASK_KEYS(kp, rid, t0) }                                                                 \
+    f32x4 pr[2], pm[2];                                                                                      \
+    _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) _Pragma("unroll") for (int r = 0; r < 4; ++r) {       \
+        pr[blk][r] = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));                                          \
+        pm[blk][r] = M16_PM(blk, r, pr[blk][r]);                                                             \
+        g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;                                                      \
+        gd[blk][r] *= cgk;                                                                                   \
+        hd_[blk][r] *= chk;                                                                                  \
+    }
+
+// (1) row statistics: two workgroups per CU, double-buffered, one barrier per tile
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_bb_stats_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    B16_SETUP
+    float uu = 0.f, aa = 0.f, bq = 0.f;
+    B16_LOAD(0)
+    B16_STORE(lds)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* cur = lds + (t & 1) * BUFB;
+        const int t0 = t * 32;
+        B16_LOAD(min(t0 + 32, last))
+        f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
+        B16_PHASE1(cur)
+        B16_ELEMENTWISE
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pr[blk][r] = fl_exp2(s[blk][r] * cs + kb[blk][r] - lse2);
-                g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;   // G
-                gd[blk][r] = M16_M(blk, r, gd[blk][r] * cg);      // gy = M o gd
-                hd_[blk][r] = M16_M(blk, r, hd_[blk][r] * ch);    // M o HD
+                uu += pr[blk][r] * g1[blk][r];
+                aa += pm[blk][r] * g1[blk][r] * gd[blk][r];
+                bq += pm[blk][r] * hd_[blk][r];
             }
-        if (STATS) {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pg = pr[blk][r] * g1[blk][r];
-                    uu += pg;
-                    aa += pg * gd[blk][r];
-                    bq += pr[blk][r] * hd_[blk][r];
-                }
-        } else {
-            f32x4 x[2];
-            u32x4 bf[2];
-            // gs = P (gy - t)                                   dq += hk^T gs
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[blk][r] = pr[blk][r] * (gd[blk][r] - dl);
-            M16_FIT_SPLIT(bf, x, ushk, fdq, dq)
-            m16_stage2(dq, cur + M16_OPB, offT, bf);
-            // HS = P (G (gy - t) - gy u + M HD - w)             dq += k^T HS
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    x[blk][r] = pr[blk][r] * (g1[blk][r] * (gd[blk][r] - dl) - gd[blk][r] * uu + hd_[blk][r] - ww);
-            M16_FIT_SPLIT(bf, x, usk, fdq, dq)
-            m16_stage2(dq, cur, offT, bf);
-            // Pd = M P                                          ddO += hv^T Pd
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r]);
-            M16_FIT_SPLIT_BOUNDED(bf, x, p.inv_keep, ushv, fddo, ddo)
-            m16_stage2(ddo, cur + 3 * M16_OPB, offT, bf);
-            // HgD = M P (G - u)                                 ddO += v^T HgD
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r] * (g1[blk][r] - uu));
-            M16_FIT_SPLIT(bf, x, usv, fddo, ddo)
-            m16_stage2(ddo, cur + 2 * M16_OPB, offT, bf);
-        }
         B16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
     }
-#undef B16_LOAD
-#undef B16_STORE
-    if (STATS) {
-        uu += __shfl_xor(uu, 16, 64); uu += __shfl_xor(uu, 32, 64);
-        aa += __shfl_xor(aa, 16, 64); aa += __shfl_xor(aa, 32, 64);
-        bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
-        if (g == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
-            p.u[so] = uu;
-            p.w[so] = aa - 2.f * dl * uu + bq;
-        }
-        return;
+    uu += __shfl_xor(uu, 16, 64); uu += __shfl_xor(uu, 32, 64);
+    aa += __shfl_xor(aa, 16, 64); aa += __shfl_xor(aa, 32, 64);
+    bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
+    if (g == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
+        p.u[so] = uu;
+        p.w[so] = aa - 2.f * dl * uu + bq;
     }
+}
+
+// (2) dq (o1), ddO (o4): split-phase
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
+    if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
+    constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
+    __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
+    B16_SETUP
+    const float uu = p.u[so], ww = p.w[so];
+    f32x4 dq[4], ddo[4];
+    M16_ZERO4(dq)
+    M16_ZERO4(ddo)
+    float fdq = FL_F0, fddo = FL_F0;
+    B16_LOAD(0)
+    B16_STORE(lds)
+    B16_LOAD(min(32, last))
+    B16_STORE(lds + BUFB)
+    __syncthreads();
+    M16_LAG_IF(M16_UPPER_HALF)
+    f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
+    B16_PHASE1(lds)
+    __syncthreads();
+
+    for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
+        const unsigned char* cur = lds + slot * BUFB;
+        const int t0 = t * 32;
+        M16_STAMP(0)
+        // ---- V(t) ----
+        B16_LOAD(min(t0 + 64, last))
+        B16_ELEMENTWISE
+        f32x4 x1[2], x2[2], x4[2];
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x1[blk][r] = pm[blk][r] * gd[blk][r] - pr[blk][r] * dl;                                     // gs = P (gy - t)
+                x2[blk][r] = g1[blk][r] * x1[blk][r] + pm[blk][r] * (hd_[blk][r] - gd[blk][r] * uu) - pr[blk][r] * ww;   // HS
+                x4[blk][r] = pm[blk][r] * (g1[blk][r] - uu);                                                 // HgD keep (the 1 / keep rides on its scale)
+            }
+        // dq += hk^T gs + k^T HS: one range check for both;  ddO += hv^T Pd + v^T HgD likewise (Pd = pm / keep <= 1 / keep)
+        u32x4 bf1[2], bf2[2], bf3[2], bf4[2];
+        m16_fit<true>(fmaxf(m16_absmax(x1) * ushk, m16_absmax(x2) * usk), fdq, dq);
+        m16_split(bf1, x1, ushk * fdq);
+        m16_split(bf2, x2, usk * fdq);
+        const float usvk = usv * p.inv_keep, ushvk = ushv * p.inv_keep;
+        m16_fit<true>(fmaxf(ushvk, m16_absmax(x4) * usvk), fddo, ddo);
+        m16_split(bf3, pm, ushvk * fddo);
+        m16_split(bf4, x4, usvk * fddo);
+        B16_STORE(lds + ((slot + 2) & 3) * BUFB)
+        M16_STAMP(1)
+        __syncthreads();
+        M16_STAMP(2)
+        // ---- M(t + 1) ----
+        {
+            M16Tr ta, tb;   // (two sets: the next operand's transposed fragments fly during a product)
+            m16_stage2_load(ta, cur + M16_OPB, offT);
+            m16_stage2_load(tb, cur + 3 * M16_OPB, offT);
+            m16_stage2_mma(dq, ta, bf1);
+            m16_stage2_load(ta, cur, offT);
+            m16_stage2_mma(ddo, tb, bf3);
+            m16_stage2_load(tb, cur + 2 * M16_OPB, offT);
+            m16_stage2_mma(dq, ta, bf2);
+            m16_stage2_mma(ddo, tb, bf4);
+        }
+        if (t + 1 < ntiles) { B16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
+        M16_STAMP(3)
+        __syncthreads();
+        M16_STAMP(4)
+    }
+    M16_LAG_IF(!M16_UPPER_HALF)
     if (q < p.L) {
         float* d1 = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * 64 + 4 * g;
         float* d4 = p.o4 + ((int64_t)b * p.L + q) * p.ld4 + p.off4 + h * 64 + 4 * g;
@@ -606,17 +717,24 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
         M16_STORE_ROW(ddo, d4, m4)
     }
 }
+#undef B16_SETUP
+#undef B16_LOAD
+#undef B16_STORE
+#undef B16_PHASE1
+#undef B16_TERM
+#undef B16_ELEMENTWISE
 
+// (3) dk (o2), dv (o3): split-phase, key-owning
 template <bool DROP>
 __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 3 * M16_OPB, BUFB = OFF_ST + 512;   // q, hq, dO rows + lse, delta, u, w [32] each
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
     M16_LANE_GEOMETRY
     M16_STAGE_GEOMETRY
     const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
     const int k0 = blockIdx.x * 128 + wave * 16, key = k0 + n;
-    const int ntiles = (p.L + 31) / 32;
+    const int ntiles = (p.L + 31) / 32, last = ntiles * 32 - 32;
     const int64_t qro = (int64_t)bh * p.Lp * 64, sto = (int64_t)bh * p.Lp, qbo = (int64_t)bh * (p.Lp / 32);
     u32x4 kf[2][2], vf[2][2], hkf[2][2], hvf[2][2];
     M16_BFRAGS(kf, p.k_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
@@ -632,8 +750,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     float fdk = FL_F0, fdv = FL_F0;
 
     uint4 sq, shq, sd;
-    float sst = 0.f;   // threads 0..127 carry lse (base 2) | delta | u | w of the next tile
-    const int64_t st_src = qro + st_pl * p.q_plane + st_idx * 8;
+    float sst = 0.f;   // threads 0..127 carry lse | delta | u | w of the staged tile
+    const int64_t st_src = qro + st_pl * p.q_plane + st_off;
 #define C16_LOAD(T0)                                                                                         \
     sq = *reinterpret_cast<const uint4*>(p.q_row + st_src + (int64_t)(T0) * 64);                             \
     shq = *reinterpret_cast<const uint4*>(p.hq_row + st_src + (int64_t)(T0) * 64);                           \
@@ -641,44 +759,45 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     if (tid < 128) {                                                                                         \
         const float* sp_ = tid < 32 ? p.lse : tid < 64 ? p.delta : tid < 96 ? p.u : p.w;                     \
         sst = sp_[sto + (T0) + (tid & 31)];                                                                  \
-        if (tid < 32) sst *= FL_LOG2E;                                                                       \
     }
 #define C16_STORE(BUF)                                                                                       \
     *reinterpret_cast<uint4*>((BUF) + st_dst) = sq; *reinterpret_cast<uint4*>((BUF) + M16_OPB + st_dst) = shq; \
     *reinterpret_cast<uint4*>((BUF) + 2 * M16_OPB + st_dst) = sd;                                            \
-    if (tid < 128) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = sst;
-    C16_LOAD(0)
-    C16_STORE(lds)
-    __syncthreads();
-
-    for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* cur = lds + (t & 1) * BUFB;
-        const int t0 = t * 32;
-        const float usq = p.q_us[qbo + t], ushq = p.hq_us[qbo + t], usd = p.do_us[qbo + t];
-        const float cs = p.scale_log2e * usq * usk, cg = usd * usv, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk, ch = usd * ushv;
-        C16_LOAD(min(t0 + 32, ntiles * 32 - 32))
-        f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int oa = ks ? offA1 : offA0;
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                u32x4 qa[2], hqa[2], da[2];
-                M16_AFRAG(qa, cur, oa, blk)
-                M16_AFRAG(hqa, cur + M16_OPB, oa, blk)
-                M16_AFRAG(da, cur + 2 * M16_OPB, oa, blk)
+    if (tid < 128) reinterpret_cast<float*>((BUF) + OFF_ST)[tid] = tid < 32 ? sst * FL_LOG2E : sst;
 #define C16_TERM(I, J)                                                                                       \
     s[blk] = m16_mma(qa[I], kf[ks][J], s[blk]); gd[blk] = m16_mma(da[I], vf[ks][J], gd[blk]);               \
     g1[blk] = m16_mma(hqa[I], kf[ks][J], g1[blk]); hd_[blk] = m16_mma(da[I], hvf[ks][J], hd_[blk]);         \
     g2[blk] = m16_mma(qa[I], hkf[ks][J], g2[blk]);
-                C16_TERM(1, 0)
-                C16_TERM(0, 1)
-                C16_TERM(0, 0)
-#undef C16_TERM
-            }
-        }
+#define C16_PHASE1(BUF)                                                                                      \
+    _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) { s[blk] = f32x4{0.f, 0.f, 0.f, 0.f}; gd[blk] = s[blk]; g1[blk] = s[blk]; g2[blk] = s[blk]; hd_[blk] = s[blk]; } \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                       \
+        const int oa = ks ? offA1 : offA0;                                                                   \
+        _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) {                                                \
+            u32x4 qa[2], hqa[2], da[2];                                                                      \
+            M16_AFRAG(qa, (BUF), oa, blk)                                                                    \
+            M16_AFRAG(hqa, (BUF) + M16_OPB, oa, blk)                                                         \
+            M16_AFRAG(da, (BUF) + 2 * M16_OPB, oa, blk)                                                      \
+            C16_TERM(1, 0) C16_TERM(0, 1) C16_TERM(0, 0)                                                     \
+        }                                                                                                    \
+    }
+    C16_LOAD(0)
+    C16_STORE(lds)
+    C16_LOAD(min(32, last))
+    C16_STORE(lds + BUFB)
+    __syncthreads();
+    M16_LAG_IF(M16_UPPER_HALF)
+    f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
+    C16_PHASE1(lds)
+    __syncthreads();
+
+    for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
+        const unsigned char* cur = lds + slot * BUFB;
+        const int t0 = t * 32;
+        // ---- V(t) ----
+        const float usq = p.q_us[qbo + t], ushq = p.hq_us[qbo + t], usd = p.do_us[qbo + t];
+        const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk,
+                    chk = usd * ushv * p.inv_keep;
+        C16_LOAD(min(t0 + 64, last))
         // statistics of this lane's 2 x 4 queries (rows 16 blk + 4 g + r of the tile)
         const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
         f32x4 lse2[2], dl[2], uu[2], ww[2];
@@ -691,45 +810,47 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
         }
         bool kp[2][4];
         if (DROP) { M16_MASK_QUERIES(kp, key, t0) }
-        f32x4 pr[2];
+        // pr = P, pm = keep ? P : 0, g1 = G, gd = gd cg / keep, hd_ = HD ch / keep   (P o gy = pm gd, P o M o HD = pm hd_)
+        f32x4 x1[2], x2[2], x3[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pr[blk][r] = fl_exp2(s[blk][r] * cs + kbias - lse2[blk][r]);
-                g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;   // G
-                gd[blk][r] = M16_M(blk, r, gd[blk][r] * cg);      // gy = M o gd
-                hd_[blk][r] = M16_M(blk, r, hd_[blk][r] * ch);    // M o HD
+                const float pr = fl_exp2(s[blk][r] * cs + (kbias - lse2[blk][r]));
+                const float pm = M16_PM(blk, r, pr);
+                const float G = g1[blk][r] * c1 + g2[blk][r] * c3, gdk = gd[blk][r] * cgk, hdk = hd_[blk][r] * chk;
+                x1[blk][r] = pm * gdk - pr * dl[blk][r];                                              // gs
+                x2[blk][r] = G * x1[blk][r] + pm * (hdk - gdk * uu[blk][r]) - pr * ww[blk][r];        // HS
+                x3[blk][r] = pm * (G - uu[blk][r]);                                                    // HgD keep
             }
-        f32x4 x[2];
-        u32x4 bf[2];
-        // gs                                                     dk += hq^T gs
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[blk][r] = pr[blk][r] * (gd[blk][r] - dl[blk][r]);
-        M16_FIT_SPLIT(bf, x, ushq, fdk, dk)
-        m16_stage2(dk, cur + M16_OPB, offT, bf);
-        // HS                                                     dk += q^T HS
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                x[blk][r] = pr[blk][r] * (g1[blk][r] * (gd[blk][r] - dl[blk][r]) - gd[blk][r] * uu[blk][r] + hd_[blk][r] - ww[blk][r]);
-        M16_FIT_SPLIT(bf, x, usq, fdk, dk)
-        m16_stage2(dk, cur, offT, bf);
-        // HgD                                                    dv += dO^T HgD
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[blk][r] = M16_M(blk, r, pr[blk][r] * (g1[blk][r] - uu[blk][r]));
-        M16_FIT_SPLIT(bf, x, usd, fdv, dv)
-        m16_stage2(dv, cur + 2 * M16_OPB, offT, bf);
-        C16_STORE(lds + ((t + 1) & 1) * BUFB)
+        // dk += hq^T gs + q^T HS: one range check for both;  dv += dO^T HgD
+        u32x4 bf1[2], bf2[2], bf3[2];
+        m16_fit<true>(fmaxf(m16_absmax(x1) * ushq, m16_absmax(x2) * usq), fdk, dk);
+        m16_split(bf1, x1, ushq * fdk);
+        m16_split(bf2, x2, usq * fdk);
+        const float usdk = usd * p.inv_keep;
+        m16_fit<true>(m16_absmax(x3) * usdk, fdv, dv);
+        m16_split(bf3, x3, usdk * fdv);
+        C16_STORE(lds + ((slot + 2) & 3) * BUFB)
+        __syncthreads();
+        // ---- M(t + 1) ----
+        {
+            M16Tr ta, tb;   // (two sets: the next operand's transposed fragments fly during a product)
+            m16_stage2_load(ta, cur + M16_OPB, offT);
+            m16_stage2_load(tb, cur + 2 * M16_OPB, offT);
+            m16_stage2_mma(dk, ta, bf1);
+            m16_stage2_load(ta, cur, offT);
+            m16_stage2_mma(dv, tb, bf3);
+            m16_stage2_mma(dk, ta, bf2);
+        }
+        if (t + 1 < ntiles) { C16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         __syncthreads();
     }
+    M16_LAG_IF(!M16_UPPER_HALF)
 #undef C16_LOAD
 #undef C16_STORE
+#undef C16_TERM
+#undef C16_PHASE1
     if (key < p.S) {
         float* d2 = p.o2 + ((int64_t)b * p.S + key) * p.ld2 + p.off2 + h * 64 + 4 * g;
         float* d3 = p.o3 + ((int64_t)b * p.S + key) * p.ld3 + p.off3 + h * 64 + 4 * g;
@@ -752,6 +873,6 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
 void fl16_launch_fwd(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_fwd_kernel, grid) }
 void fl16_launch_bwd_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_q_kernel, grid) }
 void fl16_launch_bwd_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_kv_kernel, grid) }
-void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH2(flash16_bb_q_kernel, true, grid) }
-void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH2(flash16_bb_q_kernel, false, grid) }
+void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_stats_kernel, grid) }
+void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_q_kernel, grid) }
 void fl16_launch_bb_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_kv_kernel, grid) }

@@ -55,5 +55,6 @@ def run(name, p=0.1):
     print(line, flush=True)
 
 
+import os
 for name in (sys.argv[1:] or ["fusion", "encoder", "cross", "self50"]):
-    run(name)
+    run(name, float(os.environ.get("IX_BENCH_PDROP", "0.1")))
