@@ -48,7 +48,7 @@ CONFIGS = {   # --config -> (reference yaml, MODEL.TYPE, oracle fusion style)
 }
 
 
-def model_cfg(size, queries, chunk=8, model_type="interactron", step_graph=None, compute_dtype="f32"):
+def model_cfg(size, queries, chunk=8, model_type="interactron", step_graph=None, compute_dtype="f32", inner_steps=1):
     # stride-16 backbone: h = w = ceil(size / 16) after the stem/maxpool/strided stages (19 at 300, 50 at 800)
     h = size
     for k, s, p in ((7, 2, 3), (3, 2, 1), (3, 2, 1), (3, 2, 1)):
@@ -58,7 +58,8 @@ def model_cfg(size, queries, chunk=8, model_type="interactron", step_graph=None,
                 SET_COST_GIOU=2.0, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=5 * (tokens + queries) + 5,
                 IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
                 ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3, NUM_QUERIES=queries, EPISODE_CHUNK=chunk,
-                COMPUTE_DTYPE=compute_dtype, **({} if step_graph in (None, "auto") else {"STEP_GRAPH": step_graph})), tokens
+                COMPUTE_DTYPE=compute_dtype, INNER_STEPS=inner_steps,
+                **({} if step_graph in (None, "auto") else {"STEP_GRAPH": step_graph})), tokens
 
 
 def to_gpu(data, dev):
@@ -219,7 +220,7 @@ def launch_ranks(args):
         sys.exit(1)
 
 
-def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline, tag):
+def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline, tag, inner_steps=None):
     """Build the model of `--config` at frame size `size`, run `warmup` + `steps` steps of `--mode`, return the metrics
     of the timed steps (max over ranks) and, from one extra profiled step, the per-kernel roofline numbers."""
     import torch
@@ -229,7 +230,8 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     from interactron_amd.trainer import FlatOuterStep
     lib, dev, rank, world, local = ctx["lib"], ctx["dev"], ctx["rank"], ctx["world"], ctx["local"]
 
-    cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1], args.step_graph, args.compute_dtype)
+    cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1], args.step_graph, args.compute_dtype,
+                            inner_steps or args.inner_steps)
     model = build_model(Config(**cfg))
     if hasattr(model, "fusion"):
         load_procedural(model.fusion, "fusion.")
@@ -488,6 +490,10 @@ def main():
                     help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the single-pass "
                          "16-bit mode (BASELINE.json configs[1]: --config multi_frame_baseline --compute-dtype bf16) -- its own line, "
                          "`dtype` says so, never the headline")
+    ap.add_argument("--inner-steps", type=int, default=1,
+                    help="MODEL.INNER_STEPS: learned-loss SGD steps per episode (reference: 1; BASELINE.json's '5-step adapt loop' = 5, "
+                         "a stress setting -- the default run reports it as the `inner5` sub-line)")
+    ap.add_argument("--inner5-episodes", type=int, default=4, help="episodes per GPU of the `inner5` sub-measurement (0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -527,7 +533,7 @@ def main():
         args.chunk = min(args.chunk, args.episodes)
     head = run_workload(args, args.size, args.episodes, args.chunk, args.steps, args.warmup, ctx, not args.no_roofline, "bench")
     headline_cfg = (args.size == 300 and args.mode == "train" and args.config == "interactron" and not strong
-                    and args.compute_dtype == "f32")
+                    and args.compute_dtype == "f32" and args.inner_steps == 1)
     # The per-GPU share of the reference's global batch of 16 on 8 GPUs (engine/interactron_trainer.py:78-84 + SURVEY 8e): what
     # a rank of the strong-scaling run executes per step.  At N = 1 as `small_e`; at N > 1 the same global batch as `strong`.
     small = strong_run = None
@@ -535,6 +541,11 @@ def main():
         small = run_workload(args, 300, args.small_e, args.small_e, 10, 3, ctx, False, "bench")
     if headline_cfg and world > 1 and 16 % world == 0:
         strong_run = run_workload(args, 300, 16 // world, 16 // world, 10, 3, ctx, False, "bench")
+    # BASELINE.json's "5-step adapt loop": the same step with MODEL.INNER_STEPS = 5 (five learned-loss gradients with the
+    # second-order graph through all of them; the fast weights never leave the device) -- a stress setting, never the headline
+    inner5 = None
+    if headline_cfg and world == 1 and args.inner5_episodes > 0:
+        inner5 = run_workload(args, 300, args.inner5_episodes, args.inner5_episodes, 3, 1, ctx, False, "bench", inner_steps=5)
     # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755),
     # measured in the same process after the headline: same step definition, fewer episodes per pass, its own warm-up.
     n800 = r8 = None
@@ -574,7 +585,7 @@ def main():
                                                                  "predict-batched": "predict() on all episodes of the batch at once",
                                                                  "interactive": "interactive episode (4 x get_next_action + predict)"}
                                        [args.mode], args.episodes, args.size, args.size)),
-                       "mode": args.mode, "episodes_per_gpu": args.episodes, "frame_size": args.size,
+                       "mode": args.mode, "episodes_per_gpu": args.episodes, "frame_size": args.size, "inner_steps": args.inner_steps,
                        "attention": hipops.ATTENTION_IMPL, "attention_dtype": hipops.ATTENTION_DTYPE,
                        "peak_memory_GB": head.get("peak_memory_GB"), "parallelism": "dp%d" % world,
                        "global_batch": args.global_batch if strong else args.episodes * world,
@@ -592,6 +603,11 @@ def main():
             "north_star": ({"value": n800["value"], "unit": "frames/s", "workload": n800["workload"], "ms_per_step": n800["ms_per_step"],
                             "steps": n800["steps"]} if n800 is not None and "error" not in n800 else None),
             "small_e": None, "strong": None,
+            "inner5": ({"workload": "%d episodes/GPU x 5 frames x 3x300x300, MODEL.INNER_STEPS = 5 (BASELINE.json north_star's 5-step adapt loop; "
+                                    "the reference and the headline take 1 step)" % args.inner5_episodes, "inner_steps": 5,
+                        "episodes_per_gpu": args.inner5_episodes, "steps": 3, "warmup": 1, "ms_per_step": inner5["ms_per_step"],
+                        "value": inner5["frames_per_s"], "unit": "frames/s", "peak_memory_GB": inner5.get("peak_memory_GB"),
+                        "step_graphs": inner5["step_graphs"]} if inner5 is not None else None),
             "hbm_kernels": hbm_kernels(torch, hipops, dev, min(args.chunk, args.episodes) * cfg["BLOCK_SIZE"],
                                        (min(args.chunk, args.episodes), cfg["BLOCK_SIZE"])) if not args.no_roofline else None,
             "rccl_ranks": world if world > 1 and head["allreduce"] and head["allreduce"]["backend"] == "rccl" else 0,

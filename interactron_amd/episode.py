@@ -210,14 +210,33 @@ class _Adaptive(_EpisodeModel):
             return torch.autograd.grad(learned, dtheta, create_graph=create_graph, retain_graph=create_graph,
                                        allow_unused=True)
 
+    def _inner_steps(self):
+        """MODEL.INNER_STEPS (default 1 = the reference, models/interactron.py:94-102): how often the learned-loss step
+        theta <- theta - clip(lr d||fusion(detector(frames | theta)).loss|| / d theta) is repeated before the adapted detector
+        is used -- BASELINE.json's "5-step adapt loop", SURVEY section 0 row 2.  The second-order graph runs through all of
+        them; the fast weights are device tensors from the first step to the last (one fused clipped-SGD launch per step,
+        csrc/meta.hip)."""
+        k = int(getattr(self.config, "INNER_STEPS", 1))
+        assert k >= 1, "MODEL.INNER_STEPS must be >= 1"
+        return k
+
     def _adapt(self, img, mask, create_graph):
-        dtheta = [p.detach().requires_grad_(True) for p in self._theta]
-        set_parameters(self.detector, dtheta)
-        pre = _lift(self.detector(NestedTensor(img, mask)))
-        fusion_out = self.fusion(pre)
-        learned_loss = ops.l2_norm(fusion_out["loss"])
-        grads = self._inner_grad(learned_loss, dtheta, create_graph)
-        return dtheta, grads, fusion_out
+        """-> (dtheta, [gradients of every inner step], fusion output of the first pass, adapted weights)"""
+        dtheta = cur = [p.detach().requires_grad_(True) for p in self._theta]
+        first, steps = None, []
+        nt = NestedTensor(img, mask)
+        for _ in range(self._inner_steps()):
+            set_parameters(self.detector, cur)
+            pre = _lift(self.detector(nt))
+            fusion_out = self.fusion(pre)
+            first = first or fusion_out
+            learned_loss = ops.l2_norm(fusion_out["loss"])
+            grads = self._inner_grad(learned_loss, cur, create_graph)
+            steps.append(grads)
+            cur = sgd_step(cur, grads, self.config.ADAPTIVE_LR)
+            if not create_graph:   # (eval: nothing differentiates through the step)
+                cur = [t.detach().requires_grad_(True) for t in cur]
+        return dtheta, steps, first, cur
 
     def predict(self, data):
         b, s, c, w, h = data["frames"].shape
@@ -232,9 +251,9 @@ class _Adaptive(_EpisodeModel):
         self._theta = self._real_parameters()
         try:
             with torch.enable_grad():
-                dtheta, grads, _ = self._adapt(img, mask, create_graph=False)
+                _, _, _, fast = self._adapt(img, mask, create_graph=False)
                 # stays in grad mode: set_parameters only swaps tensors that require grad (reference meta_utils.py:76)
-                set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                set_parameters(self.detector, fast)
             with torch.no_grad():
                 post = self.detector(NestedTensor(img[0:1], mask[0:1]))
         finally:
@@ -255,21 +274,23 @@ class _Adaptive(_EpisodeModel):
                 frames = data["frames"][e0:e0 + E].reshape(E * s, c, w, h)
                 masks = data["masks"][e0:e0 + E].reshape(E * s, w, h)
                 with torch.enable_grad():
-                    dtheta = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
-                    set_parameters(self.detector, dtheta)
+                    cur = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
                     nt = NestedTensor(frames, masks)
                     nt.stem = self.detector.backbone[0].body.frozen_stem(frames)
-                    pre = self.detector(nt)
-                    pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
-                    loss_map = self.fusion(pre)["loss"].reshape(E, -1)
-                    learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
-                    grads = self._inner_grad(learned, dtheta, False)
-                    set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                    for _ in range(self._inner_steps()):
+                        set_parameters(self.detector, cur)
+                        pre = self.detector(nt)
+                        pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
+                        loss_map = self.fusion(pre)["loss"].reshape(E, -1)
+                        learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
+                        grads = self._inner_grad(learned, cur, False)
+                        cur = [t.detach().requires_grad_(True) for t in sgd_step(cur, grads, self.config.ADAPTIVE_LR)]
+                    set_parameters(self.detector, cur)
                 with torch.no_grad():
                     first = NestedTensor(frames[0::s], masks[0::s])
                     first.stem = nt.stem[0::s]
                     outs.append(self.detector(first))
-                del dtheta, grads, pre, loss_map, learned
+                del cur, grads, pre, loss_map, learned
         finally:
             set_parameters(self.detector, theta)
         return {k: torch.cat([o[k] for o in outs], 0).unsqueeze(1) for k in outs[0]}
@@ -293,21 +314,27 @@ class _Adaptive(_EpisodeModel):
     def _seg_a(self, st):
         E, s, theta, lr = st.E, st.s, self._theta, self.config.ADAPTIVE_LR
         # theta_task = clone(theta); dtheta = detach(theta_task)   (reference :86-90), one copy per episode
-        st.dtheta = dtheta = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
-        set_parameters(self.detector, dtheta)
-        # the frozen stem (conv1..layer1) sees the same frames in all three forwards: computed once per chunk
+        st.dtheta = cur = [t.requires_grad_(True) for t in ops.expand_episodes(E, [p.detach() for p in theta])]
+        # the frozen stem (conv1..layer1) sees the same frames in all forwards: computed once per chunk
         st.nt = nt = NestedTensor(st.frames, st.masks)
         nt.stem = self.detector.backbone[0].body.frozen_stem(st.frames)
-        pre = self.detector(nt)
-        st.mark("1 detector fwd (theta)")
-        pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
-        fusion_out = self.fusion(pre)
-        st.mark("2 fusion fwd")
-        loss_map = fusion_out["loss"].reshape(E, -1)
-        learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
-        st.grads = grads = self._inner_grad(learned, dtheta, True)
-        st.mark("3 learned-loss grad (create_graph)")
-        set_parameters(self.detector, sgd_step(dtheta, grads, lr))
+        st.grads, first_out = [], None
+        for _ in range(self._inner_steps()):   # (MODEL.INNER_STEPS, default 1: see _inner_steps)
+            set_parameters(self.detector, cur)
+            pre = self.detector(nt)
+            st.mark("1 detector fwd (theta)")
+            pre = {k: v.reshape((E, s) + tuple(v.shape[1:])) for k, v in pre.items()}
+            fusion_out = self.fusion(pre)
+            first_out = first_out or fusion_out
+            st.mark("2 fusion fwd")
+            loss_map = fusion_out["loss"].reshape(E, -1)
+            learned = ops.rownorm_sum(loss_map)   # = sum_e torch.norm(loss_e): one launch
+            grads = self._inner_grad(learned, cur, True)
+            st.grads.append(grads)
+            st.mark("3 learned-loss grad (create_graph)")
+            cur = sgd_step(cur, grads, lr)
+        fusion_out = first_out
+        set_parameters(self.detector, cur)
         post = self.detector(nt)
         st.mark("4 inner SGD + detector fwd (theta')")
         st.actions_out = fusion_out["actions"].reshape(E * 4, 4)
@@ -329,8 +356,9 @@ class _Adaptive(_EpisodeModel):
         # The first-order branch (reference interactron.py:126-134) depends only on the learned-loss gradient, not on the
         # criterion.  The expansion of theta is differentiable; its backward sums the per-episode gradients into theta.grad.
         E, theta = st.E, self._theta
-        attached = ops.expand_episodes(E, theta)
-        fast1 = sgd_step(attached, [None if g is None else g.detach() for g in st.grads], self.config.ADAPTIVE_LR)
+        fast1 = ops.expand_episodes(E, theta)
+        for grads in st.grads:   # the inner steps again with their gradients as constants, from the attached copy of theta
+            fast1 = sgd_step(fast1, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)
         set_parameters(self.detector, fast1)
         nt1 = NestedTensor(st.frames[st.sel], st.masks[st.sel])
         nt1.stem = st.nt.stem[st.sel]
@@ -378,6 +406,8 @@ class _Adaptive(_EpisodeModel):
         #  per-episode copies dtheta, so the weight-gradient contractions with respect to them are skipped)
         # gradients as tensors + ONE multi-tensor accumulation into .grad (torch.autograd.backward would run one AccumulateGrad
         # add_ per parameter: ~110 launches per chunk in a step whose small-batch form is bound by its launch count)
+        # (only the LEAF copies: with INNER_STEPS > 1 the later fast weights are functions of the earlier steps' gradients and
+        #  the supervisor gradient reaches the fusion parameters through them)
         with ops.skip_param_grads(frozenset(id(t) for t in st.dtheta)):
             grads = torch.autograd.grad(total, self._targets2, allow_unused=True)
         self._accumulate(self._targets2, grads)
@@ -482,8 +512,8 @@ class _Adaptive(_EpisodeModel):
         try:
             for task in range(b):
                 labels = _labels(data, task)
-                dtheta, grads, fusion_out = self._adapt(img[task], mask[task], create_graph=True)
-                set_parameters(self.detector, sgd_step(dtheta, grads, self.config.ADAPTIVE_LR))
+                dtheta, steps, fusion_out, fast = self._adapt(img[task], mask[task], create_graph=True)
+                set_parameters(self.detector, fast)
                 post = self.detector(NestedTensor(img[task], mask[task]))
                 sup = self.criterion(post, labels, background_c=0.1)
                 if self.use_policy:
@@ -505,8 +535,10 @@ class _Adaptive(_EpisodeModel):
                     torch.autograd.backward(total, inputs=targets2)
 
                 # first-order detector update through the adapted weights (reference interactron.py:126-134)
-                fast1 = sgd_step(theta, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)
-                del grads, dtheta, fusion_out, post, sup, total
+                fast1 = theta
+                for grads in steps:
+                    fast1 = sgd_step(fast1, [None if g is None else g.detach() for g in grads], self.config.ADAPTIVE_LR)
+                del steps, dtheta, fusion_out, post, sup, total, fast
                 set_parameters(self.detector, fast1)
                 ridx = random.randint(0, 4)
                 post1 = self.detector(NestedTensor(img[task][ridx:ridx + 1], mask[task][ridx:ridx + 1]))

@@ -72,17 +72,27 @@ def _weighted(l):
     return l["loss_ce"] + 5 * l["loss_giou"] + 2 * l["loss_bbox"]
 
 
+def _inner_steps(cfg):
+    """MODEL.INNER_STEPS: how often the learned-loss step of reference interactron.py:94-102 is repeated (the reference does it
+    once; SURVEY section 0 row 2 / BASELINE.json's "5-step adapt loop" make it a parameter, default 1)."""
+    k = int(cfg.get("INNER_STEPS", 1)) if isinstance(cfg, dict) else int(getattr(cfg, "INNER_STEPS", 1))
+    assert k >= 1, "MODEL.INNER_STEPS must be >= 1"
+    return k
+
+
 def interactron_predict(det, fus, data, cfg, style="gpt"):
-    """reference interactron.py:31-59 (and interactron_random.py:27-56)."""
+    """reference interactron.py:31-59 (and interactron_random.py:27-56); the adapt step repeated INNER_STEPS times."""
     b, s, c, h, w = data["frames"].shape
     img, mask = data["frames"].view(s, c, h, w), data["masks"].view(s, h, w)
     names = theta_names()
-    d = _leafify(det, names)
-    pre = _unsq(detr_forward(d, img, mask))
-    learned = torch.norm(_fusion_fn(style)(fus, pre, cfg)["loss"])
-    g = torch.autograd.grad(learned, [d[k] for k in names], allow_unused=True)
-    fast = dict(d)
-    fast.update(zip(names, clipped_sgd([d[k] for k in names], g, cfg["ADAPTIVE_LR"])))
+    fast = _leafify(det, names)
+    for _ in range(_inner_steps(cfg)):
+        pre = _unsq(detr_forward(fast, img, mask))
+        learned = torch.norm(_fusion_fn(style)(fus, pre, cfg)["loss"])
+        g = torch.autograd.grad(learned, [fast[k] for k in names], allow_unused=True)
+        nxt = clipped_sgd([fast[k] for k in names], g, cfg["ADAPTIVE_LR"])
+        fast = dict(fast)
+        fast.update(zip(names, [t.detach().requires_grad_(True) for t in nxt]))
     with torch.no_grad():
         post = detr_forward(fast, img[0:1], mask[0:1])
     return {k: v.unsqueeze(0) for k, v in post.items()}
@@ -120,13 +130,19 @@ def interactron_forward(det, fus, data, cfg, path_storage, style="gpt", training
         d.update({k: outer[k] for k in det_train if k not in names})             # in_proj_* stay real parameters
         dtheta = {k: theta_task[k].clone().detach().requires_grad_(True) for k in names}
         d.update(dtheta)
-        pre = _unsq(detr_forward(d, img[task], mask[task], training))
-        fout = _fusion_fn(style)(fus_leaf, pre, cfg, training)
-        learned = torch.norm(fout["loss"])
-        g = torch.autograd.grad(learned, [dtheta[k] for k in names], create_graph=True, retain_graph=True,
-                                allow_unused=True)
-        fast = dict(d)
-        fast.update(zip(names, clipped_sgd([dtheta[k] for k in names], g, cfg["ADAPTIVE_LR"])))
+        # the learned-loss step (reference :94-102), INNER_STEPS times with the second-order graph through all of them; the
+        # policy logits are those of the first (un-adapted) pass, as in the reference's single step
+        fast, cur, fout, g_steps = d, [dtheta[k] for k in names], None, []
+        for step in range(_inner_steps(cfg)):
+            pre = _unsq(detr_forward(fast, img[task], mask[task], training))
+            fo = _fusion_fn(style)(fus_leaf, pre, cfg, training)
+            fout = fout or fo
+            learned = torch.norm(fo["loss"])
+            g = torch.autograd.grad(learned, cur, create_graph=True, retain_graph=True, allow_unused=True)
+            g_steps.append(g)
+            cur = clipped_sgd(cur, g, cfg["ADAPTIVE_LR"])
+            fast = dict(d)
+            fast.update(zip(names, cur))
         post = detr_forward(fast, img[task], mask[task], training)
         sup = set_criterion(post["pred_logits"], post["pred_boxes"], labels, cfg["NUM_CLASSES"], 0.1)
         if style == "gpt":
@@ -142,9 +158,11 @@ def interactron_forward(det, fus, data, cfg, path_storage, style="gpt", training
         total = _weighted(sup) + (sup["loss_path"] if style == "gpt" else 0)
         total.backward()
         # first-order detector update (reference interactron.py:126-134)
-        g_det = [None if x is None else x.detach().clone() for x in g]
+        cur1 = [theta_task[k] for k in names]
+        for g in g_steps:   # the same steps with the gradients as constants, from the attached copy of theta
+            cur1 = clipped_sgd(cur1, [None if x is None else x.detach().clone() for x in g], cfg["ADAPTIVE_LR"])
         fast1 = dict(d)
-        fast1.update(zip(names, clipped_sgd([theta_task[k] for k in names], g_det, cfg["ADAPTIVE_LR"])))
+        fast1.update(zip(names, cur1))
         ridx = ridx_fn()
         post1 = detr_forward(fast1, img[task][ridx:ridx + 1], mask[task][ridx:ridx + 1], training)
         dl = set_criterion(post1["pred_logits"], post1["pred_boxes"], labels[ridx:ridx + 1], cfg["NUM_CLASSES"], 0.1)

@@ -238,3 +238,39 @@ def test_g18_oracle_through_the_evaluators(kind, golden, det_sd, tmp_path):
         assert max(abs(a - b) for a, b in zip(g["box"], w["box"])) <= 1e-4, (i, g, w)
     for k, v in want["six"].items():
         assert abs(float(summary[k]) - v) <= 1e-6, (k, float(summary[k]), v)
+
+
+@pytest.mark.slow
+def test_inner_steps_parameter_of_the_oracle():
+    """MODEL.INNER_STEPS in the oracle: 1 (explicit) is the reference's single step bit for bit -- the
+    default that fixture G13 pins --, 2 repeats the learned-loss step (reference models/interactron.py:94-102) with the graph
+    through both, changes what the supervisor sees and leaves the same tensors without a gradient."""
+    import random
+    from interactron_amd.synthetic import procedural_state_dict, synthetic_episodes
+    from oracle import detector as od, episode as oe, fusion as of
+    cfg = dict(TYPE="interactron", NUM_CLASSES=1235, NUM_LAYERS=4, NUM_HEADS=8, EMBEDDING_DIM=512, BLOCK_SIZE=2060,
+               IMG_FEATURE_SIZE=256, OUTPUT_SIZE=512, BOX_EMB_SIZE=256, EMBEDDING_PDROP=0.1, RESIDUAL_PDROP=0.1,
+               ATTENTION_PDROP=0.1, ADAPTIVE_LR=1e-3)
+    det = {k[len("detector."):]: v for k, v in
+           procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+    fus = {k[len("fusion."):]: v for k, v in
+           procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, "gpt").items()}).items()}
+    data = synthetic_episodes(1, height=64, width=64, tag="inner")
+    runs = {}
+    for name, c in (("default", cfg), ("one", dict(cfg, INNER_STEPS=1)), ("two", dict(cfg, INNER_STEPS=2))):
+        random.seed(5)
+        runs[name] = oe.interactron_forward(det, fus, data, c, {}, "gpt")
+    for k, v in runs["default"][1].items():
+        assert torch.equal(v, runs["one"][1][k]), k
+    for grp in ("detector", "fusion"):
+        for k, g in runs["default"][2][grp].items():
+            g1, g2 = runs["one"][2][grp][k], runs["two"][2][grp][k]
+            assert (g is None) == (g1 is None) == (g2 is None), (grp, k)
+            if g is not None:
+                assert torch.equal(g, g1), (grp, k)
+                assert torch.isfinite(g2).all(), (grp, k)
+    sup = [k for k in runs["one"][1] if "supervisor" in k and "path" not in k]
+    assert any(float((runs["one"][1][k] - runs["two"][1][k]).abs()) > 1e-7 for k in sup), "the second inner step changed nothing"
+    p1 = oe.interactron_predict(det, fus, data, dict(cfg, INNER_STEPS=1))
+    p2 = oe.interactron_predict(det, fus, data, dict(cfg, INNER_STEPS=2))
+    assert float((p1["pred_logits"] - p2["pred_logits"]).abs().max()) > 0

@@ -818,6 +818,30 @@ def test_oracle_parity_fresh_inputs_small_resolution():
         torch.testing.assert_close(out[k].cpu(), v, atol=tol, rtol=1e-3, msg=lambda s: k + ": " + s)
 
 
+def test_inner_steps_2_against_the_oracle():
+    """MODEL.INNER_STEPS = 2 (BASELINE.json's multi-step adapt loop): two learned-loss SGD steps with the
+    second-order graph through both (reference step: models/interactron.py:94-102, utils/meta_utils.py:135-142), one episode
+    at 128 x 128.  The episode-batched schedule against the CPU oracle: every loss (2e-3) and every gradient tensor of both
+    networks -- None-pattern, direction (cosine >= 0.999), norm within 5e-3 + 3 x the float32 oracle's own distance from its
+    float64 run on that tensor (two clipped steps double the elements that sit on kinks: the float32 oracle itself is up to
+    7.5e-3 off its float64 run at two steps, 2e-3 at one).  The reference's sequential schedule (EPISODE_CHUNK 0) against the
+    batched one.  And the second step must matter: the supervisor losses differ from the single-step run's."""
+    import __graft_entry__ as entry
+    two = entry.smoke_check(128, inner_steps=2, episodes=1, chunk=16, f64_slack=True)
+    assert two["checked"] >= 300
+    seq = entry.smoke_check(128, inner_steps=2, episodes=1, chunk=0, oracle=False)
+    assert seq["norms"].keys() == two["norms"].keys()
+    for k, v in two["losses"].items():
+        assert abs(seq["losses"][k] - v) <= 2e-3 * max(abs(v), 1.0), (k, seq["losses"][k], v)
+    for k, v in two["norms"].items():
+        if max(v, seq["norms"][k]) < 1e-6:
+            continue   # mathematically zero gradient (attention key bias): rounding noise on both sides
+        assert abs(seq["norms"][k] - v) <= (5e-2 if k.endswith("loss_decoder.layers.2.bias") else 5e-3) * max(v, 1e-6), (k, seq["norms"][k], v)
+    one = entry.smoke_check(128, inner_steps=1, episodes=1, chunk=16, oracle=False)
+    diff = max(abs(two["losses"][k] - one["losses"][k]) / max(abs(one["losses"][k]), 1e-6) for k in one["losses"] if "supervisor" in k)
+    assert diff > 1e-5, "INNER_STEPS = 2 reproduced the single-step losses: the second step did nothing"
+
+
 # ---- train mode (dropout ON) against the oracle, with the HIP path's own dropout masks handed to the oracle --------------------
 def _hip_elementwise_keep(seed, n, p):
     """The counter-hash mask of csrc/elementwise.hip (dropout_kernel / relu_dropout_kernel / add_dropout_kernel: mix32 of
