@@ -230,6 +230,7 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
     from interactron_amd.trainer import FlatOuterStep
     lib, dev, rank, world, local = ctx["lib"], ctx["dev"], ctx["rank"], ctx["world"], ctx["local"]
 
+    torch.cuda.reset_peak_memory_stats()   # `peak_memory_GB` is this workload's
     cfg, tokens = model_cfg(size, args.queries, chunk, CONFIGS[args.config][1], args.step_graph, args.compute_dtype,
                             inner_steps or args.inner_steps)
     model = build_model(Config(**cfg))
@@ -354,6 +355,15 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         if lib.ix_diag_mfma_rate_f16(ctypes.byref(sus), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0 and sus.value > 0:
             res["roofline"]["sustained_mfma_tflops_measured"] = sus.value
             res["roofline"]["frac_of_sustained"] = res["roofline"]["achieved"] / sus.value
+        if res["gemm_launches_per_step"] == 0:
+            # the timed steps were replayed from HIP graphs, which pass no launch through the library's counters: the per-step
+            # work figures then come from the profiled step (the same launches, issued one by one)
+            r = res["roofline"]
+            res["gemm_gflop_per_step"] = r["gflop_per_step"] + (cfl[0] / 1e9)
+            res["gemm_launches_per_step"] = float(r["launches_per_step"] + cn[0])
+            res["attention_gflop_per_step"] = r["attention_kernels"]["gflop_per_step"]
+            res["attention_launches_per_step"] = float(r["attention_kernels"]["launches_per_step"])
+            res["work_counted_in"] = "the profiled eager step (the timed steps replay captured HIP graphs)"
 
     bad = [k for k, v in last["losses"].items() if not bool(torch.isfinite(v).all())]
     assert not bad, "non-finite losses after the timed steps: %s" % bad
@@ -404,6 +414,8 @@ def hbm_kernels(torch, hipops, dev, rows=32960, seq=(16, 2060)):
     return out
 
 
+# (head dim 64 in the fp16 form runs the 16x16x32 twins of csrc/flash16.hip -- flash16_fwd / bwd_q / bwd_kv / bb_stats / bb_q / bb_kv --
+#  under the same slots; head dim 32 the 32x32x16 kernels of csrc/flash.hip)
 FLASH_KERNELS = ["all", "flash_fwd_kernel", "flash_bwd_q_kernel", "flash_bwd_kv_kernel", "flash_bb_q_kernel<stats>",
                  "flash_bb_q_kernel", "flash_bb_kv_kernel"]
 
@@ -485,7 +497,7 @@ def main():
                     help="episodes per GPU of the `small_e` sub-measurement at N = 1 (the per-GPU share of the reference's global "
                          "batch on 8 GPUs; replayed from HIP graphs); 0 = skip it")
     ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
-                    help="MODEL.STEP_GRAPH: replay the chunk's launch sequence from captured HIP graphs (auto: chunks up to 4 x 300^2 episodes)")
+                    help="MODEL.STEP_GRAPH: replay the chunk's launch sequence from captured HIP graphs (auto: whenever the capture fits in free device memory)")
     ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16"],
                     help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the single-pass "
                          "16-bit mode (BASELINE.json configs[1]: --config multi_frame_baseline --compute-dtype bf16) -- its own line, "
@@ -494,6 +506,9 @@ def main():
                     help="MODEL.INNER_STEPS: learned-loss SGD steps per episode (reference: 1; BASELINE.json's '5-step adapt loop' = 5, "
                          "a stress setting -- the default run reports it as the `inner5` sub-line)")
     ap.add_argument("--inner5-episodes", type=int, default=4, help="episodes per GPU of the `inner5` sub-measurement (0 = skip it)")
+    ap.add_argument("--stress-steps", type=int, default=2,
+                    help="timed steps of the `stress` sub-measurement (BASELINE.json configs[4]: 1600 long edge, 200 queries, fp8 MFMA "
+                         "attention forward; one episode per step, after one warm-up step; 0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
@@ -546,6 +561,18 @@ def main():
     inner5 = None
     if headline_cfg and world == 1 and args.inner5_episodes > 0:
         inner5 = run_workload(args, 300, args.inner5_episodes, args.inner5_episodes, 3, 1, ctx, False, "bench", inner_steps=5)
+    # BASELINE.json configs[4], the bandwidth-bound stress configuration: 1600 x 1600 frames, 200 queries (T = 51 005), the two
+    # forward attention products on OCP e4m3 MFMA (the derivative passes stay fp32-grade: DESIGN.md 4.2a), one episode per step
+    stress = None
+    if headline_cfg and world == 1 and args.stress_steps > 0 and args.attention_dtype == "fp32":
+        q0, _ops.ATTENTION_DTYPE, args.queries = args.queries, "fp8", 200
+        try:
+            stress = run_workload(args, 1600, 1, 1, args.stress_steps, 1, ctx, False, "bench1600")
+        except torch.cuda.OutOfMemoryError as e:
+            stress = {"error": "out of memory: %s" % str(e)[:200]}
+            torch.cuda.empty_cache()
+        finally:
+            _ops.ATTENTION_DTYPE, args.queries = args.attention_dtype, q0
     # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755),
     # measured in the same process after the headline: same step definition, fewer episodes per pass, its own warm-up.
     n800 = r8 = None
@@ -603,6 +630,12 @@ def main():
             "north_star": ({"value": n800["value"], "unit": "frames/s", "workload": n800["workload"], "ms_per_step": n800["ms_per_step"],
                             "steps": n800["steps"]} if n800 is not None and "error" not in n800 else None),
             "small_e": None, "strong": None,
+            "stress": (stress if stress is None or "error" in stress else
+                       {"workload": "BASELINE.json configs[4]: 1 episode/GPU x 5 frames x 3x1600x1600, Q=200, fusion T=%d, same training step, "
+                                    "attention forward products on fp8 (OCP e4m3) MFMA, derivative passes fp32-grade" % stress["block_size"],
+                        "value": stress["frames_per_s"], "unit": "frames/s", "steps": args.stress_steps, "warmup": 1,
+                        "ms_per_step": stress["ms_per_step"], "peak_memory_GB": stress["peak_memory_GB"], "attention_dtype": "fp8 (forward)",
+                        "step_graphs": stress["step_graphs"]}),
             "inner5": ({"workload": "%d episodes/GPU x 5 frames x 3x300x300, MODEL.INNER_STEPS = 5 (BASELINE.json north_star's 5-step adapt loop; "
                                     "the reference and the headline take 1 step)" % args.inner5_episodes, "inner_steps": 5,
                         "episodes_per_gpu": args.inner5_episodes, "steps": 3, "warmup": 1, "ms_per_step": inner5["ms_per_step"],
@@ -635,7 +668,14 @@ def main():
                 n800["cpu_baseline"]["comparable"] = False
                 n800["cpu_baseline"]["note"] = ("NOT a like-for-like step: the detector forward alone on one 800 x 800 frame.  A full "
                                                 "meta-train step at T = 12 755 needs 8 x T^2 fp32 attention tensors with double backward "
-                                                "on the host (BASELINE.md 3); never divide the n800 value by this figure")
+                                                "on the host (BASELINE.md 3); never divide the n800 value by this figure -- the "
+                                                "like-for-like pair is `two_frame_episode`")
+                # the comparable pair: ONE meta-train episode of two 800 x 800 frames (T = 5 105) through the oracle and through HIP on
+                # one GPU box (tools/n800_two_frame.py; ~1-2 minutes of host time, so measured once per round and committed)
+                import glob
+                two = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_n800_two_frame_episode.json")))
+                if two:
+                    n800["two_frame_episode"] = dict(json.load(open(two[-1])), source="profiles/" + os.path.basename(two[-1]))
         sys.stdout.flush()
         os.write(JSON_FD, (json.dumps(line) + "\n").encode())   # the one line on the real stdout
     if world > 1:

@@ -52,10 +52,17 @@ def arg_check(arg, choices, argname):
 def build_model(args):
     arg_check(args.TYPE, MODEL_TYPES, "model")
     from . import episode
-    dtype = getattr(args, "COMPUTE_DTYPE", None)
-    if dtype is not None:   # MODEL.COMPUTE_DTYPE: f32 (default, the parity path) | bf16 / fp16 (single-pass 16-bit contractions)
-        from . import hipops
-        hipops.set_compute_dtype(dtype)
+    # MODEL.COMPUTE_DTYPE: f32 (default, the parity path) | bf16 / fp16 (single-pass 16-bit contractions).  The mode is process-wide
+    # (it is a switch of the kernel library): it is set on EVERY build, so that a model built without the key after a 16-bit one
+    # is back on the fp32-grade path, and a change is said once.
+    from . import hipops
+    dtype = getattr(args, "COMPUTE_DTYPE", "f32")
+    old = hipops.set_compute_dtype(dtype)
+    if old != hipops.COMPUTE_DTYPE:
+        import warnings
+        warnings.warn("MODEL.COMPUTE_DTYPE %r: contractions of this process now run in the %s mode (was %s)%s"
+                      % (dtype, hipops.COMPUTE_DTYPE, old, "; 'fp16' / 'half' select the same single-pass 16-bit mode as 'bf16'"
+                         if str(dtype).lower() in ("fp16", "half", "f16") else ""))
     return getattr(episode, args.TYPE)(args)
 
 

@@ -553,10 +553,11 @@ __global__ __launch_bounds__(256) void rownorm_sum_kernel(const float* __restric
 // gx[e][j] = g * x[e][j] / norms[e]   (g: one device scalar)
 __global__ void rownorm_sum_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms, const float* __restrict__ g,
                                        float* __restrict__ gx, int E, int n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)E * n) return;
-    const float nm = norms[i / n];
-    gx[i] = nm > 0.f ? *g * x[i] / nm : 0.f;
+    // grid-stride: ix_grid_1d caps the grid at 4 096 workgroups (E * n beyond 2^20 elements must still be written)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)E * n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float nm = norms[i / n];
+        gx[i] = nm > 0.f ? *g * x[i] / nm : 0.f;
+    }
 }
 // cotangent H of y = g x / ||x_e||:  Gg = sum_e <H_e, x_e> / n_e;  Gx[e] = g (H_e / n_e - x_e <H_e, x_e> / n_e^3)
 __global__ __launch_bounds__(256) void rownorm_sum_bwd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ norms,

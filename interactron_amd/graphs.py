@@ -235,10 +235,10 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
         state[key] = "warm"
 
         def warm(inputs, policy_labels):   # ... and measures what a step of this signature needs beyond what is already held
-            torch.cuda.reset_peak_memory_stats()
+            # (an upper bound from the process-wide peak, which is left alone: whoever reports peak memory -- bench.py -- owns it)
             base = torch.cuda.memory_allocated()
             res = run_eager(model, E, s, inputs, policy_labels)
-            model.__dict__.setdefault("_chunk_peaks", {})[key] = torch.cuda.max_memory_allocated() - base
+            model.__dict__.setdefault("_chunk_peaks", {})[key] = max(0, torch.cuda.max_memory_allocated() - base)
             return res
         return warm
     if ent == "eager":
@@ -252,11 +252,18 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
                     del state[old]          # its graphs, static buffers and both private pools go with it
                 need = model.__dict__.get("_chunk_peaks", {}).get(key, 0)
                 if need > (8 << 30):   # a large working set: the pools must find it as FREE device memory
+                    recapture = isinstance(state.get(key), ChunkGraphs)
+                    if recapture:
+                        state[key] = "warm"   # the stale graphs of this very signature hold the memory the new ones need
+                    import gc
+                    gc.collect()              # (evicted / stale ChunkGraphs sit in a reference cycle with the model: their pools only go now)
                     torch.cuda.synchronize()
                     torch.cuda.empty_cache()   # (the warm-up step's blocks sit in the allocator's cache, useless to a private pool)
                     free, _ = torch.cuda.mem_get_info()
                     if free < 1.15 * need + (4 << 30):
-                        state[key] = "eager"   # not an error: this signature simply stays on eager launches
+                        # not an error: eager launches.  A first capture that does not fit stays eager; a RE-capture (stamp moved)
+                        # is tried again at the next stamp change -- a transient low reading must not pin the signature
+                        state[key] = "warm" if recapture else "eager"
                         return run_eager(model, E, s, inputs, policy_labels)
                 g = ChunkGraphs(model, E, s, shape, GRAPH_PITCH, GRAPH_PITCH, inputs["masks"].dtype)
                 g.load(inputs)

@@ -320,7 +320,9 @@ def _wp_planes(b, sp, plan):
     nb = 1 if shared else sp.bo
     key = (kc, ld, so, sp.B.offset, sp.N, sp.K, nb, _wp_epoch[0])
     if _capture[0] is not None:
-        store, tag = _capture[0], ("wp", id(b)) + key
+        # (+ the scratch slot = the stream a captured segment replays on: segment C -- slot 1, the side stream -- and segment B
+        #  run concurrently at replay, so neither may read planes that the other one's graph writes)
+        store, tag = _capture[0], ("wp", _scratch_slot[0], id(b)) + key
     else:
         store = b.__dict__.setdefault("_ix_wp", {})
         tag = key
