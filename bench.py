@@ -408,7 +408,10 @@ def hbm_kernels(torch, hipops, dev, rows=32960, seq=(16, 2060)):
     out["ln_fwd_kernel"] = {"bytes": 8 * x.numel(), "GBps": 8 * x.numel() / t / 1e9}
     y = torch.randn(seq[0], seq[1], 512, device=dev)
     t = timed(lambda: hipops.attn_split(y, seq[0], seq[1], 512, 0, 8, 64))
-    out["attn_split_kernel"] = {"bytes": 14 * y.numel(), "GBps": 14 * y.numel() / t / 1e9}   # 4 B read, 4 B fp16 + 6 B bf16 planes written
+    # 4 B read + 4 B of fp16 row planes written per element; + tr planes (4 B fp16 / 6 B bf16) unless the head-dim-64 passes read
+    # the row planes both ways (csrc/flash16.hip: no tr planes at all)
+    per = 8 + (0 if hipops._rows_only(64, hipops._TR_FORMS[hipops.FLASH_TR]) else 4 if hipops.FLASH_TR == "f16" else 6)
+    out["attn_split_kernel"] = {"bytes": per * y.numel(), "GBps": per * y.numel() / t / 1e9, "bytes_per_element": per}
     for k in out:
         out[k]["frac_of_8TBps"] = out[k]["GBps"] / 8000.0
     return out

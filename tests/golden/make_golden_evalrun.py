@@ -67,6 +67,50 @@ def write_eval_annotations(root):
     return ann
 
 
+def fit_annotations(ann_path, ds, records):
+    """Round 5: ground truth that the (untrained, calibrated) detector can actually find.  The procedural boxes of
+    write_eval_annotations have nothing to do with what the detector predicts on the noise JPEGs: 12 tp of 138 records, AP_50 =
+    0.006 -- a +-0.002 check on such numbers passes for almost any detector.  The annotations are part of the fixture, so the
+    root state of every scene gets its objects FROM the frame-0 predictions of a first evaluation pass (`records`: the tp / fp
+    records of that pass, grouped by root image): most predictions become an object of their category -- the predicted box
+    moved along one axis by w (1 - t) / (1 + t), which makes the pair's IoU exactly t, for t = 0.925 / 0.775 / 0.625 / 0.425:
+    hits at every threshold of the AP sweep, every IoU 0.025 away from the nearest threshold (a record ON a threshold would
+    turn the +-0.002 AP check into a coin toss between two float32 implementations: one hit more or less moves AP_50 by
+    0.009) --, every fifth prediction gets none (a false positive), and every other scene gets one object nobody predicts (a
+    false negative).  Nothing here looks at the second pass: predict() never sees labels, so the predictions do not move."""
+    ann = json.load(open(ann_path))
+    by_img = {}
+    for r in records:
+        if r["type"] in ("tp", "fp"):
+            by_img.setdefault(r["img"], []).append(r)
+    targets = [0.925, 0.775, 0.625, 0.425]
+    for s, scene in enumerate(ann["data"]):
+        img = ds[s]["initial_image_path"]
+        preds = sorted(by_img.get(img, []), key=lambda r: -r["pred_score"])
+        dets = {}
+        for j, r in enumerate(preds):
+            if j % 5 == 4:
+                continue
+            x0, y0, x1, y1 = [300.0 * c for c in r["box"]]
+            w, h, t = x1 - x0, y1 - y0, targets[(j + s) % 4]
+            if (j + s) % 2 == 0:
+                d = w * (1 - t) / (1 + t)
+                x0 = x0 + d if x1 + d < 299.0 else x0 - d
+            else:
+                d = h * (1 - t) / (1 + t)
+                y0 = y0 + d if y1 + d < 299.0 else y0 - d
+            if x0 < 0.5 or y0 < 0.5 or x0 + w > 299.5 or y0 + h > 299.5:
+                continue   # (would be clipped by the dataset: its IoU would not be the designed one)
+            dets["fit|%d|%d" % (s, j)] = {"category_id": int(r["pred_cat"]) - 1, "bbox": [round(x0, 3), round(y0, 3), round(w, 3), round(h, 3)]}
+        if s % 2 == 0:
+            unused = [c for c in POOL if c not in {int(r["pred_cat"]) for r in preds}] or [POOL[s % len(POOL)]]
+            dets["miss|%d" % s] = {"category_id": unused[0] - 1, "bbox": [40 + 13 * s, 30 + 11 * s, 70, 60]}
+        scene["state_table"][scene["root"]]["detections"] = dets
+    with open(ann_path, "w") as f:
+        json.dump(ann, f, indent=1)
+    return ann_path
+
+
 def calibrate(model, ds, collate_fn, env, rounds=3, class_gain=2.5, class_lift=5.0, box_gain=25.0):
     """-> overrides for evalrun_weight_edit (see there).  `model` already carries the closed-form part of the edit.
 
@@ -238,8 +282,56 @@ def main():
     overrides = calibrate(model, ds, collate_fn, env)
     cfg = Config(**{"EVALUATOR": {"BATCH_SIZE": 1, "NUM_WORKERS": 0, "OUTPUT_DIRECTORY": "/tmp/g18", "CHECKPOINT": ""},
                     "DATASET": {"TEST": {"IMAGE_ROOT": os.path.join(root, "imgs") + "/", "ANNOTATION_ROOT": ann, "MODE": "test"}}})
-    G = {"overrides": overrides, "annotations": os.path.relpath(ann, root), "interactive": run(InteractiveEvaluator, model, cfg), "random_policy": run(RandomPolicyEvaluator, model, cfg)}
-    for k in ("interactive", "random_policy"):
+    first = run(InteractiveEvaluator, model, cfg)
+    print("first pass (procedural boxes):", first["returned"], first["six"])
+    for d in first["detections"]:
+        d["img"] = os.path.join(root, d["img"])
+    fit_annotations(ann, ds, first["detections"])
+    thresholds = np.arange(0.5, 1.0, 0.05)
+
+    def near(d):
+        return d["type"] == "tp" and min(abs(d["iou"] - t) for t in thresholds) < 5e-3
+
+    # config 3 (configs/interactron_random.yaml, the README's "Interactron-Rand" row): the decoder-fusion model with the same
+    # detector recipe through the fixed-rollout evaluator
+    model_r, _ = mg.build("interactron_random", Config)
+    sd_r = model_r.state_dict()
+    evalrun_weight_edit(sd_r, overrides)
+    model_r.load_state_dict(sd_r)
+    RUNS = ("interactive", "random_policy", "random_policy_interactron_random")
+    for attempt in range(6):
+        G = {"overrides": overrides, "annotations": os.path.relpath(ann, root), "interactive": run(InteractiveEvaluator, model, cfg),
+             "random_policy": run(RandomPolicyEvaluator, model, cfg),
+             "random_policy_interactron_random": run(RandomPolicyEvaluator, model_r, cfg)}
+        bad = [d for k in RUNS for d in G[k]["detections"] if near(d)]
+        margin = min(abs(d["iou"] - t) for k in RUNS for d in G[k]["detections"] if d["type"] == "tp" for t in thresholds)
+        print("attempt", attempt, "smallest distance of a hit's IoU from a sweep threshold: %.2e" % margin, "(%d hits within 5e-3)" % len(bad))
+        if not bad:
+            break
+        # The designed IoUs hold for the pass the objects were fitted to; the other evaluator adapts on other rollouts and its
+        # boxes land elsewhere.  Objects whose hit sits within 5e-3 of a threshold in EITHER pass are taken out of the ground
+        # truth (found by the record's own IoU against the objects of its image and category) and both passes are run again.
+        a = json.load(open(ann))
+        for d in bad:
+            scene = next(sc for s_, sc in enumerate(a["data"]) if os.path.relpath(ds[s_]["initial_image_path"], root) == d["img"])
+            objs = scene["state_table"][scene["root"]]["detections"]
+            px0, py0, px1, py1 = [300.0 * c for c in d["box"]]
+            best, best_err = None, 1e9
+            for name, o in objs.items():
+                if o["category_id"] + 1 != int(d["pred_cat"]):
+                    continue
+                gx0, gy0, gw, gh = o["bbox"]
+                iw, ih = max(0.0, min(px1, gx0 + gw) - max(px0, gx0)), max(0.0, min(py1, gy0 + gh) - max(py0, gy0))
+                iou = iw * ih / ((px1 - px0) * (py1 - py0) + gw * gh - iw * ih)
+                if abs(iou - d["iou"]) < best_err:
+                    best, best_err = name, abs(iou - d["iou"])
+            if best is not None and best_err < 2e-2:
+                del objs[best]
+        with open(ann, "w") as f:
+            json.dump(a, f, indent=1)
+    assert not bad, "hits still sit on thresholds of the AP sweep"
+    G["iou_threshold_margin"] = float(margin)
+    for k in RUNS:
         v = G[k]
         kinds = [d["type"] for d in v["detections"]]
         print(k, "returned", v["returned"], "actions", v["actions"], "margin", v["min_policy_margin"], "records", len(kinds),

@@ -85,10 +85,10 @@ def test_train_then_evaluate_drop_in(tmp_path):
 
 
 # ---- fixture G18: the reference's evaluators end to end (tests/golden/make_golden_evalrun.py) ---------------------------
-def _g18_model(G):
+def _g18_model(G, model_type="interactron"):
     from interactron_amd import Config, build_model
     from interactron_amd.synthetic import evalrun_weight_edit, load_procedural
-    model = build_model(Config(**MODEL))
+    model = build_model(Config(**dict(MODEL, TYPE=model_type)))
     load_procedural(model.fusion, "fusion.")      # (build_model's "procedural" covers the detector; as in the parity tests)
     sd = model.state_dict()
     sd = {k: v.clone() for k, v in sd.items()}
@@ -109,17 +109,23 @@ def _g18_cfg(G, tmp_path, kind):
                                          "CHECKPOINT": ""}})
 
 
-@pytest.mark.parametrize("kind", ["interactive_evaluator", "random_policy_evaluator"])
-def test_g18_evaluators_end_to_end_against_the_reference(kind, golden, tmp_path):
+@pytest.mark.parametrize("kind,model_type", [("interactive_evaluator", "interactron"), ("random_policy_evaluator", "interactron"),
+                                             ("random_policy_evaluator", "interactron_random")])
+def test_g18_evaluators_end_to_end_against_the_reference(kind, model_type, golden, tmp_path):
     """The only available stand-in for north_star's "AP within +-0.002": the imported reference's evaluators
     (engine/interactive_evaluator.py:35-262, engine/random_policy_evaluator.py:37-211) were run on tests/golden/data with the
-    fixture's weight recipe; the HIP evaluators must choose the same moves, produce the same records (kind, category, image
-    exactly; IoU and score to 1e-3, box corners to 2e-3) in the same order, the same counts and the six AP numbers to 0.002."""
+    fixture's weight recipe -- `interactron` through both, `interactron_random` (config 3) through the fixed rollout; the HIP
+    evaluators must choose the same moves, produce the same records (kind, category, image exactly; IoU and score to 1e-3, box
+    corners to 2e-3) in the same order, the same counts and the six AP numbers to 0.002.  Since round 5 the ground truth of the
+    root states is fitted to what the calibrated detector finds (make_golden_evalrun.py:fit_annotations): AP_50 = 0.39 / 0.39 /
+    0.33, AP = 0.24 / 0.24 / 0.13, AP_75 / AP_medium / AP_large non-zero, 54 % / 54 % / 38 % of the records hits, every hit's IoU
+    >= 5e-3 away from the sweep's thresholds -- numbers on which +-0.002 discriminates (round 4: AP_50 = 0.006)."""
     from interactron_amd import build_evaluator
     G = golden("golden_evalrun.pt")
-    want = G[kind.replace("_evaluator", "")]
+    want = G[kind.replace("_evaluator", "") + ("_interactron_random" if model_type == "interactron_random" else "")]
+    assert want["six"]["AP_50"] >= 0.3 and want["six"]["AP"] >= 0.1 and min(want["six"][k] for k in ("AP_75", "AP_medium", "AP_large")) > 0
     root, cfg = _g18_cfg(G, tmp_path, kind)
-    model = _g18_model(G)
+    model = _g18_model(G, model_type)
     moves = []
     if kind == "interactive_evaluator":
         orig = model.get_next_action

@@ -190,35 +190,40 @@ def test_g11_g12_predict_and_policy(golden, det, episode1):
 class _OracleModel(torch.nn.Module):
     """the model interface the evaluators call (predict / get_next_action / eval), answered by the CPU oracle"""
 
-    def __init__(self, det, fus):
+    def __init__(self, det, fus, style="gpt"):
         super().__init__()
-        self.det, self.fus = det, fus
+        self.det, self.fus, self.style = det, fus, style
         self.anchor = torch.nn.Parameter(torch.zeros(1))   # (the evaluators ask the model where it lives)
 
     def predict(self, data):
-        return oe.interactron_predict(self.det, self.fus, data, CFG)
+        return oe.interactron_predict(self.det, self.fus, data, CFG, self.style)
 
     def get_next_action(self, data):
         return oe.interactron_next_action(self.det, self.fus, data, CFG)[0]
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("kind", ["interactive_evaluator", "random_policy_evaluator"])
-def test_g18_oracle_through_the_evaluators(kind, golden, det_sd, tmp_path):
+@pytest.mark.parametrize("kind,style", [("interactive_evaluator", "gpt"), ("random_policy_evaluator", "gpt"),
+                                        ("random_policy_evaluator", "decoder")])
+def test_g18_oracle_through_the_evaluators(kind, style, golden, det_sd, tmp_path):
     """tests/golden/make_golden_evalrun.py: InteractiveEvaluator / RandomPolicyEvaluator of the imported reference on
-    tests/golden/data.  Same moves, same records in the same order, same six AP numbers from the oracle + engine/."""
+    tests/golden/data -- `interactron` through both, `interactron_random` (style "decoder", config 3) through the fixed rollout.
+    Same moves, same records in the same order, same six AP numbers from the oracle + engine/."""
     import json
     import os
     from interactron_amd import Config, build_evaluator
     from interactron_amd.synthetic import evalrun_weight_edit
     G = golden("golden_evalrun.pt")
-    want = G[kind.replace("_evaluator", "")]
+    want = G[kind.replace("_evaluator", "") + ("_interactron_random" if style == "decoder" else "")]
     sd = dict(det_sd)
-    sd.update(procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(CFG, "gpt").items()}))
+    fsd = procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(CFG, style).items()})
+    if style == "decoder" and "fusion.pos_embed" not in fsd:
+        fsd["fusion.pos_embed"] = of.decoder_fusion_pos_embed()
+    sd.update(fsd)
     sd = {k: v.clone() for k, v in sd.items()}
     evalrun_weight_edit(sd, G["overrides"])
     model = _OracleModel(strip({k: v for k, v in sd.items() if k.startswith("detector.")}, "detector."),
-                         strip({k: v for k, v in sd.items() if k.startswith("fusion.")}, "fusion."))
+                         strip({k: v for k, v in sd.items() if k.startswith("fusion.")}, "fusion."), style)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
     cfg = Config(**{"EVALUATOR": {"TYPE": kind, "BATCH_SIZE": 1, "NUM_WORKERS": 0, "OUTPUT_DIRECTORY": str(tmp_path), "CHECKPOINT": ""},
                     "DATASET": {"TEST": {"TYPE": "sequence", "MODE": "test", "IMAGE_ROOT": os.path.join(root, "imgs") + "/",
@@ -234,7 +239,9 @@ def test_g18_oracle_through_the_evaluators(kind, golden, det_sd, tmp_path):
     for i, (g, w) in enumerate(zip(got, want["detections"])):
         assert (g["type"], g["pred_cat"], g["category_match"]) == (w["type"], w["pred_cat"], w["category_match"]), (i, g, w)
         assert os.path.relpath(g["img"], root) == w["img"]
-        assert abs(g["iou"] - w["iou"]) <= 1e-4 and abs(g["pred_score"] - w["pred_score"]) <= 1e-4, (i, g, w)
+        # (IoU: the round-5 ground truth sits a designed distance from the predicted boxes, so a box that differs by 1e-4 moves
+        #  its IoU by several times that; every hit is >= 5e-3 away from the thresholds of the AP sweep, G["iou_threshold_margin"])
+        assert abs(g["iou"] - w["iou"]) <= 1e-3 and abs(g["pred_score"] - w["pred_score"]) <= 1e-4, (i, g, w)
         assert max(abs(a - b) for a, b in zip(g["box"], w["box"])) <= 1e-4, (i, g, w)
     for k, v in want["six"].items():
         assert abs(float(summary[k]) - v) <= 1e-6, (k, float(summary[k]), v)
