@@ -181,7 +181,7 @@ __device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, 
     const int st_off = st_row * 64 + st_c * 8;   /* element offset of the chunk inside the tile's 32 x 64 rows */
 // per-lane fragment offsets: A fragment of k-slice 0 / 1 (row n of a block), transpose-read base (rows 4 g + (n >> 2))
 #define M16_LANE_GEOMETRY                                                                                    \
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;             \
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4; \
     const int offA0 = (g >> 1) * M16_PANEL + n * 32 + ((g & 1) << 4), offA1 = offA0 + 2 * M16_PANEL;        \
     const int offT = (4 * g + (n >> 2)) * 32 + ((n & 3) << 3);                                               \
     (void)offA1; (void)offT;                                                                                 \
@@ -421,6 +421,10 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
 // into the same accumulator share one range check (their fragments are converted before either product runs).  The
 // staging ring is four tiles deep: tile t is read in M(t) (first stage) and M(t + 1) (second stage) by both halves, and
 // tile t + 2 is written at the end of V(t).
+// Waves whose 16 owner rows all lie beyond the tensor (the tail of the last workgroup of a row: 2 060 rows = 16 x 128 + 12 leaves
+// seven of its eight waves empty) stage their share of every tile and keep the barriers, nothing else (`live`): the last
+// workgroup of a row then costs a fraction of a full one -- it is the whole second round of the grid at two episodes (17 x 16
+// workgroups on 256 CUs, one per CU).  (The passes that run two workgroups per CU have room for that round anyway.)
 #define M16_LAG_IF(COND) if (COND) __syncthreads();
 #define M16_UPPER_HALF (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
 #define M16_NSLOT 4
@@ -477,8 +481,10 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     K16_STORE(lds + BUFB)
     __syncthreads();
     M16_LAG_IF(M16_UPPER_HALF)
+    const bool live = k0 < p.S;   // (wave-uniform)
     f32x4 s[2], gd[2];
-    K16_PHASE1(lds)
+    u32x4 bfv[2], bfk[2];
+    if (live) { K16_PHASE1(lds) }
     __syncthreads();
 
     for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
@@ -488,6 +494,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
         const float usq = p.q_us[qbo + t], usd = p.do_us[qbo + t];
         const float cs = c2 * usq, cgk = usv * usd * p.inv_keep;
         K16_LOAD(min(t0 + 64, last))
+        if (live) {
         const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
         f32x4 lse2[2], dl[2];
         lse2[0] = *reinterpret_cast<const f32x4*>(st + 4 * g); lse2[1] = *reinterpret_cast<const f32x4*>(st + 16 + 4 * g);
@@ -503,20 +510,20 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
                 pd[blk][r] = M16_PM(blk, r, pr);                                  // (x 1/keep at the end, on gV)
                 gs[blk][r] = pd[blk][r] * (gd[blk][r] * cgk) - pr * dl[blk][r];   // gs = P o (M o gd - t)
             }
-        u32x4 bfv[2], bfk[2];
         M16_FIT_SPLIT_BOUNDED(bfv, pd, 1.f, usd, fv, gv)
         M16_FIT_SPLIT(bfk, gs, usq, fk, gk)
+        }
         K16_STORE(lds + ((slot + 2) & 3) * BUFB)
         __syncthreads();
         // ---- M(t + 1) ----
-        {
+        if (live) {
             M16Tr ta, tb;
             m16_stage2_load(ta, cur + M16_OPB, offT);
             m16_stage2_load(tb, cur, offT);
             m16_stage2_mma(gv, ta, bfv);   // gV^T[d, key] += dO^T[d, query] Pd[query, key]
             m16_stage2_mma(gk, tb, bfk);   // gK^T[d, key] += Q^T[d, query] gs[query, key]
+            if (t + 1 < ntiles) { K16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         }
-        if (t + 1 < ntiles) { K16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         __syncthreads();
     }
     M16_LAG_IF(!M16_UPPER_HALF)
@@ -658,8 +665,10 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
     B16_STORE(lds + BUFB)
     __syncthreads();
     M16_LAG_IF(M16_UPPER_HALF)
+    const bool live = q0 < p.L;   // (wave-uniform)
     f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
-    B16_PHASE1(lds)
+    u32x4 bf1[2], bf2[2], bf3[2], bf4[2];
+    if (live) { B16_PHASE1(lds) }
     __syncthreads();
 
     for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
@@ -668,6 +677,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
         M16_STAMP(0)
         // ---- V(t) ----
         B16_LOAD(min(t0 + 64, last))
+        if (live) {
         B16_ELEMENTWISE
         f32x4 x1[2], x2[2], x4[2];
 #pragma unroll
@@ -679,7 +689,6 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
                 x4[blk][r] = pm[blk][r] * (g1[blk][r] - uu);                                                 // HgD keep (the 1 / keep rides on its scale)
             }
         // dq += hk^T gs + k^T HS: one range check for both;  ddO += hv^T Pd + v^T HgD likewise (Pd = pm / keep <= 1 / keep)
-        u32x4 bf1[2], bf2[2], bf3[2], bf4[2];
         m16_fit<true>(fmaxf(m16_absmax(x1) * ushk, m16_absmax(x2) * usk), fdq, dq);
         m16_split(bf1, x1, ushk * fdq);
         m16_split(bf2, x2, usk * fdq);
@@ -687,12 +696,13 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
         m16_fit<true>(fmaxf(ushvk, m16_absmax(x4) * usvk), fddo, ddo);
         m16_split(bf3, pm, ushvk * fddo);
         m16_split(bf4, x4, usvk * fddo);
+        }
         B16_STORE(lds + ((slot + 2) & 3) * BUFB)
         M16_STAMP(1)
         __syncthreads();
         M16_STAMP(2)
         // ---- M(t + 1) ----
-        {
+        if (live) {
             M16Tr ta, tb;   // (two sets: the next operand's transposed fragments fly during a product)
             m16_stage2_load(ta, cur + M16_OPB, offT);
             m16_stage2_load(tb, cur + 3 * M16_OPB, offT);
@@ -702,8 +712,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
             m16_stage2_load(tb, cur + 2 * M16_OPB, offT);
             m16_stage2_mma(dq, ta, bf2);
             m16_stage2_mma(ddo, tb, bf4);
+            if (t + 1 < ntiles) { B16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         }
-        if (t + 1 < ntiles) { B16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         M16_STAMP(3)
         __syncthreads();
         M16_STAMP(4)
@@ -786,8 +796,10 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     C16_STORE(lds + BUFB)
     __syncthreads();
     M16_LAG_IF(M16_UPPER_HALF)
+    const bool live = k0 < p.S;   // (wave-uniform)
     f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
-    C16_PHASE1(lds)
+    u32x4 bf1[2], bf2[2], bf3[2];
+    if (live) { C16_PHASE1(lds) }
     __syncthreads();
 
     for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
         const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk, c3 = p.scale * usq * ushk,
                     chk = usd * ushv * p.inv_keep;
         C16_LOAD(min(t0 + 64, last))
+        if (live) {
         // statistics of this lane's 2 x 4 queries (rows 16 blk + 4 g + r of the tile)
         const float* st = reinterpret_cast<const float*>(cur + OFF_ST);
         f32x4 lse2[2], dl[2], uu[2], ww[2];
@@ -824,17 +837,17 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
                 x3[blk][r] = pm * (G - uu[blk][r]);                                                    // HgD keep
             }
         // dk += hq^T gs + q^T HS: one range check for both;  dv += dO^T HgD
-        u32x4 bf1[2], bf2[2], bf3[2];
         m16_fit<true>(fmaxf(m16_absmax(x1) * ushq, m16_absmax(x2) * usq), fdk, dk);
         m16_split(bf1, x1, ushq * fdk);
         m16_split(bf2, x2, usq * fdk);
         const float usdk = usd * p.inv_keep;
         m16_fit<true>(m16_absmax(x3) * usdk, fdv, dv);
         m16_split(bf3, x3, usdk * fdv);
+        }
         C16_STORE(lds + ((slot + 2) & 3) * BUFB)
         __syncthreads();
         // ---- M(t + 1) ----
-        {
+        if (live) {
             M16Tr ta, tb;   // (two sets: the next operand's transposed fragments fly during a product)
             m16_stage2_load(ta, cur + M16_OPB, offT);
             m16_stage2_load(tb, cur + 2 * M16_OPB, offT);
@@ -842,8 +855,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
             m16_stage2_load(ta, cur, offT);
             m16_stage2_mma(dv, tb, bf3);
             m16_stage2_mma(dk, ta, bf2);
+            if (t + 1 < ntiles) { C16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         }
-        if (t + 1 < ntiles) { C16_PHASE1(lds + ((slot + 1) & 3) * BUFB) }
         __syncthreads();
     }
     M16_LAG_IF(!M16_UPPER_HALF)
