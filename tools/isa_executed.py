@@ -23,6 +23,8 @@ for name in sorted(set(re.findall(r"^(_Z\w+):", s, flags=re.M))):
             nm = sum('mfma' in x for x in lines[labels[m.group(1)]:n])
             if nm > bm:
                 best, bm = (labels[m.group(1)], n), nm
+    if best is None:
+        continue
     out, n = [], best[0]
     while n < best[1]:
         l = lines[n]
