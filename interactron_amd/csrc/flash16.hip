@@ -21,14 +21,9 @@
 //   * the accumulator registers of a tile ARE the B fragment (k = 8 g + e <-> streamed rows 4 g + e | 16 + 4 g + e - 4) of
 //     the products that contract over the streamed rows: no [L, S] value passes through LDS;
 //   * two LDS buffers, ONE barrier per tile; the next tile's rows are requested before the tile's arithmetic and written to
-//     the other buffer after it.
-// Ping-pong (the passes that run one workgroup per CU: dk / dv, dq / ddO, gK / gV).  Left to themselves the two waves of a
-// SIMD run in lock-step -- both in their first-stage matrix burst, then both in the element-wise stretch (clock stamps:
-// tools/m16_timeline.py, profiles/r5g_m16_timeline_lockstep.txt) -- so matrix and vector work add up.  A tile is therefore
-// two segments around two barriers, M (the first-stage products) and V (element-wise arithmetic, conversions, second-stage
-// products), and waves 4..7 run one segment behind waves 0..3 (they pass one extra barrier before the loop, the others one
-// after it): at any time one wave of each SIMD is in M and its partner in V.  The staging ring is three tiles deep so that
-// both halves can write "two tiles ahead" with the same code.
+//     the other buffer after it (forward, gQ, row statistics: two workgroups per CU);
+//   * the passes that run one workgroup per CU (gK / gV, dq / ddO, dk / dv) separate vector and matrix work in time and run
+//     the two halves of the workgroup in opposite segments over a ring of four tiles -- see "split-phase passes" below.
 #include "flash_common.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
