@@ -198,11 +198,25 @@ __device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, 
         KP[blk_][2 * i_] = (hsh_ & 0xffffu) >= p.thr16;                                                      \
         KP[blk_][2 * i_ + 1] = (hsh_ >> 16) >= p.thr16;                                                      \
     }
+// Key-owning: lanes n and n ^ 1 hold keys 2 j and 2 j + 1 -- the same hash for every query row, different halves of it.  Each of
+// the two computes the hashes of HALF of the tile's query rows (rows 2 (n & 1) + {0, 1} of every four) and reads the other half
+// out of its partner's registers (DPP quad_perm, folded into the v_and that masks the lane's half); the comparison runs on the
+// half in place (odd keys: the high half against thr16 << 16).  Same mask as fl_hash taken per element, half the instructions.
 #define M16_MASK_QUERIES(KP, KEY, T0)                                                                        \
-    _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) { \
-        const int q_ = (T0) + 16 * blk_ + 4 * g + r_;                                                        \
-        const unsigned hsh_ = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q_), (unsigned)(KEY) >> 1); \
-        KP[blk_][r_] = (((KEY) & 1) ? (hsh_ >> 16) : (hsh_ & 0xffffu)) >= p.thr16;                           \
+    {                                                                                                        \
+        const unsigned odd_ = (unsigned)(KEY) & 1u, half_ = odd_ ? 0xffff0000u : 0xffffu;                    \
+        const unsigned thr_ = odd_ ? p.thr16 << 16 : p.thr16;                                                \
+        unsigned hq_[2][2];                                                                                  \
+        _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) { \
+            const int q_ = (T0) + 16 * blk_ + 4 * g + 2 * (int)odd_ + j_;                                    \
+            hq_[blk_][j_] = fl_hash(p.seed_lo, p.seed_hi, (unsigned)(bh * p.L + q_), (unsigned)(KEY) >> 1);  \
+        }                                                                                                    \
+        _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) { \
+            const unsigned own_ = hq_[blk_][r_ & 1];   /* rows 0, 1: the even lane's registers; rows 2, 3: the odd lane's */ \
+            const unsigned h_ = (r_ >> 1) ? (unsigned)__builtin_amdgcn_mov_dpp((int)own_, 0xF5, 0xf, 0xf, true)   /* quad_perm [1,1,3,3] */ \
+                                          : (unsigned)__builtin_amdgcn_mov_dpp((int)own_, 0xA0, 0xf, 0xf, true);  /* quad_perm [0,0,2,2] */ \
+            KP[blk_][r_] = (h_ & half_) >= thr_;                                                             \
+        }                                                                                                    \
     }
 // Dropout enters every formula through pm = keep ? P : 0 (one select per element); the 1 / keep of M = keep / (1 - p) is folded
 // into wave-uniform constants: gy = M o gd -> P o gy = pm (gd cg / keep), M o HD likewise, and products whose whole [L, S]
@@ -604,14 +618,16 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
         hd_[blk][r] *= chk;                                                                                  \
     }
 
-// (1) row statistics: two workgroups per CU, double-buffered, one barrier per tile
+// (1) row statistics: two workgroups per CU, double-buffered, one barrier per tile.  u = sum P G and w = sum pm (G gd' + hd') - 2 t u:
+// the two masked sums of w share their multiply by pm.  (Four waves per SIMD asked for explicitly: at two the compiler's schedule
+// of this pass sits at 127-129 registers, and 129 would leave one workgroup per CU.)
 template <bool DROP>
-__global__ __launch_bounds__(512, 2) void flash16_bb_stats_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
     B16_SETUP
-    float uu = 0.f, aa = 0.f, bq = 0.f;
+    float uu = 0.f, ab = 0.f;
     B16_LOAD(0)
     B16_STORE(lds)
     __syncthreads();
@@ -621,24 +637,31 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_stats_kernel(FlashArgs p) {
         B16_LOAD(min(t0 + 32, last))
         f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
         B16_PHASE1(cur)
-        B16_ELEMENTWISE
+        f32x4 kb[2];
+        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
+        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t];
+        const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk,
+                    c3 = p.scale * usq * ushk, chk = usd * ushv * p.inv_keep;
+        bool kp[2][4];
+        if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                uu += pr[blk][r] * g1[blk][r];
-                aa += pm[blk][r] * g1[blk][r] * gd[blk][r];
-                bq += pm[blk][r] * hd_[blk][r];
+            for (int r = 0; r < 4; ++r) {   // w = sum pm (G gd' + hd') - 2 t u: the two masked sums as one
+                const float pr = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));
+                const float G = g1[blk][r] * c1 + g2[blk][r] * c3;
+                uu += pr * G;
+                ab += M16_PM(blk, r, pr) * (G * (gd[blk][r] * cgk) + hd_[blk][r] * chk);
             }
         B16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
     }
     uu += __shfl_xor(uu, 16, 64); uu += __shfl_xor(uu, 32, 64);
-    aa += __shfl_xor(aa, 16, 64); aa += __shfl_xor(aa, 32, 64);
-    bq += __shfl_xor(bq, 16, 64); bq += __shfl_xor(bq, 32, 64);
+    ab += __shfl_xor(ab, 16, 64); ab += __shfl_xor(ab, 32, 64);
     if (g == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
         p.u[so] = uu;
-        p.w[so] = aa - 2.f * dl * uu + bq;
+        p.w[so] = ab - 2.f * dl * uu;
     }
 }
 

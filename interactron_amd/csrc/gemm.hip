@@ -50,7 +50,7 @@ static inline FastDiv make_fastdiv(unsigned d) {
 // per 16-byte load, where the element lives in the NHWC tensor.  A "pixel row" index decomposes over a grid
 //     row = (img * gH + gy) * gW + gx
 // and tap (ky, kx) of that pixel reads the source tensor [img][sH][sW][sC] at
-//     sy = (gy * a + b + ky * d) >> qs,  sx = (gx * a + b + kx * d) >> qs      (valid iff both divisible by 1 << qs and inside)
+//     sy = (gy * a + b + ky * d) >> qs,  sx = (gx * a + bx + kx * d) >> qs     (valid iff both divisible by 1 << qs and inside)
 // -- forward / weight gradient: grid = output pixels, a = stride, b = -pad, d = dilation, qs = 0;  data gradient: grid =
 // input pixels, source = dY, a = 1, b = pad, d = -dilation, qs = log2(stride).  Invalid taps are requested out of range
 // (the buffer load returns zeros without touching memory).
@@ -60,7 +60,7 @@ static inline FastDiv make_fastdiv(unsigned d) {
 struct ConvGather {
     int mode_a, mode_b;
     int gH, gW, sH, sW, sC;
-    int a, b, d, qs, KW;
+    int a, b, bx, d, qs, KW;   // (b: row offset, bx: column offset -- equal except in the parity classes of conv_bwd_data_s2)
     int bmod, btap;
     FastDiv dW, dHW, dC, dKW, dBmod;   // divisions by gW, gH * gW, sC, KW, bmod
 };
@@ -525,7 +525,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                 const int gy = fd_div(rem, g.dW), gx = rem - gy * g.gW;
                 base[i] = img * (g.sH * g.sW);
                 ys[i] = gy * g.a + g.b;
-                xs[i] = gx * g.a + g.b;
+                xs[i] = gx * g.a + g.bx;
             }
         }
     };
@@ -581,7 +581,7 @@ struct SplitLoader {   // BT x 32 fp32 operand tile (BT = 128, 64 or 32 rows) ->
                                               bool valid) {
         const int tap = fd_div(t0, g.dC), c0 = t0 - tap * g.sC;
         const int ky = fd_div(tap, g.dKW), kx = tap - ky * g.KW;
-        const int ty = ky * g.d + g.b, tx = kx * g.d + g.b, qm = (1 << g.qs) - 1;
+        const int ty = ky * g.d + g.b, tx = kx * g.d + g.bx, qm = (1 << g.qs) - 1;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int k = min(k0 + (tid & 7) * 4 + i, kmax - 1);
@@ -3559,26 +3559,90 @@ static int conv_split(int M, int N, int K, int groups, int* kps_out) {
     return ix_div_up(K, kps);
 }
 
+// ---- the stride-2 data gradient as stride-1 convolutions, one per parity class of the input pixels -------------------------
+// dx[y][x] of a stride-2 convolution only receives the taps with (y + pad - ky) and (x + pad - kx) even: gathered over all
+// input pixels (kind 1, qs = 1) three of four requested taps are the out-of-range zeros and the kernel still multiplies them
+// (measured, tools/gemm_census.py: 69 TFLOP/s of useful work where the stride-1 convolutions of the same size run 245-275).
+// Pixels (2i + py, 2j + px) of one parity class all see the SAME taps ky = ky0 + 2a, kx = kx0 + 2b, and over the class grid
+// (i, j) that is a plain stride-1 convolution of dy with the sub-kernel, taps flipped:
+//     dx[2i+py][2j+px][c] = sum_{a'',b'',co} dy[i - pad_y + a''][j - pad_x + b''][co] * wt[c][a''][b''][co]
+//     wt[c][a''][b''][co] = w[co][ky0 + 2 (nky-1-a'')][kx0 + 2 (nkx-1-b'')][c],   pad_y = nky - 1 - (py + pad - ky0) / 2
+// (3x3, pad 1: sub-kernels 1x1 / 1x2 / 2x1 / 2x2 with pads 0 -- 9 taps instead of 36; the 1x1 stride-2 downsample: one class
+// with one tap, the other three are zero).  The regrouped weights and the class outputs live in the call's scratch; one
+// interleaving pass writes dx (every element, so no memset).  Needs a workspace; without one the one-launch form runs.
+static int g_conv_s2_split = -1;   // IX_CONV_S2_SPLIT=0: keep the one-launch form (A/B runs)
+extern "C" int ix_conv_set_s2_split(int on) {
+    g_conv_s2_split = on ? 1 : 0;
+    return IX_OK;
+}
+static bool conv_s2_split_enabled() {
+    if (g_conv_s2_split < 0) {
+        const char* e = getenv("IX_CONV_S2_SPLIT");
+        g_conv_s2_split = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_conv_s2_split != 0;
+}
+struct S2Axis {
+    int n, k0, pad, len;   // taps of the class along this axis, the first of them, the sub-convolution's pad, the class grid's extent
+};
+static S2Axis s2_axis(int extent, int parity, int K, int pad) {
+    S2Axis x;
+    x.k0 = (parity + pad) & 1;
+    x.n = x.k0 < K ? (K - 1 - x.k0) / 2 + 1 : 0;
+    x.pad = x.n - 1 - (parity + pad - x.k0) / 2;
+    x.len = extent > parity ? (extent - parity + 1) / 2 : 0;
+    return x;
+}
+struct S2Plan {
+    S2Axis ay[4], ax[4];
+    int64_t w_off[4], y_off[4];   // element offsets of the class's regrouped weights / output in their regions
+    int64_t w_elems, y_elems;
+    size_t planes;                // split-K planes: the largest any class launch needs
+};
+static size_t round256(size_t b) { return (b + 255) / 256 * 256; }
+static S2Plan s2_plan(int groups, int imgs, int H, int W, int Cin, int Cout, int KH, int KW, int pad) {
+    S2Plan p;
+    p.w_elems = p.y_elems = 0;
+    p.planes = 0;
+    for (int c = 0; c < 4; ++c) {
+        p.ay[c] = s2_axis(H, c >> 1, KH, pad);
+        p.ax[c] = s2_axis(W, c & 1, KW, pad);
+        p.w_off[c] = p.w_elems;
+        p.y_off[c] = p.y_elems;
+        const int64_t taps = (int64_t)p.ay[c].n * p.ax[c].n, px = (int64_t)p.ay[c].len * p.ax[c].len;
+        if (taps == 0 || px == 0) continue;
+        p.w_elems += (int64_t)groups * Cin * taps * Cout;
+        p.y_elems += (int64_t)groups * imgs * px * Cin;
+        int kps;
+        const int M = (int)(imgs * px), K = (int)(taps * Cout);
+        const size_t b = splitk_plane_bytes(conv_split(M, Cin, K, groups, &kps), groups, groups, M, Cin);
+        if (b > p.planes) p.planes = b;
+    }
+    return p;
+}
+static bool conv_takes_s2_split(int kind, int stride, int dil, int H, int W) {
+    return kind == 1 && stride == 2 && dil == 1 && H >= 2 && W >= 2 && conv_s2_split_enabled();
+}
+
 extern "C" int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout,
-                                                int KH, int KW, size_t* out) {
+                                                int KH, int KW, int stride, int pad, int dil, size_t* out) {
     IX_CHECK_ARG(out != nullptr && kind >= 0 && kind <= 2, "ix_workspace_bytes_conv_gemm_f32: bad args");
     int M, N, K, kps;
     conv_gemm_dims(kind, imgs, H, W, Cin, OH, OW, Cout, KH * KW, &M, &N, &K);
     *out = splitk_plane_bytes(conv_split(M, N, K, groups, &kps), groups, groups, M, N);
+    if (conv_takes_s2_split(kind, stride, dil, H, W)) {   // whichever form runs when the call is issued (ix_conv_set_s2_split)
+        const S2Plan p = s2_plan(groups, imgs, H, W, Cin, Cout, KH, KW, pad);
+        const size_t b = round256(p.planes) + round256((size_t)p.w_elems * 4) + round256((size_t)p.y_elems * 4);
+        if (b > *out) *out = b;
+    }
     if (*out) *out += IX_TICKET_BYTES;
     return IX_OK;
 }
 
-extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W,
-                                int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
-                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    IX_CHECK_ARG(src && other && out, "ix_conv_gemm_f32: null operand");
-    IX_CHECK_ARG(kind >= 0 && kind <= 2, "ix_conv_gemm_f32: kind %d", kind);
-    IX_CHECK_ARG(ix_conv_gemm_supported(groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil),
-                 "ix_conv_gemm_f32: unsupported geometry (Cin %d, Cout %d must be multiples of 64; stride %d in {1, 2, 4}; a group's "
-                 "tensors below 2 GiB) -- use ix_im2col_f32 + ix_gemm_f32",
-                 Cin, Cout, stride);
-    IX_CHECK_ARG(aligned16(src) && aligned16(other) && aligned16(out), "ix_conv_gemm_f32: operands must be 16-byte aligned");
+// one convolution kind as ONE launch of the gathering kernel (+ its split-K reduction); `planes` = split-K scratch (past the tickets)
+static int conv_gemm_core(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W, int Cin,
+                          int OH, int OW, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int dil, void* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
     const int T = KH * KW;
     const int qs = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
     GemmArgs a;
@@ -3606,7 +3670,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         a.sAo = x_slice; a.sBo = w_slice; a.sCo = y_slice;
         a.extA = x_slice; a.extB = w_slice;
         g.mode_a = 1;
-        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad_y; g.bx = -pad_x; g.d = dil; g.qs = 0;
         a_kc = 1; b_kc = 1;
     } else if (kind == 1) {   // dx = conv^T(dy, w):  A = dy gathered over input pixels, B rows (tap, co) remapped into w
         a.A = src; a.B = other; a.C = out;
@@ -3615,7 +3679,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         a.sAo = y_slice; a.sBo = w_slice; a.sCo = x_slice;
         a.extA = y_slice; a.extB = w_slice;
         g.mode_a = 1; g.mode_b = 3;
-        g.gH = H; g.gW = W; g.sH = OH; g.sW = OW; g.sC = Cout; g.a = 1; g.b = pad; g.d = -dil; g.qs = qs;
+        g.gH = H; g.gW = W; g.sH = OH; g.sW = OW; g.sC = Cout; g.a = 1; g.b = pad_y; g.bx = pad_x; g.d = -dil; g.qs = qs;
         g.bmod = Cout; g.btap = Cin; g.dBmod = make_fastdiv(Cout);
         a_kc = 1; b_kc = 0;
     } else {                  // dw = dy^T (x) x:  A = dy^T (co x pixels), B rows = pixels, columns (tap, c) gathered from x
@@ -3625,7 +3689,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         a.sAo = y_slice; a.sBo = x_slice; a.sCo = w_slice;
         a.extA = y_slice; a.extB = x_slice;
         g.mode_b = 2;
-        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad_y; g.bx = -pad_x; g.d = dil; g.qs = 0;
         a_kc = 0; b_kc = 0;
     }
     (void)a_kc; (void)b_kc;
@@ -3640,11 +3704,6 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     const int split = conv_split(a.M, a.N, a.K, groups, &kps);
     a.split_k = split;
     a.k_per_split = kps;
-    if (workspace) {   // [IX_TICKET_BYTES of reduction tickets][scratch], as every entry point
-        IX_CHECK_ARG(workspace_bytes >= IX_TICKET_BYTES && aligned16(workspace), "ix_conv_gemm_f32: workspace below %d bytes or unaligned", IX_TICKET_BYTES);
-        workspace = static_cast<char*>(workspace) + IX_TICKET_BYTES;
-        workspace_bytes -= IX_TICKET_BYTES;
-    }
     SplitReal real;
     {
         const int rc = splitk_begin(a, groups, groups, false, workspace, workspace_bytes, real, "ix_conv_gemm_f32", stream);
@@ -3672,6 +3731,98 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
     prof_mark(stream);
     IX_CHECK_LAUNCH("ix_conv_gemm_f32");
     return IX_OK;
+}
+
+// wt[g][c][tap'][co] = w[g][co][ky][kx][c] for the taps of one parity class: [co][c] -> [c][co] through a 32 x 33 LDS tile
+__global__ __launch_bounds__(256) void conv_s2_regroup_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin, int Cout,
+                                                              int KW, int T, int nky, int nkx, int ky0, int kx0) {
+    __shared__ float tile[32][33];
+    const int taps = nky * nkx, gz = blockIdx.z / taps, tp = blockIdx.z - gz * taps;
+    const int a = tp / nkx, b = tp - a * nkx;
+    const int tap = (ky0 + 2 * (nky - 1 - a)) * KW + kx0 + 2 * (nkx - 1 - b);
+    const int c0 = blockIdx.x * 32, co0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = w + ((int64_t)gz * Cout * T + tap) * Cin;            // + co * T * Cin + c
+    float* dst = wt + ((int64_t)gz * Cin * taps + tp) * Cout;               // + c * taps * Cout + co
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(int64_t)(co0 + r) * T * Cin + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) dst[(int64_t)(c0 + r) * taps * Cout + co0 + tx] = tile[tx][r];
+}
+
+struct S2Interleave {
+    const float* cls[4];   // class outputs [groups*imgs][len_y][len_x][Cin]; null: the class has no taps (zeros)
+    int ly[4], lx[4];
+};
+__global__ __launch_bounds__(256) void conv_s2_interleave_kernel(S2Interleave s, float* __restrict__ dx, int H, int W, int C4,
+                                                                 int64_t total4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += stride) {
+        const int c4 = (int)(t % C4);
+        const int64_t pix = t / C4;
+        const int x = (int)(pix % W);
+        const int64_t r = pix / W;
+        const int y = (int)(r % H);
+        const int64_t img = r / H;
+        const int c = ((y & 1) << 1) | (x & 1);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s.cls[c])
+            v = reinterpret_cast<const float4*>(s.cls[c])[((img * s.ly[c] + (y >> 1)) * s.lx[c] + (x >> 1)) * C4 + c4];
+        reinterpret_cast<float4*>(dx)[t] = v;
+    }
+}
+
+static int conv_bwd_data_s2(const float* dy, const float* w, float* dx, int groups, int imgs, int H, int W, int Cin, int OH, int OW,
+                            int Cout, int KH, int KW, int pad, const S2Plan& p, char* scratch, hipStream_t stream) {
+    char* planes = scratch;
+    float* wt = reinterpret_cast<float*>(scratch + round256(p.planes));
+    float* ys = reinterpret_cast<float*>(scratch + round256(p.planes) + round256((size_t)p.w_elems * 4));
+    S2Interleave il;
+    for (int c = 0; c < 4; ++c) {
+        const S2Axis &ay = p.ay[c], &ax = p.ax[c];
+        il.cls[c] = nullptr;
+        il.ly[c] = ay.len; il.lx[c] = ax.len;
+        if (ay.n * ax.n == 0 || ay.len * ax.len == 0) continue;
+        float* wc = wt + p.w_off[c];
+        float* yc = ys + p.y_off[c];
+        il.cls[c] = yc;
+        hipLaunchKernelGGL(conv_s2_regroup_kernel, dim3(Cin / 32, Cout / 32, groups * ay.n * ax.n), dim3(256), 0, stream, w, wc, Cin,
+                           Cout, KW, KH * KW, ay.n, ax.n, ay.k0, ax.k0);
+        // the class as a forward convolution: source dy [imgs][OH][OW][Cout], "Cin" = Cout, "Cout" = Cin, output grid len_y x len_x
+        const int rc = conv_gemm_core(0, dy, wc, yc, groups, imgs, OH, OW, Cout, ay.len, ax.len, Cin, ay.n, ax.n, 1, ay.pad, ax.pad, 1,
+                                      p.planes ? planes : nullptr, p.planes, stream);
+        if (rc != IX_OK) return rc;
+    }
+    const int64_t total4 = (int64_t)groups * imgs * H * W * Cin / 4;
+    hipLaunchKernelGGL(conv_s2_interleave_kernel, dim3(ix_grid_1d(total4, 256)), dim3(256), 0, stream, il, dx, H, W, Cin / 4, total4);
+    IX_CHECK_LAUNCH("ix_conv_gemm_f32 (stride-2 data gradient)");
+    return IX_OK;
+}
+
+extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W,
+                                int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    IX_CHECK_ARG(src && other && out, "ix_conv_gemm_f32: null operand");
+    IX_CHECK_ARG(kind >= 0 && kind <= 2, "ix_conv_gemm_f32: kind %d", kind);
+    IX_CHECK_ARG(ix_conv_gemm_supported(groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil),
+                 "ix_conv_gemm_f32: unsupported geometry (Cin %d, Cout %d must be multiples of 64; stride %d in {1, 2, 4}; a group's "
+                 "tensors below 2 GiB) -- use ix_im2col_f32 + ix_gemm_f32",
+                 Cin, Cout, stride);
+    IX_CHECK_ARG(aligned16(src) && aligned16(other) && aligned16(out), "ix_conv_gemm_f32: operands must be 16-byte aligned");
+    if (workspace) {   // [IX_TICKET_BYTES of reduction tickets][scratch], as every entry point
+        IX_CHECK_ARG(workspace_bytes >= IX_TICKET_BYTES && aligned16(workspace), "ix_conv_gemm_f32: workspace below %d bytes or unaligned", IX_TICKET_BYTES);
+        workspace = static_cast<char*>(workspace) + IX_TICKET_BYTES;
+        workspace_bytes -= IX_TICKET_BYTES;
+    }
+    if (workspace && conv_takes_s2_split(kind, stride, dil, H, W)) {
+        const S2Plan p = s2_plan(groups, imgs, H, W, Cin, Cout, KH, KW, pad);
+        const size_t need = round256(p.planes) + round256((size_t)p.w_elems * 4) + round256((size_t)p.y_elems * 4);
+        if (workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0)
+            return conv_bwd_data_s2(src, other, out, groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, pad, p, static_cast<char*>(workspace),
+                                    stream);
+    }
+    return conv_gemm_core(kind, src, other, out, groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, pad, dil, workspace,
+                          workspace_bytes, stream);
 }
 
 // ---- contraction + frozen-BN affine (+ residual) (+ ReLU) as ONE launch where the kernel can take it -------------------------

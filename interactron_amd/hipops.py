@@ -1852,7 +1852,7 @@ def _conv_gemm(kind, src, other, out_shape, cg):
     if nws is None:
         n = ctypes.c_size_t(0)
         _chk(_L().ix_workspace_bytes_conv_gemm_f32(kind, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW,
-                                                   ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
+                                                   cg.stride, cg.pad, cg.dil, ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
         nws = _conv_ws[(kind, cg)] = n.value
     ws = _workspace(nws, src.device) if nws else None
     _chk(_L().ix_conv_gemm_f32(kind, src.data_ptr(), other.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin,
@@ -1933,7 +1933,7 @@ class ConvFwdBnAct(Function):
         if nws is None:
             n = ctypes.c_size_t(0)
             _chk(_L().ix_workspace_bytes_conv_gemm_f32(0, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW,
-                                                       ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
+                                                       cg.stride, cg.pad, cg.dil, ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_f32")
             nws = _conv_ws[(0, cg)] = n.value
         ws = _workspace(nws, x.device) if nws else None
         _chk(_L().ix_conv_gemm_bn_act_f32(x.data_ptr(), w.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH,

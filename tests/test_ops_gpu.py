@@ -1037,6 +1037,44 @@ def test_episode_batched_linear_layernorm_rowvec(ops):
              lambda a, v: (a.reshape(E, 5, 64) + v[:, None, :]).reshape(E * 5, 64), [a, v], name="grouped add_rowvec")
 
 
+@pytest.mark.parametrize("cin,cout,k,pad,h,w,n,E", [
+    (128, 128, 3, 1, 20, 21, 3, 1),    # even x odd extent: the odd-column classes have one column fewer
+    (64, 128, 3, 1, 9, 9, 2, 2),       # odd x odd, per-episode weights
+    (256, 128, 1, 0, 15, 16, 2, 1),    # the 1 x 1 downsample: one class with one tap, three classes of zeros
+    (64, 64, 7, 3, 18, 14, 1, 1),      # a stem-shaped kernel: sub-kernels 3x3 / 3x4 / 4x3 / 4x4 with pad 1
+    (64, 64, 2, 0, 12, 10, 2, 2),      # an even kernel: every class sees exactly one tap
+    (64, 64, 3, 0, 11, 13, 1, 1)])     # no padding: classes with a negative sub-convolution pad do not occur, grids differ
+@pytest.mark.usefixtures("kernel_form")
+def test_stride2_data_gradient_as_parity_classes(ops, cin, cout, k, pad, h, w, n, E):
+    """csrc/gemm.hip conv_bwd_data_s2: the data gradient of a stride-2 convolution as one stride-1 convolution per parity
+    class of the input pixels (only the taps that reach the class) + an interleaving pass, against F.conv_transpose-style
+    float64 autograd AND against the one-launch gather of the same call (ix_conv_set_s2_split(0))."""
+    g = ops.conv_geom(n, h, w, cin, k, k, 2, pad, 1)
+    cg = ops.ConvGemmGeom(E, n // E, h, w, cin, g.OH, g.OW, cout, k, k, 2, pad, 1)
+    assert ops.conv_gemm_supported(cg)
+    dy = rnd(n, g.OH, g.OW, cout, seed=3).cuda()
+    wt = rnd(E, cout, k, k, cin, seed=4, scale=(cin * k * k) ** -0.5).cuda()
+    x64 = torch.zeros(n, h, w, cin, dtype=torch.float64, requires_grad=True)
+    per = n // E
+    y64 = torch.cat([F.conv2d(x64[e * per:(e + 1) * per].permute(0, 3, 1, 2), wt[e].cpu().double().permute(0, 3, 1, 2), None, 2, pad)
+                     for e in range(E)]).permute(0, 2, 3, 1)
+    ref, = torch.autograd.grad(y64, x64, dy.cpu().double())
+    lib = ops._L()
+    try:
+        lib.ix_conv_set_s2_split(1)
+        ops._conv_ws.clear()
+        got = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
+        lib.ix_conv_set_s2_split(0)
+        ops._conv_ws.clear()
+        one = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
+    finally:
+        lib.ix_conv_set_s2_split(1)
+        ops._conv_ws.clear()
+    close(one, ref, what="one-launch gather vs float64")
+    close(got, ref, what="parity classes vs float64")
+    close(got, one, what="parity classes vs one-launch gather")
+
+
 @pytest.mark.usefixtures("kernel_form")
 def test_episode_batched_conv(ops):
     E, n, cin, cout = 2, 4, 8, 12
