@@ -153,10 +153,11 @@ int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out,
 /* scratch of one convolution kind: split-K planes (deterministic ordered reduction, as ix_gemm_f32_ws; workspace NULL =
  * atomics) and, for the stride-2 data gradient, the regrouped weights + per-parity-class outputs of its stride-1 form
  * (csrc/gemm.hip conv_bwd_data_s2: dx of a stride-2 convolution as four stride-1 convolutions of dy, 9 taps instead of 36 for
- * a 3x3; without a workspace, or after ix_conv_set_s2_split(0) / IX_CONV_S2_SPLIT=0, the one-launch gather runs) */
+ * a 3x3; without a workspace, below the size where it pays, or after ix_conv_set_s2_split(0) / IX_CONV_S2_SPLIT=0 the one-launch
+ * gather runs) */
 int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
                                      int KW, int stride, int pad, int dil, size_t* out_host);
-int ix_conv_set_s2_split(int on);
+int ix_conv_set_s2_split(int mode); /* 0 never, 1 where it pays (default: >= 40 GFLOP executed by the one-launch form, 4 for a 1x1), 2 always */
 
 int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,
                   int64_t sxc, int KH, int KW, int stride, int pad, int dil, int Kp, ix_stream_t stream);

@@ -1091,9 +1091,11 @@ extern "C" int ix_flash_set_m16(int on) {
 }
 static inline bool fl_m16(int hd, int form) { return g_fl_m16 && hd == 64 && form == 1; }
 
-static int fl_common(FlashArgs& a, const char* who, const float* bias, int n, int H, int L, int Lp, int S, int Sp, int hd,
+// bias == NULL ("no key is masked") is taken by the head-dim-64 fp16-form passes of flash16.hip only: they then neither load nor
+// add a bias and blank the keys >= S of the last tile themselves
+static int fl_common(FlashArgs& a, const char* who, const float* bias, bool m16, int n, int H, int L, int Lp, int S, int Sp, int hd,
                      float scale, float p_drop, uint64_t seed) {
-    IX_CHECK_ARG(bias != nullptr, "%s: null key bias", who);
+    IX_CHECK_ARG(bias != nullptr || m16, "%s: null key bias (only the head-dim-64 fp16-form kernels run without one)", who);
     IX_CHECK_ARG(hd == 32 || hd == 64, "%s: head dim %d (32 or 64)", who, hd);
     IX_CHECK_ARG(S > 0 && Lp % 128 == 0 && Sp % 128 == 0 && Lp >= L && Sp >= S, "%s: bad padded sizes", who);
     IX_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: p=%f outside [0,1)", who, p_drop);
@@ -1134,7 +1136,7 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     IX_CHECK_ARG(!out || (v && (m16 ? v->row != nullptr : v->tr != nullptr)), "ix_flash_fwd_f32: v planes missing (%s)", m16 ? "row" : "tr");
     IX_CHECK_ARG(FL_OUT_OK(ld_out, off_out) && ((uintptr_t)out & 15) == 0, "ix_flash_fwd_f32: output rows must be 16-byte aligned");
     FlashArgs a;
-    const int rc = fl_common(a, "ix_flash_fwd_f32", bias, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
+    const int rc = fl_common(a, "ix_flash_fwd_f32", bias, m16, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
     if (rc) return rc;
     a.q_row = (const unsigned short*)q->row; a.q_us = q->unscale;
     a.k_row = (const unsigned short*)k->row; a.k_us = k->unscale;
@@ -1179,7 +1181,7 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     IX_CHECK_ARG(gq || (gk && gv), "ix_flash_bwd_f32: no output requested");
     IX_CHECK_ARG(FL_OUT_OK(ld_q, off_q) && FL_OUT_OK(ld_k, off_k) && FL_OUT_OK(ld_v, off_v), "ix_flash_bwd_f32: output rows must be 16-byte aligned");
     FlashArgs a;
-    const int rc = fl_common(a, "ix_flash_bwd_f32", bias, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
+    const int rc = fl_common(a, "ix_flash_bwd_f32", bias, m16, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
     if (rc) return rc;
     a.q_row = (const unsigned short*)q->row; a.q_us = q->unscale; a.q_tr = (const unsigned short*)q->tr;
     a.do_row = (const unsigned short*)d_out->row; a.do_us = d_out->unscale; a.do_tr = (const unsigned short*)d_out->tr;
@@ -1236,7 +1238,7 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
         return IX_ERR_WORKSPACE;
     }
     FlashArgs a;
-    const int rc = fl_common(a, "ix_flash_bwd_bwd_f32", bias, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
+    const int rc = fl_common(a, "ix_flash_bwd_bwd_f32", bias, m16, n, H, L, Lp, S, Sp, hd, scale, p_drop, seed);
     if (rc) return rc;
 #define FL_SET(NAME, SRC) a.NAME##_row = (const unsigned short*)(SRC)->row; a.NAME##_us = (SRC)->unscale; a.NAME##_tr = (const unsigned short*)(SRC)->tr;
     FL_SET(q, q) FL_SET(k, k) FL_SET(v, v) FL_SET(do, d_out) FL_SET(hq, hq) FL_SET(hk, hk) FL_SET(hv, hv)

@@ -25,6 +25,7 @@
 //   * the passes that run one workgroup per CU (gK / gV, dq / ddO, dk / dv) separate vector and matrix work in time and run
 //     the two halves of the workgroup in opposite segments over a ring of four tiles -- see "split-phase passes" below.
 #include "flash_common.h"
+#include <type_traits>
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -222,11 +223,39 @@ __device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, 
 // into wave-uniform constants: gy = M o gd -> P o gy = pm (gd cg / keep), M o HD likewise, and products whose whole [L, S]
 // operand carries an M (Pd, HgD) take 1 / keep in their conversion scale.
 #define M16_PM(B, R, X) (DROP ? (kp[B][R] ? (X) : 0.f) : (X))
+// Key bias.  BIAS: the additive bias row of the batch entry ([n][Sp]: 0 / -inf, padded keys and the tail).  !BIAS (no bias
+// pointer: no key is masked): nothing is loaded or added -- a query-owning pass sends the scores of keys >= S of its LAST tile
+// to -inf itself (P = 0 there; the other tile kinds are finite, the planes are zero beyond S), a key-owning pass needs nothing:
+// owner keys >= S are never stored.
+#define M16_KB_LOAD(KB, T0)                                                                                  \
+    f32x4 KB[2];                                                                                             \
+    if (BIAS) {                                                                                              \
+        KB[0] = *reinterpret_cast<const f32x4*>(bias + (T0) + 4 * g);                                        \
+        KB[1] = *reinterpret_cast<const f32x4*>(bias + (T0) + 16 + 4 * g);                                   \
+    }
+#define M16_TAIL_KEYS(SC, T0)                                                                                \
+    if (!BIAS && LAST) {                                                                                     \
+        _Pragma("unroll") for (int blk_ = 0; blk_ < 2; ++blk_) _Pragma("unroll") for (int r_ = 0; r_ < 4; ++r_) \
+            if ((T0) + 16 * blk_ + 4 * g + r_ >= p.S) SC[blk_][r_] = -INFINITY;                              \
+    }
+// The tile loop of a query-owning pass: with a bias every tile is the same; without one the LAST tile is peeled off (its copy
+// of the body carries the blanking of keys >= S; a branch inside the loop body would cut the block the compiler schedules the
+// matrix and the element-wise instructions in).  BODY(t, slot) is a generic lambda taking the tile index, the ring slot and
+// std::bool_constant<LAST>.
+#define M16_TILE_LOOP(BODY, NTILES)                                                                          \
+    if (BIAS) {                                                                                              \
+        for (int t_ = 0; t_ < (NTILES); ++t_) BODY(t_, t_ & 3, std::false_type{});                           \
+    } else {                                                                                                 \
+        for (int t_ = 0; t_ + 1 < (NTILES); ++t_) BODY(t_, t_ & 3, std::false_type{});                       \
+        BODY((NTILES) - 1, ((NTILES) - 1) & 3, std::true_type{});                                            \
+    }
+// log2 P of element (B, R): S cs + (bias - lse2)
+#define M16_ARG(B, R, LSE2) (BIAS ? s[B][R] * cs + (kb[B][R] - (LSE2)) : s[B][R] * cs - (LSE2))
 
 // ============================================================================================================
 // forward: query-owning, streams k (scores) and v (P v, transposed reads); online softmax, one query per lane quadruple
 // ============================================================================================================
-template <bool DROP>
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 2 * M16_OPB;
@@ -257,12 +286,11 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
     F16_STORE(lds)
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](const int t, const int, auto last_tile) {
+        constexpr bool LAST = decltype(last_tile)::value;
         const unsigned char* cur = lds + (t & 1) * BUFB;
         const int t0 = t * 32;
-        f32x4 kb[2];
-        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
-        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        M16_KB_LOAD(kb, t0)
         const float cs = c2 * p.k_us[kbo + t], usv = p.v_us[kbo + t];
         F16_LOAD(min(t0 + 32, ntiles * 32 - 32))
         f32x4 s[2];
@@ -277,13 +305,14 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
             s[0] = m16_mma(k0f[0], qf[ks][1], s[0]); s[1] = m16_mma(k1f[0], qf[ks][1], s[1]);
             s[0] = m16_mma(k0f[0], qf[ks][0], s[0]); s[1] = m16_mma(k1f[0], qf[ks][0], s[1]);
         }
+        M16_TAIL_KEYS(s, t0)
         f32x4 x[2];
         float tmax = -INFINITY;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                x[blk][r] = s[blk][r] * cs + kb[blk][r];
+                x[blk][r] = BIAS ? s[blk][r] * cs + kb[blk][r] : s[blk][r] * cs;
                 tmax = fmaxf(tmax, x[blk][r]);
             }
         {   // the query's maximum over the four lanes that share it
@@ -319,7 +348,8 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
         M16_PRODUCT_BOUNDED(o, cur + M16_OPB, x, 1.f, usv, fo)
         F16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
-    }
+    };
+    M16_TILE_LOOP(tile, ntiles)
 #undef F16_LOAD
 #undef F16_STORE
     lrun += __shfl_xor(lrun, 16, 64);
@@ -337,8 +367,8 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
 // ============================================================================================================
 // backward (algebra in flash.hip): gQ from query-owning workgroups, gK and gV from key-owning ones
 // ============================================================================================================
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
+template <bool DROP, bool BIAS>
+__global__ __launch_bounds__(512, 4) void flash16_bwd_q_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 2 * M16_OPB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
@@ -371,12 +401,11 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
     Q16_STORE(lds)
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](const int t, const int, auto last_tile) {
+        constexpr bool LAST = decltype(last_tile)::value;
         const unsigned char* cur = lds + (t & 1) * BUFB;
         const int t0 = t * 32;
-        f32x4 kb[2];
-        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
-        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        M16_KB_LOAD(kb, t0)
         const float usk = p.k_us[kbo + t];
         const float cs = c2 * usk, cgk = usd * p.v_us[kbo + t] * p.inv_keep;
         Q16_LOAD(min(t0 + 32, ntiles * 32 - 32))
@@ -397,18 +426,20 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
         }
         bool kp[2][4];
         if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
+        M16_TAIL_KEYS(s, t0)
         f32x4 x[2];
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {   // gs = P o (M o gd - t) = pm gd' - P t
-                const float pr = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));
+                const float pr = fl_exp2(M16_ARG(blk, r, lse2));
                 x[blk][r] = M16_PM(blk, r, pr) * (gd[blk][r] * cgk) - pr * dl;
             }
         M16_PRODUCT(gq, cur, x, usk, fq)   // gQ^T[d, query] += K^T[d, key] gs^T[key, query]
         Q16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
-    }
+    };
+    M16_TILE_LOOP(tile, ntiles)
 #undef Q16_LOAD
 #undef Q16_STORE
     if (q < p.L) {
@@ -438,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_q_kernel(FlashArgs p) {
 #define M16_UPPER_HALF (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
 #define M16_NSLOT 4
 
-template <bool DROP>
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 2 * M16_OPB, BUFB = OFF_ST + 256;   // q, dO rows + lse[32], delta[32]
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     M16_BFRAGS(vf, p.v_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
     const int64_t kbk = (int64_t)bh * (p.Sp / 32) + k0 / 32;
     const float c2 = p.scale_log2e * p.k_us[kbk], usv = p.v_us[kbk];
-    const float kbias = p.bias[(int64_t)b * p.Sp + key];
+    const float kbias = BIAS ? p.bias[(int64_t)b * p.Sp + key] : 0.f;
     f32x4 gk[4], gv[4];
     M16_ZERO4(gk)
     M16_ZERO4(gv)
@@ -515,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = fl_exp2(s[blk][r] * cs + (kbias - lse2[blk][r]));
+                const float pr = fl_exp2(BIAS ? s[blk][r] * cs + (kbias - lse2[blk][r]) : s[blk][r] * cs - lse2[blk][r]);
                 pd[blk][r] = M16_PM(blk, r, pr);                                  // (x 1/keep at the end, on gV)
                 gs[blk][r] = pd[blk][r] * (gd[blk][r] * cgk) - pr * dl[blk][r];   // gs = P o (M o gd - t)
             }
@@ -601,9 +632,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
 // element-wise part common to (1) and (2): pr = P, pm = keep ? P : 0, g1 = G, gd = gd cg / keep, hd_ = HD ch / keep
 // (P o gy = pm gd, P o M o HD = pm hd_)
 #define B16_ELEMENTWISE                                                                                      \
-    f32x4 kb[2];                                                                                             \
-    kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);                                              \
-    kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);                                         \
+    M16_KB_LOAD(kb, t0)                                                                                      \
+    M16_TAIL_KEYS(s, t0)                                                                                     \
     const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t]; \
     const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk,     \
                 c3 = p.scale * usq * ushk, chk = usd * ushv * p.inv_keep;                                    \
@@ -611,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
     if (DROP) { M16_MASK_KEYS(kp, rid, t0) }                                                                 \
     f32x4 pr[2], pm[2];                                                                                      \
     _Pragma("unroll") for (int blk = 0; blk < 2; ++blk) _Pragma("unroll") for (int r = 0; r < 4; ++r) {       \
-        pr[blk][r] = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));                                          \
+        pr[blk][r] = fl_exp2(M16_ARG(blk, r, lse2));                                                         \
         pm[blk][r] = M16_PM(blk, r, pr[blk][r]);                                                             \
         g1[blk][r] = g1[blk][r] * c1 + g2[blk][r] * c3;                                                      \
         gd[blk][r] *= cgk;                                                                                   \
@@ -621,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
 // (1) row statistics: two workgroups per CU, double-buffered, one barrier per tile.  u = sum P G and w = sum pm (G gd' + hd') - 2 t u:
 // the two masked sums of w share their multiply by pm.  (Four waves per SIMD asked for explicitly: at two the compiler's schedule
 // of this pass sits at 127-129 registers, and 129 would leave one workgroup per CU.)
-template <bool DROP>
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
@@ -631,32 +661,33 @@ __global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
     B16_LOAD(0)
     B16_STORE(lds)
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](const int t, const int, auto last_tile) {
+        constexpr bool LAST = decltype(last_tile)::value;
         const unsigned char* cur = lds + (t & 1) * BUFB;
         const int t0 = t * 32;
         B16_LOAD(min(t0 + 32, last))
         f32x4 s[2], gd[2], g1[2], g2[2], hd_[2];
         B16_PHASE1(cur)
-        f32x4 kb[2];
-        kb[0] = *reinterpret_cast<const f32x4*>(bias + t0 + 4 * g);
-        kb[1] = *reinterpret_cast<const f32x4*>(bias + t0 + 16 + 4 * g);
+        M16_KB_LOAD(kb, t0)
         const float usk = p.k_us[kbo + t], ushk = p.hk_us[kbo + t], usv = p.v_us[kbo + t], ushv = p.hv_us[kbo + t];
         const float cs = p.scale_log2e * usq * usk, cgk = usd * usv * p.inv_keep, c1 = p.scale * ushq * usk,
                     c3 = p.scale * usq * ushk, chk = usd * ushv * p.inv_keep;
         bool kp[2][4];
         if (DROP) { M16_MASK_KEYS(kp, rid, t0) }
+        M16_TAIL_KEYS(s, t0)
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {   // w = sum pm (G gd' + hd') - 2 t u: the two masked sums as one
-                const float pr = fl_exp2(s[blk][r] * cs + (kb[blk][r] - lse2));
+                const float pr = fl_exp2(M16_ARG(blk, r, lse2));
                 const float G = g1[blk][r] * c1 + g2[blk][r] * c3;
                 uu += pr * G;
                 ab += M16_PM(blk, r, pr) * (G * (gd[blk][r] * cgk) + hd_[blk][r] * chk);
             }
         B16_STORE(lds + ((t + 1) & 1) * BUFB)
         __syncthreads();
-    }
+    };
+    M16_TILE_LOOP(tile, ntiles)
     uu += __shfl_xor(uu, 16, 64); uu += __shfl_xor(uu, 32, 64);
     ab += __shfl_xor(ab, 16, 64); ab += __shfl_xor(ab, 32, 64);
     if (g == 0) {   // (padded queries: P = 0 -> zeros; the whole [BH][Lp] workspace is written)
@@ -666,7 +697,7 @@ __global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
 }
 
 // (2) dq (o1), ddO (o4): split-phase
-template <bool DROP>
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
@@ -689,7 +720,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
     if (live) { B16_PHASE1(lds) }
     __syncthreads();
 
-    for (int t = 0, slot = 0; t < ntiles; ++t, slot = (slot + 1) & 3) {
+    auto tile = [&](const int t, const int slot, auto last_tile) {
+        constexpr bool LAST = decltype(last_tile)::value;
         const unsigned char* cur = lds + slot * BUFB;
         const int t0 = t * 32;
         M16_STAMP(0)
@@ -735,7 +767,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
         M16_STAMP(3)
         __syncthreads();
         M16_STAMP(4)
-    }
+    };
+    M16_TILE_LOOP(tile, ntiles)
     M16_LAG_IF(!M16_UPPER_HALF)
     if (q < p.L) {
         float* d1 = p.o1 + ((int64_t)b * p.L + q) * p.ld1 + p.off1 + h * 64 + 4 * g;
@@ -753,7 +786,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
 #undef B16_ELEMENTWISE
 
 // (3) dk (o2), dv (o3): split-phase, key-owning
-template <bool DROP>
+template <bool DROP, bool BIAS>
 __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 3 * M16_OPB, BUFB = OFF_ST + 512;   // q, hq, dO rows + lse, delta, u, w [32] each
@@ -771,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
     M16_BFRAGS(hvf, p.hv_row, ((int64_t)bh * p.Sp + key) * 64 + 8 * g, p.k_plane)
     const int64_t kbk = (int64_t)bh * (p.Sp / 32) + k0 / 32;
     const float usk = p.k_us[kbk], ushk = p.hk_us[kbk], usv = p.v_us[kbk], ushv = p.hv_us[kbk];
-    const float kbias = p.bias[(int64_t)b * p.Sp + key];
+    const float kbias = BIAS ? p.bias[(int64_t)b * p.Sp + key] : 0.f;
     f32x4 dk[4], dv[4];
     M16_ZERO4(dk)
     M16_ZERO4(dv)
@@ -847,7 +880,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pr = fl_exp2(s[blk][r] * cs + (kbias - lse2[blk][r]));
+                const float pr = fl_exp2(BIAS ? s[blk][r] * cs + (kbias - lse2[blk][r]) : s[blk][r] * cs - lse2[blk][r]);
                 const float pm = M16_PM(blk, r, pr);
                 const float G = g1[blk][r] * c1 + g2[blk][r] * c3, gdk = gd[blk][r] * cgk, hdk = hd_[blk][r] * chk;
                 x1[blk][r] = pm * gdk - pr * dl[blk][r];                                              // gs
@@ -895,11 +928,13 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
 // launchers (called from the C-ABI entry points of flash.hip when hd == 64 and the operands carry the fp16 form)
 // ------------------------------------------------------------------------------------------------------------
 #define M16_LAUNCH(KERNEL, GRID)                                                                             \
-    if (a.thr16) hipLaunchKernelGGL((KERNEL<true>), GRID, dim3(512), 0, stream, a);                          \
-    else hipLaunchKernelGGL((KERNEL<false>), GRID, dim3(512), 0, stream, a);
-#define M16_LAUNCH2(KERNEL, ST, GRID)                                                                        \
-    if (a.thr16) hipLaunchKernelGGL((KERNEL<true, ST>), GRID, dim3(512), 0, stream, a);                      \
-    else hipLaunchKernelGGL((KERNEL<false, ST>), GRID, dim3(512), 0, stream, a);
+    if (a.bias) {                                                                                            \
+        if (a.thr16) hipLaunchKernelGGL((KERNEL<true, true>), GRID, dim3(512), 0, stream, a);                \
+        else hipLaunchKernelGGL((KERNEL<false, true>), GRID, dim3(512), 0, stream, a);                       \
+    } else {                                                                                                 \
+        if (a.thr16) hipLaunchKernelGGL((KERNEL<true, false>), GRID, dim3(512), 0, stream, a);               \
+        else hipLaunchKernelGGL((KERNEL<false, false>), GRID, dim3(512), 0, stream, a);                      \
+    }
 
 void fl16_launch_fwd(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_fwd_kernel, grid) }
 void fl16_launch_bwd_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_q_kernel, grid) }

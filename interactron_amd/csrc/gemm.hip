@@ -3570,17 +3570,17 @@ static int conv_split(int M, int N, int K, int groups, int* kps_out) {
 // (3x3, pad 1: sub-kernels 1x1 / 1x2 / 2x1 / 2x2 with pads 0 -- 9 taps instead of 36; the 1x1 stride-2 downsample: one class
 // with one tap, the other three are zero).  The regrouped weights and the class outputs live in the call's scratch; one
 // interleaving pass writes dx (every element, so no memset).  Needs a workspace; without one the one-launch form runs.
-static int g_conv_s2_split = -1;   // IX_CONV_S2_SPLIT=0: keep the one-launch form (A/B runs)
-extern "C" int ix_conv_set_s2_split(int on) {
-    g_conv_s2_split = on ? 1 : 0;
+static int g_conv_s2_split = -1;   // 0: never (A/B runs), 1: where it pays (default), 2: always (tests); IX_CONV_S2_SPLIT
+extern "C" int ix_conv_set_s2_split(int mode) {
+    g_conv_s2_split = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return IX_OK;
 }
-static bool conv_s2_split_enabled() {
+static int conv_s2_split_mode() {
     if (g_conv_s2_split < 0) {
         const char* e = getenv("IX_CONV_S2_SPLIT");
-        g_conv_s2_split = (e && e[0] == '0') ? 0 : 1;
+        g_conv_s2_split = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
     }
-    return g_conv_s2_split != 0;
+    return g_conv_s2_split;
 }
 struct S2Axis {
     int n, k0, pad, len;   // taps of the class along this axis, the first of them, the sub-convolution's pad, the class grid's extent
@@ -3620,8 +3620,15 @@ static S2Plan s2_plan(int groups, int imgs, int H, int W, int Cin, int Cout, int
     }
     return p;
 }
-static bool conv_takes_s2_split(int kind, int stride, int dil, int H, int W) {
-    return kind == 1 && stride == 2 && dil == 1 && H >= 2 && W >= 2 && conv_s2_split_enabled();
+// ... where it pays: the class form is 2 (one class with taps) to 9 launches instead of one.  Measured break-even
+// (tools/conv_s2_bench.py, tools/gemm_census.py): ~ 30 GFLOP executed by the one-launch form for a 3x3 (16 frames of 75 x 75 x
+// 128: 75 us either way), far lower when a single class has taps (the 1x1 downsample: one quarter-size contraction + the zeros).
+static bool conv_takes_s2_split(int kind, int stride, int dil, int groups, int imgs, int H, int W, int Cin, int Cout, int KH, int KW) {
+    const int mode = conv_s2_split_mode();
+    if (!(kind == 1 && stride == 2 && dil == 1 && H >= 2 && W >= 2 && mode != 0)) return false;
+    if (mode == 2) return true;
+    const double executed = 2.0 * groups * imgs * H * W * (double)Cin * Cout * KH * KW;
+    return executed >= ((KH == 1 && KW == 1) ? 4e9 : 40e9);
 }
 
 extern "C" int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout,
@@ -3630,7 +3637,7 @@ extern "C" int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, 
     int M, N, K, kps;
     conv_gemm_dims(kind, imgs, H, W, Cin, OH, OW, Cout, KH * KW, &M, &N, &K);
     *out = splitk_plane_bytes(conv_split(M, N, K, groups, &kps), groups, groups, M, N);
-    if (conv_takes_s2_split(kind, stride, dil, H, W)) {   // whichever form runs when the call is issued (ix_conv_set_s2_split)
+    if (conv_takes_s2_split(kind, stride, dil, groups, imgs, H, W, Cin, Cout, KH, KW)) {   // whichever form runs when the call is issued (ix_conv_set_s2_split)
         const S2Plan p = s2_plan(groups, imgs, H, W, Cin, Cout, KH, KW, pad);
         const size_t b = round256(p.planes) + round256((size_t)p.w_elems * 4) + round256((size_t)p.y_elems * 4);
         if (b > *out) *out = b;
@@ -3814,7 +3821,7 @@ extern "C" int ix_conv_gemm_f32(int kind, const float* src, const float* other, 
         workspace = static_cast<char*>(workspace) + IX_TICKET_BYTES;
         workspace_bytes -= IX_TICKET_BYTES;
     }
-    if (workspace && conv_takes_s2_split(kind, stride, dil, H, W)) {
+    if (workspace && conv_takes_s2_split(kind, stride, dil, groups, imgs, H, W, Cin, Cout, KH, KW)) {
         const S2Plan p = s2_plan(groups, imgs, H, W, Cin, Cout, KH, KW, pad);
         const size_t need = round256(p.planes) + round256((size_t)p.w_elems * 4) + round256((size_t)p.y_elems * 4);
         if (workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255) == 0)

@@ -813,6 +813,7 @@ class _PlanesC(ctypes.Structure):   # struct ix_attn_planes of include/interactr
 # since round 3); "bf16" = tr form 0, three bf16 planes and six instructions.  Both carry the parity record (tests/conftest.py
 # kernel_form).  Read when an operand is split; the derivative passes follow the form their forward was split with.
 FLASH_TR = _os.environ.get("IX_FLASH_TR", "f16")
+FLASH_NOBIAS = _os.environ.get("IX_FLASH_NOBIAS", "1") == "1"   # "0": always hand the kernels a key-bias tensor (A/B runs)
 _TR_FORMS = {"bf16": 0, "f16": 1}
 
 
@@ -986,6 +987,10 @@ def attn_split_fp8(x, n, R, ld, off, H, hd, row=True, tr=False):
     return rowp, trp, us
 
 
+def _bias_ptr(pl):
+    return pl["bias"].data_ptr() if pl["bias"] is not None else None
+
+
 def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
     """-> (out [n, L, H*hd], lse [n*H, Lp] (+inf beyond L), operand planes) for geometry g (AttnGeom).
     dtype "fp8": the two forward products on e4m3 operands (ATTENTION_DTYPE); the planes for the derivative kernels are
@@ -993,7 +998,10 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
     dev = q.device
     dtype = dtype or ATTENTION_DTYPE
     fp8 = dtype == "fp8"
-    pl = {"bias": attn_bias(mask, g.n, g.S, dev)}
+    # no key mask + the head-dim-64 fp16-form kernels (csrc/flash16.hip): no bias tensor at all (NULL: they blank the keys beyond
+    # S of the last tile themselves and skip the bias loads / adds of every other tile)
+    no_bias = FLASH_NOBIAS and mask is None and not fp8 and _rows_only(g.hd, _TR_FORMS[FLASH_TR])
+    pl = {"bias": None if no_bias else attn_bias(mask, g.n, g.S, dev)}
     if need_backward or not fp8:
         pl["q"], pl["k"], pl["v"] = attn_split_multi([(q, g.L, g.q_ld, g.q_off, True, need_backward),
                                                       (k, g.S, g.k_ld, g.k_off, True, need_backward),
@@ -1012,7 +1020,7 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
             _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, None, pl["bias"].data_ptr(), None, lse.data_ptr(), g.n, g.heads,
                                        g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, 0.0, 0, _stream()), "ix_flash_fwd_f32")
         return out, lse, pl
-    _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(),
+    _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, _bias_ptr(pl), out.data_ptr(), lse.data_ptr(),
                                g.n, g.heads, g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_f32")
     return out, lse, pl
 
@@ -1081,7 +1089,7 @@ class FlashAttentionBwd(Function):
         _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
                                      _stream()), "ix_attn_rowdot_f32")
         gq, gk, gv = _grad_buffers(g, q, k, v, same_qk)
-        _chk(_L().ix_flash_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, dop.ref, pl["bias"].data_ptr(), lse.data_ptr(),
+        _chk(_L().ix_flash_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, dop.ref, _bias_ptr(pl), lse.data_ptr(),
                                    delta.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
                                    g.hd, g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, g.scale, p, seed, _stream()),
              "ix_flash_bwd_f32")
@@ -1116,7 +1124,7 @@ class FlashAttentionBwd(Function):
         _chk(_L().ix_workspace_bytes_flash_bwd_bwd(g.n, g.heads, g.L, ctypes.byref(need)), "ix_workspace_bytes_flash_bwd_bwd")
         ws = torch.empty(need.value // 4, dtype=torch.float32, device=dev)
         _chk(_L().ix_flash_bwd_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, pl["do"].ref, hqp.ref, hkp.ref, hvp.ref,
-                                       pl["bias"].data_ptr(), lse.data_ptr(), pl["delta"].data_ptr(), dq.data_ptr(),
+                                       _bias_ptr(pl), lse.data_ptr(), pl["delta"].data_ptr(), dq.data_ptr(),
                                        dk.data_ptr(), dv.data_ptr(), ddo.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp, g.hd,
                                        g.q_ld, g.q_off, g.k_ld, g.k_off, g.v_ld, g.v_off, E, 0, g.scale, ctx.p, ctx.seed,
                                        ws.data_ptr(), need.value, _stream()), "ix_flash_bwd_bwd_f32")

@@ -1061,7 +1061,7 @@ def test_stride2_data_gradient_as_parity_classes(ops, cin, cout, k, pad, h, w, n
     ref, = torch.autograd.grad(y64, x64, dy.cpu().double())
     lib = ops._L()
     try:
-        lib.ix_conv_set_s2_split(1)
+        lib.ix_conv_set_s2_split(2)   # (2: also below the size where the library would choose it)
         ops._conv_ws.clear()
         got = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
         lib.ix_conv_set_s2_split(0)

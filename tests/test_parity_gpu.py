@@ -992,3 +992,21 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libinteractron_hip.so")
     with pytest.raises(_lib.HipLibraryError):
         _lib.load()
+
+
+def test_meta_train_step_with_the_stride2_data_gradients_in_class_form():
+    """The smoke step (one episode at 128 x 128 against the CPU oracle: losses 2e-3, every gradient tensor's direction and norm)
+    with csrc/gemm.hip conv_bwd_data_s2 FORCED (ix_conv_set_s2_split(2)): at this size the library would keep the one-launch
+    gather, at the bench sizes it takes the per-parity-class form for layer2.0 / layer3.0 conv2 and the layer3.0 downsample --
+    first- and second-order backward."""
+    import __graft_entry__ as entry
+    from interactron_amd import hipops
+    lib = hipops._L()
+    try:
+        lib.ix_conv_set_s2_split(2)
+        hipops._conv_ws.clear()
+        res = entry.smoke_check(128)
+    finally:
+        lib.ix_conv_set_s2_split(1)
+        hipops._conv_ws.clear()
+    assert res["checked"] >= 300
