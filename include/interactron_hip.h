@@ -299,6 +299,9 @@ int ix_workspace_bytes_layernorm_bwd(int64_t rows, int D, int groups, size_t* ou
  *   call must share one form.
  * ix_attn_bias_f32: key_padding_mask uint8 [n][mask_ld] (nonzero = ignore; null = none) -> additive bias [n][Sb],
  *   Sb >= S (the kernels want S rounded up to 128): 0 for valid keys, -inf for masked keys and the tail.
+ *   bias == NULL in ix_flash_fwd / bwd / bwd_bwd_f32 means "no key is masked" and is taken by the head-dim-64 fp16-form
+ *   passes (csrc/flash16.hip) only: they skip the bias loads and adds and blank the keys >= S of the last tile themselves;
+ *   every other kernel family needs the tensor (IX_ERR_ARG otherwise).
  * ix_flash_fwd_f32: out [n][L][ld_out] (head h at off_out + h*hd), lse [n*H][Lp] (natural-log softmax normalisers; rows
  *   L..Lp are written as +inf so that padded query rows count as P = 0 in the derivative kernels).
  *   p_drop / seed: dropout on the probabilities, mask = pure function of (seed, batch*head, query, key).
