@@ -1169,6 +1169,36 @@ def test_flash_attention_first_order_against_float64(ops, n, H, L, S, hd, masked
         close(a, b, 3e-5, "flash grad " + name)
 
 
+@pytest.mark.parametrize("L,S,pdrop", [(300, 300, 0.1), (130, 517, 0.0), (64, 2060, 0.1)])
+def test_flash_without_a_bias_tensor_equals_the_bias_path(ops, L, S, pdrop):
+    """Head dim 64, no key mask: hipops hands the 16x16x32 passes bias = NULL (no bias loads / adds, keys >= S of the last tile
+    blanked in a peeled copy of the tile body).  Same arithmetic as adding a zero bias: forward, backward and double backward
+    must equal the bias path (FLASH_NOBIAS = False) to rounding -- key counts that are not multiples of the 32-key tile."""
+    if not ops.flash_m16():
+        pytest.skip("the 16x16x32 family is switched off")
+    n, H, hd = 1, 4, 64
+    E = H * hd
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    q, k, v, gy = rnd(n, L, E, seed=1), rnd(n, S, E, seed=2), rnd(n, S, E, seed=3), rnd(n, L, E, seed=5)
+    hs = [rnd(n, L, E, seed=6), rnd(n, S, E, seed=7), rnd(n, S, E, seed=8)]
+    res = {}
+    old = ops.FLASH_NOBIAS
+    try:
+        for flag in (True, False):
+            ops.FLASH_NOBIAS = flag
+            x = [t.cuda().requires_grad_(True) for t in (q, k, v)]
+            gyh = gy.cuda().requires_grad_(True)
+            out = ops.FlashAttention.apply(x[0], x[1], x[2], g, None, pdrop, 77)
+            g1 = torch.autograd.grad(out, x, gyh, create_graph=True)
+            g2 = torch.autograd.grad(sum((a * h.cuda()).sum() for a, h in zip(g1, hs)), x + [gyh])
+            res[flag] = [out.detach()] + [t.detach() for t in g1] + list(g2)
+    finally:
+        ops.FLASH_NOBIAS = old
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        close(a, b, 1e-6, "no-bias vs bias path, tensor %d" % i)
+
+
 @pytest.mark.usefixtures("flash_form")
 def test_flash_attention_packed_qk_buffer(ops):
     """q and k read out of one [n, L, 2E] projection buffer (nn.MultiheadAttention self-attention with q = k input):
