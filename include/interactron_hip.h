@@ -157,7 +157,8 @@ int ix_conv_gemm_f32(int kind, const float* src, const float* other, float* out,
  * gather runs) */
 int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
                                      int KW, int stride, int pad, int dil, size_t* out_host);
-int ix_conv_set_s2_split(int mode); /* 0 never, 1 where it pays (default: >= 40 GFLOP executed by the one-launch form, 4 for a 1x1), 2 always */
+int ix_conv_set_s2_split(int mode); /* 0 never, 1 where it pays (default: >= 40 GFLOP executed by the one-launch form, 4 for a 1x1), 2 always;
+                                         | 4: class outputs through scratch + the interleaving pass even where a class can write dx in place */
 
 int ix_im2col_f32(const float* x, float* cols, int n, int H, int W, int C, int64_t sxn, int64_t sxh, int64_t sxw,
                   int64_t sxc, int KH, int KW, int stride, int pad, int dil, int Kp, ix_stream_t stream);

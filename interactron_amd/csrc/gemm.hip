@@ -62,6 +62,10 @@ struct ConvGather {
     int gH, gW, sH, sW, sC;
     int a, b, bx, d, qs, KW;   // (b: row offset, bx: column offset -- equal except in the parity classes of conv_bwd_data_s2)
     int bmod, btap;
+    // C row map of a parity-class launch of conv_bwd_data_s2 (cmap != 0; forward-kind kernel, fp16x3 form, no split-K): output
+    // row m = (img, i, j) of the class grid gH x gW is pixel (2 i + cpy, 2 j + cpx) of the cH x cW image -- the class writes its
+    // pixels of dx in place
+    int cmap, cH, cW, cpy, cpx;
     FastDiv dW, dHW, dC, dKW, dBmod;   // divisions by gW, gH * gW, sC, KW, bmod
 };
 
@@ -1776,7 +1780,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
 // ------------------------------------------------------------------------------------------------------------
 typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
 
-template <bool A_KC, bool B_KC, int GA = 0, int GB = 0, bool ONE = false>
+template <bool A_KC, bool B_KC, int GA = 0, int GB = 0, bool ONE = false, bool CMAP = false>
 __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, int total_items) {
     constexpr int BN = 128, BM = X6_BT, ROWB = X6_ROWB, NC = 4;
     constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 2 * (PLANE_A + PLANE_B);
@@ -1798,6 +1802,17 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
     int w = xcd * per_xcd + (blockIdx.x >> 3);
     if (w >= last) return;
     const bool staged = !p.atomic && p.c_vec;
+    // (CMAP, a separate instance of the forward-kind convolution kernel: the row of C a tile row goes to when the launch is a parity
+    //  class of conv_bwd_data_s2 writing its pixels of dx in place, ConvGather::cmap.  Separate because the same code behind a
+    //  run-time flag cost the plain forward convolutions 10 %.)
+    static_assert(!CMAP || (GA == 1 && GB == 0), "row map: forward-kind convolution only");
+    auto crow = [&](int m) -> int {
+        if (!CMAP) return m;
+        const int img = fd_div(m, p.cg.dHW), rem = m - img * (p.cg.gH * p.cg.gW);
+        const int ci = fd_div(rem, p.cg.dW), cj = rem - ci * p.cg.gW;
+        return (img * p.cg.cH + 2 * ci + p.cg.cpy) * p.cg.cW + 2 * cj + p.cg.cpx;
+    };
+#define X3_CROW(M_) crow(M_)
 
     if (wave >= NC + 4) {
         x6q_produce<BN, BN, B_KC, true, false, GB, true, ONE, PIPE3>(p, w, stride, last, &lds[0][0], BUF, 2 * PLANE_A, tid - (NC + 4) * 64,
@@ -2106,7 +2121,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const int c = lane + 64 * q;
-                        *reinterpret_cast<float4*>(it.C + (int64_t)(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
+                        *reinterpret_cast<float4*>(it.C + (int64_t)X3_CROW(r0 + c / CPR) * p.ldc + c0 + (c % CPR) * 4) = v[q];
                     }
                 } else {
 #pragma unroll
@@ -2116,7 +2131,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
                         const int gr = r0 + row, gc = c0 + col;
                         if (gr >= p.M || gc >= p.N) continue;
                         const float* src = &ct[row * CP + col];
-                        float* dst = it.C + (int64_t)gr * p.ldc + gc;
+                        float* dst = it.C + (int64_t)X3_CROW(gr) * p.ldc + gc;
                         dst[0] = src[0];
                         if (gc + 1 < p.N) dst[1] = src[1];
                         if (gc + 2 < p.N) dst[2] = src[2];
@@ -2157,6 +2172,7 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
 #undef X3Q_SLICE
 #undef X3Q_EXPO
 #endif
+#undef X3_CROW
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -3508,6 +3524,11 @@ static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t s
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
+    if (x3 && BN == 128 && a.cg.cmap) {   // a parity class of conv_bwd_data_s2 written in place (forward kind)
+        if (g_single_pass) hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, true, true>), grid, dim3(768), 0, stream, a, items);
+        else hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, false, true>), grid, dim3(768), 0, stream, a, items);
+        return;
+    }
     if (x3 && BN == 128 && g_single_pass) {   // ... its single-pass form (MODEL.COMPUTE_DTYPE: bf16 / fp16)
         if (kind == 0)
             hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, true>), grid, dim3(768), 0, stream, a, items);
@@ -3570,8 +3591,11 @@ static int conv_split(int M, int N, int K, int groups, int* kps_out) {
 // (3x3, pad 1: sub-kernels 1x1 / 1x2 / 2x1 / 2x2 with pads 0 -- 9 taps instead of 36; the 1x1 stride-2 downsample: one class
 // with one tap, the other three are zero).  The regrouped weights and the class outputs live in the call's scratch; one
 // interleaving pass writes dx (every element, so no memset).  Needs a workspace; without one the one-launch form runs.
+static int g_conv_s2_in_place = 1;   // ix_conv_set_s2_split(mode | 4): classes through scratch + interleave even where the row map applies (A/B, tests)
 static int g_conv_s2_split = -1;   // 0: never (A/B runs), 1: where it pays (default), 2: always (tests); IX_CONV_S2_SPLIT
 extern "C" int ix_conv_set_s2_split(int mode) {
+    g_conv_s2_in_place = (mode >= 0 && (mode & 4)) ? 0 : 1;
+    if (mode >= 0) mode &= 3;
     g_conv_s2_split = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return IX_OK;
 }
@@ -3647,15 +3671,24 @@ extern "C" int ix_workspace_bytes_conv_gemm_f32(int kind, int groups, int imgs, 
 }
 
 // one convolution kind as ONE launch of the gathering kernel (+ its split-K reduction); `planes` = split-K scratch (past the tickets)
+struct S2Map {   // a parity class written in place: the full image extent, the class's parities, elements of one group's dx
+    int H, W, py, px;
+    int64_t x_slice;
+};
+static bool conv_uses_x3(int kind, int N, int Cin) {   // the fp16x3 form of the gathering kernel (128-wide N tiles)
+    const int bn = (kind == 2 ? (Cin % 128 == 0) : (N > 64)) ? 128 : 64;
+    return bn == 128 && x3k_enabled() && g_x6 == 3;
+}
 static int conv_gemm_core(int kind, const float* src, const float* other, float* out, int groups, int imgs, int H, int W, int Cin,
                           int OH, int OW, int Cout, int KH, int KW, int stride, int pad_y, int pad_x, int dil, void* workspace,
-                          size_t workspace_bytes, hipStream_t stream) {
+                          size_t workspace_bytes, hipStream_t stream, const S2Map* map = nullptr) {
     const int T = KH * KW;
     const int qs = stride == 1 ? 0 : (stride == 2 ? 1 : 2);
     GemmArgs a;
     a.cg = ConvGather();
     ConvGather& g = a.cg;
     g.mode_a = g.mode_b = 0;
+    g.cmap = 0; g.cH = g.cW = g.cpy = g.cpx = 0;
     a.rowsum = nullptr;
     a.sRowsum = 0;
     g.KW = KW;
@@ -3711,6 +3744,10 @@ static int conv_gemm_core(int kind, const float* src, const float* other, float*
     const int split = conv_split(a.M, a.N, a.K, groups, &kps);
     a.split_k = split;
     a.k_per_split = kps;
+    if (map) {   // (the caller checked: forward kind, fp16x3 form, no split-K)
+        g.cmap = 1; g.cH = map->H; g.cW = map->W; g.cpy = map->py; g.cpx = map->px;
+        a.sCo = map->x_slice;
+    }
     SplitReal real;
     {
         const int rc = splitk_begin(a, groups, groups, false, workspace, workspace_bytes, real, "ix_conv_gemm_f32", stream);
@@ -3760,6 +3797,7 @@ __global__ __launch_bounds__(256) void conv_s2_regroup_kernel(const float* __res
 struct S2Interleave {
     const float* cls[4];   // class outputs [groups*imgs][len_y][len_x][Cin]; null: the class has no taps (zeros)
     int ly[4], lx[4];
+    int in_place;          // bit c: class c wrote its pixels of dx itself (ConvGather::cmap) -- leave them alone
 };
 __global__ __launch_bounds__(256) void conv_s2_interleave_kernel(S2Interleave s, float* __restrict__ dx, int H, int W, int C4,
                                                                  int64_t total4) {
@@ -3772,6 +3810,7 @@ __global__ __launch_bounds__(256) void conv_s2_interleave_kernel(S2Interleave s,
         const int y = (int)(r % H);
         const int64_t img = r / H;
         const int c = ((y & 1) << 1) | (x & 1);
+        if ((s.in_place >> c) & 1) continue;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s.cls[c])
             v = reinterpret_cast<const float4*>(s.cls[c])[((img * s.ly[c] + (y >> 1)) * s.lx[c] + (x >> 1)) * C4 + c4];
@@ -3784,24 +3823,38 @@ static int conv_bwd_data_s2(const float* dy, const float* w, float* dx, int grou
     char* planes = scratch;
     float* wt = reinterpret_cast<float*>(scratch + round256(p.planes));
     float* ys = reinterpret_cast<float*>(scratch + round256(p.planes) + round256((size_t)p.w_elems * 4));
+    // In place where the launch can carry a row map (fp16x3 form of the forward-kind kernel, no split-K): the class writes its
+    // pixels of dx itself and the interleaving pass only has the pixels of classes without taps left (none for a 3 x 3).
+    bool direct = conv_uses_x3(0, Cin, Cout) && g_conv_s2_in_place != 0;
+    for (int c = 0; c < 4 && direct; ++c) {
+        const int64_t taps = (int64_t)p.ay[c].n * p.ax[c].n, px = (int64_t)p.ay[c].len * p.ax[c].len;
+        int kps;
+        if (taps && px && conv_split((int)(imgs * px), Cin, (int)(taps * Cout), groups, &kps) > 1) direct = false;
+    }
     S2Interleave il;
+    il.in_place = 0;
+    int left = 0;   // classes the interleaving pass still has to write
     for (int c = 0; c < 4; ++c) {
         const S2Axis &ay = p.ay[c], &ax = p.ax[c];
         il.cls[c] = nullptr;
         il.ly[c] = ay.len; il.lx[c] = ax.len;
-        if (ay.n * ax.n == 0 || ay.len * ax.len == 0) continue;
+        if (ay.len * ax.len == 0) continue;
+        if (ay.n * ax.n == 0) { ++left; continue; }
         float* wc = wt + p.w_off[c];
         float* yc = ys + p.y_off[c];
         il.cls[c] = yc;
+        if (direct) il.in_place |= 1 << c; else ++left;
         hipLaunchKernelGGL(conv_s2_regroup_kernel, dim3(Cin / 32, Cout / 32, groups * ay.n * ax.n), dim3(256), 0, stream, w, wc, Cin,
                            Cout, KW, KH * KW, ay.n, ax.n, ay.k0, ax.k0);
         // the class as a forward convolution: source dy [imgs][OH][OW][Cout], "Cin" = Cout, "Cout" = Cin, output grid len_y x len_x
-        const int rc = conv_gemm_core(0, dy, wc, yc, groups, imgs, OH, OW, Cout, ay.len, ax.len, Cin, ay.n, ax.n, 1, ay.pad, ax.pad, 1,
-                                      p.planes ? planes : nullptr, p.planes, stream);
+        const S2Map map = {H, W, c >> 1, c & 1, (int64_t)imgs * H * W * Cin};
+        const int rc = conv_gemm_core(0, dy, wc, direct ? dx : yc, groups, imgs, OH, OW, Cout, ay.len, ax.len, Cin, ay.n, ax.n, 1, ay.pad,
+                                      ax.pad, 1, p.planes ? planes : nullptr, p.planes, stream, direct ? &map : nullptr);
         if (rc != IX_OK) return rc;
     }
     const int64_t total4 = (int64_t)groups * imgs * H * W * Cin / 4;
-    hipLaunchKernelGGL(conv_s2_interleave_kernel, dim3(ix_grid_1d(total4, 256)), dim3(256), 0, stream, il, dx, H, W, Cin / 4, total4);
+    if (left)
+        hipLaunchKernelGGL(conv_s2_interleave_kernel, dim3(ix_grid_1d(total4, 256)), dim3(256), 0, stream, il, dx, H, W, Cin / 4, total4);
     IX_CHECK_LAUNCH("ix_conv_gemm_f32 (stride-2 data gradient)");
     return IX_OK;
 }

@@ -1061,9 +1061,12 @@ def test_stride2_data_gradient_as_parity_classes(ops, cin, cout, k, pad, h, w, n
     ref, = torch.autograd.grad(y64, x64, dy.cpu().double())
     lib = ops._L()
     try:
-        lib.ix_conv_set_s2_split(2)   # (2: also below the size where the library would choose it)
+        lib.ix_conv_set_s2_split(2)   # (2: also below the size where the library would choose it; classes written in place)
         ops._conv_ws.clear()
         got = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
+        lib.ix_conv_set_s2_split(2 | 4)   # (| 4: classes through scratch + the interleaving pass)
+        ops._conv_ws.clear()
+        via = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
         lib.ix_conv_set_s2_split(0)
         ops._conv_ws.clear()
         one = ops._conv_gemm(1, dy, wt if E > 1 else wt[0], (n, h, w, cin), cg)
@@ -1073,6 +1076,7 @@ def test_stride2_data_gradient_as_parity_classes(ops, cin, cout, k, pad, h, w, n
     close(one, ref, what="one-launch gather vs float64")
     close(got, ref, what="parity classes vs float64")
     close(got, one, what="parity classes vs one-launch gather")
+    assert torch.equal(got, via), "classes written in place vs through the interleaving pass: same launches, same bits"
 
 
 @pytest.mark.usefixtures("kernel_form")
