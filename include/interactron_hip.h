@@ -185,6 +185,10 @@ int ix_gemm_bn_act_f32(const float* A, const float* B, float* C, int M, int N, i
 int ix_conv_gemm_bn_act_f32(const float* x, const float* w, float* y, int groups, int imgs, int H, int W, int Cin, int OH, int OW,
                             int Cout, int KH, int KW, int stride, int pad, int dil, const float* scale, const float* shift,
                             const float* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+/* out[o][n][r] = x[o][n][r] * scale[n] (R % 4 == 0): the frozen-BN scale applied to a weight tensor [(E,) N, R] or to its gradient --
+ * what the backward of convolution + FrozenBatchNorm2d needs when the scale sits on the weight side (dx = g (W o scale),
+ * dW = scale o (g^T x)) instead of on the activation-sized gradient (models/detr_models/backbone.py:44-54 under autograd) */
+int ix_row_scale_f32(const float* x, const float* scale, float* out, int64_t outer, int N, int64_t R, ix_stream_t stream);
 int ix_channel_affine_f32(const float* x, const float* scale, const float* shift, const float* residual, float* out,
                           int64_t n, int C, int relu, ix_stream_t stream);
 

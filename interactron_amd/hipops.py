@@ -1665,6 +1665,44 @@ class ChannelScale(Function):
         return ChannelScale.call(g, scale), None
 
 
+class RowScale(Function):
+    """w * scale[n] along the output-channel dim of a weight tensor -- linear [(E,) N, K] (tail = 1), convolution
+    [(E,) Cout, KH, KW, Cin] (tail = 3) -- or of its gradient; scale is a constant buffer.  The result keeps standing for the
+    Parameter in skip_param_grads and on the weight-planes route."""
+
+    @staticmethod
+    def forward(ctx, w, scale, tail):
+        key = _param_key(w)
+        marked = getattr(w, "_ix_weight", False)
+        w = _req(w, "weight")
+        N = w.shape[-(tail + 1)]
+        R = _numel(w.shape[-tail:])
+        out = torch.empty_like(w)
+        _chk(_L().ix_row_scale_f32(w.data_ptr(), scale.data_ptr(), out.data_ptr(), w.numel() // (N * R), N, R, _stream()),
+             "ix_row_scale_f32")
+        ctx.tail = tail
+        ctx.save_for_backward(scale)
+        out._ix_of_param = key
+        if marked:
+            mark_weight(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        return RowScale.call(g.contiguous(), scale, ctx.tail), None, None
+
+
+# IX_BN_SCALE_ON_WEIGHTS: "1" (default) = the backward of a fused contraction + frozen-BN node applies the BN scale to the weights
+# (dx = g (W o scale), dW = scale o (g^T x): two passes over a weight tensor) where it would otherwise run a pass over the
+# activation-sized gradient (no ReLU, or ReLU behind a residual: the bottleneck tails and the downsample branches); "0" = g o scale
+BN_SCALE_ON_WEIGHTS = os.environ.get("IX_BN_SCALE_ON_WEIGHTS", "1") == "1"
+
+
+def _bn_scale_on_weights(relu, has_res, w, tail):
+    return BN_SCALE_ON_WEIGHTS and (has_res or not relu) and _numel(w.shape[-tail:]) % 4 == 0
+
+
 class ReluBwdChannelScale(Function):
     """[y > 0] * g * scale[c]: linear in g, so it is its own second-order form."""
 
@@ -1749,8 +1787,17 @@ class GemmBnAct(Function):
         a, b, scale, y = ctx.saved_tensors
         need_a = ctx.needs_input_grad[0] and not _is_unwanted(ctx.a_key, _unwanted)
         need_b = ctx.needs_input_grad[1] and not _is_unwanted(ctx.b_key, _unwanted)
-        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, need_a or need_b, ctx.needs_input_grad[4])
         da = db = None
+        if _bn_scale_on_weights(ctx.relu, ctx.has_res, b, 1):
+            g = g.contiguous()
+            g1 = ReluBwd.call(g, y) if ctx.relu else g
+            gres = g1 if (ctx.has_res and ctx.needs_input_grad[4]) else None
+            if need_a:
+                da = _gemm_backward(ctx.sp, a, RowScale.call(b, scale, 1), ctx.a_shape, ctx.b_shape, g1, True, False)[0]
+            if need_b:
+                db = RowScale.call(_gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, g1, False, True)[1], scale, 1)
+            return da, db, None, None, gres, None, None
+        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, need_a or need_b, ctx.needs_input_grad[4])
         if gz is not None:
             da, db = _gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, gz, need_a, need_b)
         return da, db, None, None, gres, None, None
@@ -1957,8 +2004,17 @@ class ConvFwdBnAct(Function):
     def backward(ctx, g):
         x, w, scale, y = ctx.saved_tensors
         need_w = ctx.needs_input_grad[1] and not _is_unwanted(ctx.w_key, _unwanted)
-        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0] or need_w, ctx.needs_input_grad[4])
         dx = dw = None
+        if _bn_scale_on_weights(ctx.relu, ctx.has_res, w, 3):
+            g = g.contiguous()
+            g1 = ReluBwd.call(g, y) if ctx.relu else g
+            gres = g1 if (ctx.has_res and ctx.needs_input_grad[4]) else None
+            if ctx.needs_input_grad[0]:
+                dx = ConvBwdData.call(g1, RowScale.call(w, scale, 3), ctx.cg)
+            if need_w:
+                dw = RowScale.call(ConvBwdWeight.call(g1, x, ctx.cg, tuple(w.shape)), scale, 3)
+            return dx, dw, None, None, gres, None, None
+        gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0] or need_w, ctx.needs_input_grad[4])
         if gz is not None:
             dx = ConvBwdData.call(gz, w, ctx.cg) if ctx.needs_input_grad[0] else None
             dw = ConvBwdWeight.call(gz, x, ctx.cg, tuple(w.shape)) if need_w else None

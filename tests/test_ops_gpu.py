@@ -261,13 +261,17 @@ def test_implicit_gemm_conv(ops, cin, cout, k, stride, pad, dil, hw, n):
     (128, 256, 1, 2, 0, 15, 2, 2, False, False),  # the stride-2 downsample: affine only, per-episode weights
     (64, 64, 3, 1, 1, 38, 5, 1, False, True),     # enough pixels for an unsplit launch (affine in the kernel's store)
     (64, 128, 1, 1, 0, 75, 4, 1, True, True)])    # enough rows for an unsplit plain contraction
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", [True, False, "scale on the gradient"])
 @pytest.mark.usefixtures("kernel_form")
 def test_conv_bn_act_rides_on_the_contraction(ops, fused, cin, cout, k, stride, pad, hw, n, E, res, relu):
     """hipops.conv2d_nhwc_bn_act -- frozen-BN affine (+ residual) (+ ReLU) riding on the contraction (ix_gemm_bn_act_f32 /
     ix_conv_gemm_bn_act_f32: in the split-K reduction, or the library's own affine launch after an unsplit plan) and as two
     separate nodes -- against float64, with both gradients, the residual's, and the gradients of those (the MAML double
     backward)."""
+    # (fused = True: the backward applies the BN scale to the weights where a pass over the gradient would be needed --
+    #  hipops.RowScale, BN_SCALE_ON_WEIGHTS; "scale on the gradient": the fused forward with the older backward)
+    on_weights, ops.BN_SCALE_ON_WEIGHTS = ops.BN_SCALE_ON_WEIGHTS, fused is True
+    fused = bool(fused)
     old, ops.FUSE_CONV_BN = ops.FUSE_CONV_BN, fused
     try:
         scale = (rnd(cout, seed=31).abs() + 0.5).cuda()
@@ -302,6 +306,7 @@ def test_conv_bn_act_rides_on_the_contraction(ops, fused, cin, cout, k, stride, 
         assert (sum(counts) > 0) == fused, counts
     finally:
         ops.FUSE_CONV_BN = old
+        ops.BN_SCALE_ON_WEIGHTS = on_weights
 
 
 def test_conv_bn_act_reaches_both_places_the_affine_can_run(ops):
