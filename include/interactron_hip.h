@@ -328,6 +328,10 @@ struct ix_attn_planes {
 };
 int ix_attn_split_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R, int Rp,
                       int64_t ld, int off, int H, int hd, ix_stream_t stream);
+/* ix_attn_split_f32 of x with t[bh][row] = sum_d x[row, h, d] y[row, h, d] riding along (t [n*H][Rp], rows R..Rp written as 0): the
+ * backward pass's planes of dO and delta = dO . O from ONE read of dO (instead of ix_attn_split_f32 + ix_attn_rowdot_f32) */
+int ix_attn_split_dot_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R, int Rp,
+                          int64_t ld, int off, int H, int hd, const float* y, int64_t ldy, int offy, float* t, ix_stream_t stream);
 /* up to three operands of one attention call (q, k, v / hq, hk, hv) in ONE launch; arrays of `count` entries, null entries
  * of row_planes / tr_planes as in ix_attn_split_f32 */
 int ix_attn_split_multi_f32(int count, const float* const* x, void* const* row_planes, float* const* row_unscale,

@@ -53,6 +53,12 @@ struct SplitOp {
     float* unscale;
     int R, Rp, off;
     int64_t ld, plane_elems;
+    // optional ride-along (ix_attn_split_dot_f32): t[bh][row] = sum_d x[row, h, d] * y[row, h, d] (delta = dO . O of the backward
+    // pass: the split of dO reads dO anyway), rows R..Rp written as 0
+    const float* dot_y;
+    float* dot_out;
+    int64_t dot_ld;
+    int dot_off;
 };
 struct SplitOps {
     SplitOp op[3];
@@ -83,6 +89,20 @@ __global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, in
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in) t = *reinterpret_cast<const float4*>(src + i);
         v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+    if (o.dot_y) {   // (block-uniform) the TPR threads of a row are consecutive lanes: partial dot products, then a butterfly
+        float d = 0.f;
+        if (in) {
+            const float* ys = o.dot_y + ((int64_t)b * R + r0 + row) * o.dot_ld + o.dot_off + h * HD + c0;
+#pragma unroll
+            for (int i = 0; i < EPT; i += 4) {
+                const float4 t = *reinterpret_cast<const float4*>(ys + i);
+                d += v[i] * t.x + v[i + 1] * t.y + v[i + 2] * t.z + v[i + 3] * t.w;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < TPR; m <<= 1) d += __shfl_xor(d, m, 64);
+        if ((tid % TPR) == 0) o.dot_out[(int64_t)bh * Rp + r0 + row] = d;
     }
     unsigned ph[EPT / 2], pm[EPT / 2], pl[EPT / 2];
     if (rowp || (trp && tr_form == 1)) {
@@ -138,7 +158,8 @@ __global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, in
 
 static int fl_split_launch(const char* who, int count, const float* const* x, void* const* row_planes, float* const* unscale,
                            void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
-                           const int* off, int H, int hd, hipStream_t stream) {
+                           const int* off, int H, int hd, hipStream_t stream, const float* dot_y = nullptr, int64_t dot_ld = 0,
+                           int dot_off = 0, float* dot_out = nullptr) {
     IX_CHECK_ARG(count >= 1 && count <= 3, "%s: %d operands (1..3)", who, count);
     IX_CHECK_ARG(tr_form == 0 || tr_form == 1, "%s: tr_form %d (0 = three bf16 planes, 1 = two fp16 planes)", who, tr_form);
     IX_CHECK_ARG(hd == 32 || hd == 64, "%s: head dim %d (32 or 64)", who, hd);
@@ -157,6 +178,10 @@ static int fl_split_launch(const char* who, int count, const float* const* x, vo
         o.plane_elems = (int64_t)n * H * Rp[i] * hd;
         maxRp = Rp[i] > maxRp ? Rp[i] : maxRp;
     }
+    if (dot_y) {   // rides on operand 0
+        IX_CHECK_ARG(dot_out && dot_ld % 4 == 0 && dot_off % 4 == 0 && ((uintptr_t)dot_y & 15) == 0, "%s: the dot operand's rows must be 16-byte aligned", who);
+        ops.op[0].dot_y = dot_y; ops.op[0].dot_out = dot_out; ops.op[0].dot_ld = dot_ld; ops.op[0].dot_off = dot_off;
+    }
     dim3 grid(maxRp / 32, n * H, count);
     if (hd == 64)
         hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, stream, ops, H, tr_form);
@@ -171,6 +196,17 @@ extern "C" int ix_attn_split_f32(const float* x, void* row_planes, float* row_un
     if (n <= 0 || R <= 0) return IX_OK;
     return fl_split_launch("ix_attn_split_f32", 1, &x, &row_planes, &row_unscale, &tr_planes, tr_form, n, &R, &Rp, &ld, &off, H, hd,
                            stream);
+}
+
+// split of x with t[bh][row] = sum_d x[row, h, d] y[row, h, d] riding along (rows R..Rp of t: 0) -- the backward pass's dO planes and
+// delta = dO . O in one read of dO (ix_attn_split_f32 + ix_attn_rowdot_f32 otherwise)
+extern "C" int ix_attn_split_dot_f32(const float* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R,
+                                     int Rp, int64_t ld, int off, int H, int hd, const float* y, int64_t ldy, int offy, float* t,
+                                     hipStream_t stream) {
+    if (n <= 0 || R <= 0) return IX_OK;
+    IX_CHECK_ARG(y && t, "ix_attn_split_dot_f32: null dot operand / output");
+    return fl_split_launch("ix_attn_split_dot_f32", 1, &x, &row_planes, &row_unscale, &tr_planes, tr_form, n, &R, &Rp, &ld, &off, H, hd,
+                           stream, y, ldy, offy, t);
 }
 
 // the same for up to three operands of one attention call in ONE launch (arrays of `count` entries)

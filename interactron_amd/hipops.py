@@ -813,6 +813,7 @@ class _PlanesC(ctypes.Structure):   # struct ix_attn_planes of include/interactr
 # since round 3); "bf16" = tr form 0, three bf16 planes and six instructions.  Both carry the parity record (tests/conftest.py
 # kernel_form).  Read when an operand is split; the derivative passes follow the form their forward was split with.
 FLASH_TR = _os.environ.get("IX_FLASH_TR", "f16")
+FLASH_SPLIT_DOT = _os.environ.get("IX_FLASH_SPLIT_DOT", "1") == "1"   # "0": delta = dO . O by its own launch (A/B runs)
 FLASH_NOBIAS = _os.environ.get("IX_FLASH_NOBIAS", "1") == "1"   # "0": always hand the kernels a key-bias tensor (A/B runs)
 _TR_FORMS = {"bf16": 0, "f16": 1}
 
@@ -840,8 +841,9 @@ class AttnPlanes:
         self.ref = ctypes.byref(self.c)
 
 
-def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
-    """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> AttnPlanes (Rp = R rounded up to 128)."""
+def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None, dot=None):
+    """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> AttnPlanes (Rp = R rounded up to 128).
+    dot = (y, ldy, offy): also t[n*H, Rp] = sum_d x[.., h, d] * y[.., h, d] from the same read of x -> (AttnPlanes, t)."""
     x = _req(x, "attention operand")
     Rp = _pad128(R)
     dev = x.device
@@ -854,6 +856,13 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None):
     if tr:
         trp = (torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if form == 1 else
                torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev))
+    if dot is not None:
+        y, ldy, offy = dot
+        t = torch.empty(n * H, Rp, dtype=torch.float32, device=dev)
+        _chk(_L().ix_attn_split_dot_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
+                                        trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _req(y).data_ptr(), ldy, offy,
+                                        t.data_ptr(), _stream()), "ix_attn_split_dot_f32")
+        return AttnPlanes(rowp, us, trp, form), t
     _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
                                 trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_f32")
     return AttnPlanes(rowp, us, trp, form)
@@ -1084,10 +1093,13 @@ class FlashAttentionBwd(Function):
         do = _req(do.contiguous(), "attention dO")
         dev = q.device
         Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
-        dop = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd, tr_form=pl["q"].tr_form)
-        delta = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)
-        _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
-                                     _stream()), "ix_attn_rowdot_f32")
+        if FLASH_SPLIT_DOT:   # the planes of dO and delta = dO . O (per query and head) from one read of dO
+            dop, delta = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd, tr_form=pl["q"].tr_form, dot=(out, E, 0))
+        else:
+            dop = attn_split(do, g.n, g.L, E, 0, g.heads, g.hd, tr_form=pl["q"].tr_form)
+            delta = torch.empty(g.n * g.heads, Lp, dtype=torch.float32, device=dev)
+            _chk(_L().ix_attn_rowdot_f32(do.data_ptr(), out.data_ptr(), delta.data_ptr(), g.n, g.heads, g.L, Lp, g.hd, E, 0, E, 0,
+                                         _stream()), "ix_attn_rowdot_f32")
         gq, gk, gv = _grad_buffers(g, q, k, v, same_qk)
         _chk(_L().ix_flash_bwd_f32(pl["q"].ref, pl["k"].ref, pl["v"].ref, dop.ref, _bias_ptr(pl), lse.data_ptr(),
                                    delta.data_ptr(), gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,

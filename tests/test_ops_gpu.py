@@ -1178,6 +1178,27 @@ def test_flash_attention_first_order_against_float64(ops, n, H, L, S, hd, masked
         close(a, b, 3e-5, "flash grad " + name)
 
 
+@pytest.mark.parametrize("n,H,L,hd", [(2, 8, 361, 32), (1, 4, 300, 64), (3, 2, 50, 32)])
+def test_attn_split_with_the_row_dot_riding_along(ops, n, H, L, hd):
+    """ix_attn_split_dot_f32: the planes are those of ix_attn_split_f32 bit for bit, t = sum_d x y per (row, head) agrees with
+    ix_attn_rowdot_f32 and with float64, rows beyond L are zero."""
+    import ctypes
+    E = H * hd
+    x, y = rnd(n, L, E, seed=1).cuda(), rnd(n, L, E, seed=2).cuda()
+    Lp = (L + 127) // 128 * 128
+    plain = ops.attn_split(x, n, L, E, 0, H, hd)
+    both, t = ops.attn_split(x, n, L, E, 0, H, hd, dot=(y, E, 0))
+    assert torch.equal(plain.row, both.row) and torch.equal(plain.unscale, both.unscale)
+    assert (plain.tr is None) == (both.tr is None) and (plain.tr is None or torch.equal(plain.tr, both.tr))
+    ref = (x.double() * y.double()).view(n, L, H, hd).sum(-1).permute(0, 2, 1).reshape(n * H, L)
+    close(t[:, :L], ref, 2e-6, "row dot riding on the split")
+    assert float(t[:, L:].abs().max()) == 0.0 if Lp > L else True
+    t2 = torch.empty(n * H, Lp, device="cuda")
+    assert ops._L().ix_attn_rowdot_f32(x.data_ptr(), y.data_ptr(), t2.data_ptr(), n, H, L, Lp, hd, E, 0, E, 0,
+                                       torch.cuda.current_stream().cuda_stream) == 0
+    close(t, t2, 2e-6, "against ix_attn_rowdot_f32")
+
+
 @pytest.mark.parametrize("L,S,pdrop", [(300, 300, 0.1), (130, 517, 0.0), (64, 2060, 0.1)])
 def test_flash_without_a_bias_tensor_equals_the_bias_path(ops, L, S, pdrop):
     """Head dim 64, no key mask: hipops hands the 16x16x32 passes bias = NULL (no bias loads / adds, keys >= S of the last tile
