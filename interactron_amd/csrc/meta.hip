@@ -27,6 +27,17 @@ __global__ __launch_bounds__(256) void multi_map2_kernel(MultiArgs m, F f) {
     const float* a = m.a[t];
     const float* b = m.b[t];
     float* o = m.o[t];
+    // (16-byte accesses where the three tensors allow it -- they do for every parameter of the detector: at 16 episodes this
+    //  kernel moves 7 GB per step, and with 4-byte accesses it did so at 2.6 TB/s)
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(o)) & 15) == 0) {
+        const int64_t end4 = base + ((end - base) & ~(int64_t)3);
+        for (int64_t k = base + 4 * threadIdx.x; k < end4; k += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(a + k), y = *reinterpret_cast<const float4*>(b + k);
+            *reinterpret_cast<float4*>(o + k) = make_float4(f(x.x, y.x), f(x.y, y.y), f(x.z, y.z), f(x.w, y.w));
+        }
+        for (int64_t k = end4 + threadIdx.x; k < end; k += 256) o[k] = f(a[k], b[k]);
+        return;
+    }
     for (int64_t k = base + threadIdx.x; k < end; k += 256) o[k] = f(a[k], b[k]);
 }
 
@@ -69,6 +80,16 @@ __global__ __launch_bounds__(256) void multi_expand_kernel(MultiArgs m, int E) {
     const int64_t n = m.n[t] / E;
     const float* a = m.a[t];
     float* o = m.o[t];
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(o)) & 15) == 0 && (n & 3) == 0) {
+        // 16-byte copies; the source index wraps by subtraction (one 64-bit remainder per thread instead of one per element)
+        int64_t k = base + 4 * threadIdx.x, sidx = k % n;
+        for (; k < end; k += 1024) {
+            *reinterpret_cast<float4*>(o + k) = *reinterpret_cast<const float4*>(a + sidx);
+            sidx += 1024;
+            while (sidx >= n) sidx -= n;
+        }
+        return;
+    }
     for (int64_t k = base + threadIdx.x; k < end; k += 256) o[k] = a[k % n];
 }
 
@@ -80,6 +101,17 @@ __global__ __launch_bounds__(256) void multi_reduce_kernel(MultiArgs m, int E) {
     const int64_t end = base + MT_CHUNK < n ? base + MT_CHUNK : n;
     const float* a = m.a[t];
     float* o = m.o[t];
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(o)) & 15) == 0 && (n & 3) == 0) {   // (same sums, same order)
+        for (int64_t k = base + 4 * threadIdx.x; k < end; k += 1024) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = 0; e < E; ++e) {
+                const float4 x = *reinterpret_cast<const float4*>(a + (int64_t)e * n + k);
+                s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+            }
+            *reinterpret_cast<float4*>(o + k) = s;
+        }
+        return;
+    }
     for (int64_t k = base + threadIdx.x; k < end; k += 256) {
         float s = 0.f;
         for (int e = 0; e < E; ++e) s += a[(int64_t)e * n + k];

@@ -336,6 +336,9 @@ def test_stem_conv_and_maxpool(ops):
     w = rnd(64, 3, 7, 7, scale=0.1)
     g = ops.conv_geom(2, 37, 41, 3, 7, 7, 2, 3, 1)
     cols = ops.im2col_any_layout(x.cuda(), g, channels_last=False)
+    # (the patch matrix itself, exactly: rows (b, oh, ow), columns (kh, kw, ci), pad columns zero -- four columns per thread)
+    unf = F.unfold(x, 7, 1, 3, 2).view(2, 3, 49, g.OH * g.OW).permute(0, 3, 2, 1).reshape(2 * g.OH * g.OW, 147)
+    assert torch.equal(cols[:, :147].cpu(), unf) and float(cols[:, 147:].abs().max()) == 0.0
     w2 = F.pad(w.permute(0, 2, 3, 1).reshape(64, -1), (0, g.Kp - 147)).cuda()
     y = ops.linear(cols, w2).reshape(2, g.OH, g.OW, 64)
     ref = F.conv2d(x, w, None, 2, 3)
