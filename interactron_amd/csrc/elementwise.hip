@@ -680,22 +680,27 @@ extern "C" int ix_relu_bwd_channel_scale_f32(const float* g, const float* y, con
 // out[o][n][r] = x[o][n][r] * scale[n]: the frozen-BN scale on the WEIGHT side (w [(E,) N, R] with R = K or KH*KW*Cin, R % 4 == 0).
 // hipops.RowScale: the backward of a convolution + frozen BN multiplies the weights (and the weight gradient) by the scale
 // instead of the activation-sized gradient -- a tenth of the bytes even with per-episode weights.
-__global__ void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ scale, float* __restrict__ o, int64_t n4,
-                                 int N, int R4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n4; k += stride) {
-        const float s = scale[(int)((k / R4) % N)];
-        float4 v = reinterpret_cast<const float4*>(x)[k];
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-        reinterpret_cast<float4*>(o)[k] = v;
+__global__ __launch_bounds__(64) void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       float* __restrict__ o, int64_t rows, int N, int R4) {
+    // one wave per weight row (o, n): no per-element index arithmetic, the row's scale read once
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float s = scale[(int)(row % N)];
+        const float4* src = reinterpret_cast<const float4*>(x) + row * R4;
+        float4* dst = reinterpret_cast<float4*>(o) + row * R4;
+        for (int k = threadIdx.x; k < R4; k += 64) {
+            float4 v = src[k];
+            v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+            dst[k] = v;
+        }
     }
 }
 extern "C" int ix_row_scale_f32(const float* x, const float* scale, float* out, int64_t outer, int N, int64_t R, hipStream_t stream) {
     if (outer <= 0 || N <= 0 || R <= 0) return IX_OK;
     IX_CHECK_ARG(x && scale && out && R % 4 == 0 && R / 4 < (1 << 30), "ix_row_scale_f32: null pointer or row length %lld not a multiple of 4", (long long)R);
     IX_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "ix_row_scale_f32: pointers must be 16-byte aligned");
-    const int64_t n4 = outer * N * (R / 4);
-    hipLaunchKernelGGL(row_scale_kernel, dim3(ix_grid_1d(n4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, x, scale, out, n4, N, (int)(R / 4));
+    const int64_t rows = outer * N;
+    hipLaunchKernelGGL(row_scale_kernel, dim3((unsigned)(rows < (1 << 20) ? rows : (1 << 20))), dim3(64), 0, stream, x, scale, out, rows, N,
+                       (int)(R / 4));
     IX_CHECK_LAUNCH("ix_row_scale_f32");
     return IX_OK;
 }
