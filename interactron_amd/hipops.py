@@ -1803,11 +1803,13 @@ class GemmBnAct(Function):
         if _bn_scale_on_weights(ctx.relu, ctx.has_res, b, 1):
             g = g.contiguous()
             g1 = ReluBwd.call(g, y) if ctx.relu else g
-            gres = g1 if (ctx.has_res and ctx.needs_input_grad[4]) else None
+            want_res = ctx.has_res and ctx.needs_input_grad[4]
+            gs = list(fanout(g1, int(need_a) + int(need_b) + int(want_res)))   # (one sum of its consumers' gradients in the outer backward)
+            gres = gs.pop() if want_res else None
             if need_a:
-                da = _gemm_backward(ctx.sp, a, RowScale.call(b, scale, 1), ctx.a_shape, ctx.b_shape, g1, True, False)[0]
+                da = _gemm_backward(ctx.sp, a, RowScale.call(b, scale, 1), ctx.a_shape, ctx.b_shape, gs.pop(), True, False)[0]
             if need_b:
-                db = RowScale.call(_gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, g1, False, True)[1], scale, 1)
+                db = RowScale.call(_gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, gs.pop(), False, True)[1], scale, 1)
             return da, db, None, None, gres, None, None
         gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, need_a or need_b, ctx.needs_input_grad[4])
         if gz is not None:
@@ -2020,11 +2022,13 @@ class ConvFwdBnAct(Function):
         if _bn_scale_on_weights(ctx.relu, ctx.has_res, w, 3):
             g = g.contiguous()
             g1 = ReluBwd.call(g, y) if ctx.relu else g
-            gres = g1 if (ctx.has_res and ctx.needs_input_grad[4]) else None
+            want_res = ctx.has_res and ctx.needs_input_grad[4]
+            gs = list(fanout(g1, int(bool(ctx.needs_input_grad[0])) + int(need_w) + int(want_res)))
+            gres = gs.pop() if want_res else None
             if ctx.needs_input_grad[0]:
-                dx = ConvBwdData.call(g1, RowScale.call(w, scale, 3), ctx.cg)
+                dx = ConvBwdData.call(gs.pop(), RowScale.call(w, scale, 3), ctx.cg)
             if need_w:
-                dw = RowScale.call(ConvBwdWeight.call(g1, x, ctx.cg, tuple(w.shape)), scale, 3)
+                dw = RowScale.call(ConvBwdWeight.call(gs.pop(), x, ctx.cg, tuple(w.shape)), scale, 3)
             return dx, dw, None, None, gres, None, None
         gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0] or need_w, ctx.needs_input_grad[4])
         if gz is not None:

@@ -6,7 +6,7 @@ import bench
 from interactron_amd import Config, build_model
 from interactron_amd.synthetic import load_procedural, synthetic_episodes
 from interactron_amd.trainer import FlatOuterStep
-cfg, _ = bench.model_cfg(300, 50, 16)
+cfg, _ = bench.model_cfg(300, 50, 16, step_graph="off")   # (eager: a replayed graph shows no ATen ops)
 model = build_model(Config(**cfg)); load_procedural(model.fusion, "fusion."); model = model.cuda().train()
 outer = FlatOuterStep(model)
 data = bench.to_gpu(synthetic_episodes(16, height=300, width=300, tag="bench-r0"), torch.device("cuda"))
