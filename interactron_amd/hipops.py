@@ -1520,8 +1520,33 @@ class AddDropout(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and torch.is_grad_enabled() and g.requires_grad:
+            gx, ga = _AddDropoutBwd.apply(g, ctx.p, ctx.seed)   # (recorded: its own backward is ONE add_dropout pass)
+            return gx, ga, None, None
         return (g if ctx.needs_input_grad[0] else None), \
             (_Dropout.call(g, ctx.p, ctx.seed) if ctx.needs_input_grad[1] else None), None, None
+
+
+class _AddDropoutBwd(Function):
+    """g -> (g, dropout(g)): AddDropout's backward as one node, so that the gradient of g in the outer backward is
+    G_x + dropout(G_a) in one pass (add_dropout) instead of a dropout pass and an autograd sum."""
+
+    @staticmethod
+    def forward(ctx, g, p, seed):
+        ctx.set_materialize_grads(False)
+        ctx.p, ctx.seed = p, seed
+        g = _req(g)
+        return g.view_as(g), _Dropout.forward(_NullCtx(), g, p, seed)
+
+    @staticmethod
+    def backward(ctx, Gx, Ga):
+        if Gx is None and Ga is None:
+            return None, None, None
+        if Ga is None:
+            return Gx, None, None
+        if Gx is None:
+            return _Dropout.call(Ga.contiguous(), ctx.p, ctx.seed), None, None
+        return AddDropout.call(Gx.contiguous(), Ga.contiguous(), ctx.p, ctx.seed), None, None
 
 
 def add_dropout(x, a, p, training):

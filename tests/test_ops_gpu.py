@@ -390,6 +390,24 @@ def test_relu_dropout_matches_relu_then_dropout(ops):
     assert 0.25 < float((res[0][0] == 0).float().mean()) < 0.75
 
 
+def test_add_dropout_matches_add_of_dropout_to_second_order(ops):
+    """x + dropout(a) as one pass; its backward is one node (g -> (g, dropout(g))) whose own backward is again ONE add_dropout pass:
+    forward, both gradients and the gradient of a functional of those against the two separate nodes with the same seed."""
+    x, a = rnd(333, 257, seed=1).cuda(), rnd(333, 257, seed=2).cuda()
+    g = rnd(333, 257, seed=3)
+    hx, ha = rnd(333, 257, seed=4).cuda(), rnd(333, 257, seed=5).cuda()
+    res = []
+    for fused in (True, False):
+        xs, as_ = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+        gs = g.cuda().requires_grad_(True)
+        y = ops.AddDropout.apply(xs, as_, 0.3, 4242) if fused else xs + ops._Dropout.apply(as_, 0.3, 4242)
+        gx, ga = torch.autograd.grad(y, [xs, as_], gs, create_graph=True)
+        (gg,) = torch.autograd.grad((gx * hx).sum() + (ga * ha).sum(), gs)
+        res.append((y, gx, ga, gg))
+    for i, (p, q) in enumerate(zip(res[0], res[1])):
+        close(p, q, 1e-6, "add_dropout tensor %d" % i)
+
+
 def test_dropout_is_scaled_mask_and_self_adjoint(ops):
     x = torch.ones(400000).cuda().requires_grad_(True)
     y = ops._Dropout.apply(x, 0.1, 1234567)
