@@ -535,7 +535,9 @@ extern "C" int ix_layernorm_fwd_f32(const float* x, const float* gamma, const fl
 
 // Backward.  g = dy*gamma; dx = r*(g - mean(g) - xhat*mean(g*xhat)); dgamma += dy*xhat; dbeta += dy
 // Column reductions: per-block LDS partials over its 4 rows x many row-groups, then one atomic per column.
-template <int NREG>
+// VEC: a lane owns four consecutive columns per 256-column slab (16-byte loads and stores; D % 4 == 0, 16-byte aligned rows) --
+// register i <-> column 256 (i / 4) + 4 lane + (i % 4); else register i <-> column lane + 64 i
+template <int NREG, bool VEC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, float* __restrict__ dx,
@@ -550,26 +552,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         dy += go * D; x += go * D; dx += go * D; mean += go; rstd += go;
         gamma += (int64_t)blockIdx.y * D; dgamma += (int64_t)blockIdx.y * D; dbeta += (int64_t)blockIdx.y * D;
     }
-    float ag[NREG], ab[NREG];
+    auto col = [&](int i) { return VEC ? 256 * (i >> 2) + 4 * lane + (i & 3) : lane + 64 * i; };
+    float ag[NREG], ab[NREG], gm[NREG];
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) ag[i] = ab[i] = 0.f;
+    for (int i = 0; i < NREG; ++i) {
+        ag[i] = ab[i] = 0.f;
+        gm[i] = col(i) < D ? gamma[col(i)] : 0.f;   // (the same columns in every row of this wave)
+    }
     for (int g = 0; g < row_groups; ++g) {
         const int64_t row = ((int64_t)blockIdx.x * row_groups + g) * ROWS_PER_BLOCK + w;
         if (row >= rows) break;
         const float mu = mean[row], r = rstd[row];
         const float* xr = x + row * D;
         const float* gr = dy + row * D;
-        float xh[NREG], gg[NREG];
+        float xh[NREG], gg[NREG], dv[NREG], xv[NREG];
+        if (VEC) {
+#pragma unroll
+            for (int v = 0; v < NREG / 4; ++v) {
+                const int c0 = 256 * v + 4 * lane;
+                float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f), x4 = d4;
+                if (c0 < D) { d4 = *reinterpret_cast<const float4*>(gr + c0); x4 = *reinterpret_cast<const float4*>(xr + c0); }
+                dv[4 * v] = d4.x; dv[4 * v + 1] = d4.y; dv[4 * v + 2] = d4.z; dv[4 * v + 3] = d4.w;
+                xv[4 * v] = x4.x; xv[4 * v + 1] = x4.y; xv[4 * v + 2] = x4.z; xv[4 * v + 3] = x4.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NREG; ++i) {
+                const int c = lane + 64 * i;
+                dv[i] = c < D ? gr[c] : 0.f;
+                xv[i] = c < D ? xr[c] : 0.f;
+            }
+        }
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) {
-                const float d = gr[c];
-                xh[i] = (xr[c] - mu) * r;
-                gg[i] = d * gamma[c];
-                ag[i] += d * xh[i];
-                ab[i] += d;
+            if (col(i) < D) {
+                xh[i] = (xv[i] - mu) * r;
+                gg[i] = dv[i] * gm[i];
+                ag[i] += dv[i] * xh[i];
+                ab[i] += dv[i];
             } else {
                 xh[i] = gg[i] = 0.f;
             }
@@ -579,16 +600,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         a = ix_wave_sum(a) / D;
         b = ix_wave_sum(b) / D;
         float* o = dx + row * D;
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < NREG; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) o[c] = r * (gg[i] - a - xh[i] * b);
+            for (int v = 0; v < NREG / 4; ++v) {
+                const int c0 = 256 * v + 4 * lane;
+                if (c0 < D)
+                    *reinterpret_cast<float4*>(o + c0) = make_float4(r * (gg[4 * v] - a - xh[4 * v] * b), r * (gg[4 * v + 1] - a - xh[4 * v + 1] * b),
+                                                                    r * (gg[4 * v + 2] - a - xh[4 * v + 2] * b), r * (gg[4 * v + 3] - a - xh[4 * v + 3] * b));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NREG; ++i) {
+                const int c = lane + 64 * i;
+                if (c < D) o[c] = r * (gg[i] - a - xh[i] * b);
+            }
         }
     }
 #pragma unroll
     for (int i = 0; i < NREG; ++i) {
-        sg[w][lane + 64 * i] = ag[i];
-        sb[w][lane + 64 * i] = ab[i];
+        sg[w][col(i)] = ag[i];
+        sb[w][col(i)] = ab[i];
     }
     __syncthreads();
     // column sums over the rows of a group: one partial per workgroup, added in workgroup order by the last one to arrive
@@ -664,10 +695,17 @@ extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float
     if (rc != IX_OK) return rc;
     const int row_groups = ln_row_groups(rows);
     dim3 grid(ln_grid_x(rows), groups), block(256);
-#define LNB(N) hipLaunchKernelGGL(ln_bwd_kernel<N>, grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups, part, tickets)
-    if (D <= 256) LNB(4);
-    else if (D <= 512) LNB(8);
-    else LNB(16);
+#define LNB(N, V) hipLaunchKernelGGL((ln_bwd_kernel<N, V>), grid, block, 0, stream, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, row_groups, part, tickets)
+    const bool vec = D % 4 == 0 && ix_al16(dy) && ix_al16(x) && ix_al16(dx);
+    if (vec) {
+        if (D <= 256) LNB(4, true);
+        else if (D <= 512) LNB(8, true);
+        else LNB(16, true);
+    } else {
+        if (D <= 256) LNB(4, false);
+        else if (D <= 512) LNB(8, false);
+        else LNB(16, false);
+    }
 #undef LNB
     IX_CHECK_LAUNCH("ix_layernorm_bwd_f32");
     return IX_OK;
@@ -680,7 +718,7 @@ extern "C" int ix_layernorm_bwd_f32(const float* dy, const float* x, const float
 //   grad_gamma = sum_rows P(Gx)*dy
 //   Xh         = -r*b*Gx - r*g*m(Gx*xh) + Gg*dy
 //   grad_x     = P(Xh) - r*xh*m(Gx*dx)
-template <int NREG>
+template <int NREG, bool VEC>   // (VEC as in ln_bwd_kernel: four consecutive columns per lane and 256-column slab)
 __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict__ Gx, const float* __restrict__ Gg,
                                                          const float* __restrict__ Gb, const float* __restrict__ dy,
                                                          const float* __restrict__ x, const float* __restrict__ gamma,
@@ -699,9 +737,16 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
         dy += go * D; x += go * D; grad_dy += go * D; grad_x += go * D; mean += go; rstd += go;
         gamma += (int64_t)blockIdx.y * D; grad_gamma += (int64_t)blockIdx.y * D;
     }
-    float ag[NREG];
+    auto col = [&](int i) { return VEC ? 256 * (i >> 2) + 4 * lane + (i & 3) : lane + 64 * i; };
+    float ag[NREG], gm[NREG], ggv[NREG], gbv[NREG];
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) ag[i] = 0.f;
+    for (int i = 0; i < NREG; ++i) {
+        const int c = col(i);
+        ag[i] = 0.f;
+        gm[i] = c < D ? gamma[c] : 0.f;   // (the same columns in every row of this wave)
+        ggv[i] = (Gg && c < D) ? Gg[c] : 0.f;
+        gbv[i] = (Gb && c < D) ? Gb[c] : 0.f;
+    }
     for (int grp = 0; grp < row_groups; ++grp) {
         const int64_t row = ((int64_t)blockIdx.x * row_groups + grp) * ROWS_PER_BLOCK + w;
         if (row >= rows) break;
@@ -709,14 +754,34 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
         const int64_t off = row * D;
         float xh[NREG], g[NREG], gx[NREG], d[NREG];
         float a = 0.f, b = 0.f, mgx = 0.f, mgxxh = 0.f;
+        if (VEC) {
+#pragma unroll
+            for (int v = 0; v < NREG / 4; ++v) {
+                const int c0 = 256 * v + 4 * lane;
+                float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f), x4 = d4, q4 = d4;
+                if (c0 < D) {
+                    d4 = *reinterpret_cast<const float4*>(dy + off + c0);
+                    x4 = *reinterpret_cast<const float4*>(x + off + c0);
+                    if (Gx) q4 = *reinterpret_cast<const float4*>(Gx + off + c0);
+                }
+                d[4 * v] = d4.x; d[4 * v + 1] = d4.y; d[4 * v + 2] = d4.z; d[4 * v + 3] = d4.w;
+                xh[4 * v] = x4.x; xh[4 * v + 1] = x4.y; xh[4 * v + 2] = x4.z; xh[4 * v + 3] = x4.w;
+                gx[4 * v] = q4.x; gx[4 * v + 1] = q4.y; gx[4 * v + 2] = q4.z; gx[4 * v + 3] = q4.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NREG; ++i) {
+                const int c = lane + 64 * i;
+                d[i] = c < D ? dy[off + c] : 0.f;
+                xh[i] = c < D ? x[off + c] : 0.f;
+                gx[i] = (Gx && c < D) ? Gx[off + c] : 0.f;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) {
-                d[i] = dy[off + c];
-                xh[i] = (x[off + c] - mu) * r;
-                g[i] = d[i] * gamma[c];
-                gx[i] = Gx ? Gx[off + c] : 0.f;
+            if (col(i) < D) {
+                xh[i] = (xh[i] - mu) * r;
+                g[i] = d[i] * gm[i];
             } else {
                 d[i] = xh[i] = g[i] = gx[i] = 0.f;
             }
@@ -734,10 +799,9 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
         float mgxdx = 0.f, mX = 0.f, mXxh = 0.f;
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) {
+            if (col(i) < D) {
                 const float dxv = r * (g[i] - a - xh[i] * b);
-                const float gg = Gg ? Gg[c] : 0.f;
+                const float gg = ggv[i];
                 Xh[i] = -r * b * gx[i] - r * g[i] * mgxxh + gg * d[i];
                 mgxdx += gx[i] * dxv;
                 mX += Xh[i];
@@ -749,21 +813,33 @@ __global__ __launch_bounds__(256) void ln_bwd_bwd_kernel(const float* __restrict
         mgxdx = ix_wave_sum(mgxdx) / D;
         mX = ix_wave_sum(mX) / D;
         mXxh = ix_wave_sum(mXxh) / D;
+        float o1[NREG], o2[NREG];
 #pragma unroll
         for (int i = 0; i < NREG; ++i) {
-            const int c = lane + 64 * i;
-            if (c < D) {
-                const float pgx = r * (gx[i] - mgx - xh[i] * mgxxh);
-                const float gg = Gg ? Gg[c] : 0.f;
-                const float gb = Gb ? Gb[c] : 0.f;
-                grad_dy[off + c] = pgx * gamma[c] + gg * xh[i] + gb;
-                grad_x[off + c] = r * (Xh[i] - mX - xh[i] * mXxh) - r * xh[i] * mgxdx;
-                ag[i] += pgx * d[i];
+            const float pgx = r * (gx[i] - mgx - xh[i] * mgxxh);
+            o1[i] = pgx * gm[i] + ggv[i] * xh[i] + gbv[i];
+            o2[i] = r * (Xh[i] - mX - xh[i] * mXxh) - r * xh[i] * mgxdx;
+            if (col(i) < D) ag[i] += pgx * d[i];
+        }
+        if (VEC) {
+#pragma unroll
+            for (int v = 0; v < NREG / 4; ++v) {
+                const int c0 = 256 * v + 4 * lane;
+                if (c0 < D) {
+                    *reinterpret_cast<float4*>(grad_dy + off + c0) = make_float4(o1[4 * v], o1[4 * v + 1], o1[4 * v + 2], o1[4 * v + 3]);
+                    *reinterpret_cast<float4*>(grad_x + off + c0) = make_float4(o2[4 * v], o2[4 * v + 1], o2[4 * v + 2], o2[4 * v + 3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NREG; ++i) {
+                const int c = lane + 64 * i;
+                if (c < D) { grad_dy[off + c] = o1[i]; grad_x[off + c] = o2[i]; }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < NREG; ++i) sg[w][lane + 64 * i] = ag[i];
+    for (int i = 0; i < NREG; ++i) sg[w][col(i)] = ag[i];
     __syncthreads();
     if (gridDim.x == 1) {
         for (int c = threadIdx.x; c < D; c += 256) grad_gamma[c] = sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c];
@@ -795,10 +871,17 @@ extern "C" int ix_layernorm_bwd_bwd_f32(const float* Gx, const float* Gg, const 
     if (rc != IX_OK) return rc;
     const int row_groups = ln_row_groups(rows);
     dim3 grid(ln_grid_x(rows), groups), block(256);
-#define LNBB(N) hipLaunchKernelGGL(ln_bwd_bwd_kernel<N>, grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups, part, tickets)
-    if (D <= 256) LNBB(4);
-    else if (D <= 512) LNBB(8);
-    else LNBB(16);
+#define LNBB(N, V) hipLaunchKernelGGL((ln_bwd_bwd_kernel<N, V>), grid, block, 0, stream, Gx, Gg, Gb, dy, x, gamma, mean, rstd, grad_dy, grad_x, grad_gamma, rows, D, row_groups, part, tickets)
+    const bool vec = D % 4 == 0 && ix_al16(dy) && ix_al16(x) && ix_al16(grad_dy) && ix_al16(grad_x) && (!Gx || ix_al16(Gx));
+    if (vec) {
+        if (D <= 256) LNBB(4, true);
+        else if (D <= 512) LNBB(8, true);
+        else LNBB(16, true);
+    } else {
+        if (D <= 256) LNBB(4, false);
+        else if (D <= 512) LNBB(8, false);
+        else LNBB(16, false);
+    }
 #undef LNBB
     IX_CHECK_LAUNCH("ix_layernorm_bwd_bwd_f32");
     return IX_OK;
