@@ -185,6 +185,9 @@ int ix_gemm_bn_act_f32(const float* A, const float* B, float* C, int M, int N, i
 int ix_conv_gemm_bn_act_f32(const float* x, const float* w, float* y, int groups, int imgs, int H, int W, int Cin, int OH, int OW,
                             int Cout, int KH, int KW, int stride, int pad, int dil, const float* scale, const float* shift,
                             const float* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+/* out = (a + b) * [y > 0]: the ReLU derivative of an activation with two consumers, their gradients summed in the same pass
+ * (torchvision Bottleneck: `out = relu(out + identity)` feeding the next block's conv1 AND its identity branch) */
+int ix_relu_bwd_sum_f32(const float* a, const float* b, const float* y, float* out, int64_t n, ix_stream_t stream);
 /* out[o][n][r] = x[o][n][r] * scale[n] (R % 4 == 0): the frozen-BN scale applied to a weight tensor [(E,) N, R] or to its gradient --
  * what the backward of convolution + FrozenBatchNorm2d needs when the scale sits on the weight side (dx = g (W o scale),
  * dW = scale o (g^T x)) instead of on the activation-sized gradient (models/detr_models/backbone.py:44-54 under autograd) */

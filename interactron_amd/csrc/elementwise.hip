@@ -295,6 +295,33 @@ extern "C" int ix_relu_bwd_scaled_f32(const float* dy, const float* y, float* dx
     LAUNCH2("ix_relu_bwd_scaled_f32", dy, y, dx, n, stream, [scale] __device__(float g, float v) { return v > 0.f ? g * scale : 0.f; });
 }
 
+// (a + b) * [y > 0]: the ReLU derivative of a bottleneck tail whose output feeds two consumers (the next block's first
+// convolution and its identity branch) -- their two gradients are summed HERE instead of by a pass of their own (hipops.ReluBwdSum)
+__global__ void relu_bwd_sum_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ y,
+                                    float* __restrict__ o, int64_t n, bool vec) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t done = 0;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        for (int64_t k = i; k < n4; k += stride) {
+            const float4 p = reinterpret_cast<const float4*>(a)[k], q = reinterpret_cast<const float4*>(b)[k];
+            const float4 v = reinterpret_cast<const float4*>(y)[k];
+            reinterpret_cast<float4*>(o)[k] = make_float4(v.x > 0.f ? p.x + q.x : 0.f, v.y > 0.f ? p.y + q.y : 0.f,
+                                                          v.z > 0.f ? p.z + q.z : 0.f, v.w > 0.f ? p.w + q.w : 0.f);
+        }
+        done = n4 << 2;
+    }
+    for (int64_t k = done + i; k < n; k += stride) o[k] = y[k] > 0.f ? a[k] + b[k] : 0.f;
+}
+extern "C" int ix_relu_bwd_sum_f32(const float* a, const float* b, const float* y, float* out, int64_t n, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(a && b && y && out, "ix_relu_bwd_sum_f32: null pointer");
+    const bool vec = al16(a) && al16(b) && al16(y) && al16(out);
+    hipLaunchKernelGGL(relu_bwd_sum_kernel, dim3(ix_grid_1d((n + 3) / 4, EW_BLOCK)), dim3(EW_BLOCK), 0, stream, a, b, y, out, n, vec);
+    IX_CHECK_LAUNCH("ix_relu_bwd_sum_f32");
+    return IX_OK;
+}
+
 // ---- row-vector broadcast and column reductions ----------------------------------------------------------
 __global__ void add_rowvec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ o,
                                   int64_t n, int C) {

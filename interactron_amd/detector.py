@@ -47,19 +47,22 @@ class Bottleneck(nn.Module):
         self.bn3 = FrozenBatchNorm2d(planes * 4)
         self.downsample = downsample
 
-    def forward(self, x):
-        x, idt = ops.fanout(x, 2)   # (two consumers: their gradients are summed in one pass, hipops.Fanout)
+    def forward(self, x, two_consumers=False):
+        """x: the block input, or the PAIR of aliases the previous block handed out (two_consumers=True there): the block input
+        feeds conv1 and the identity branch, and the sum of their two gradients then happens inside the previous tail's ReLU
+        derivative (hipops.ReluBwdSum) instead of in a pass of its own (hipops.Fanout: the first block after the frozen stem)."""
+        x, idt = x if isinstance(x, tuple) else ops.fanout(x, 2)
         if self.downsample is not None:
             idt = _conv_bn(self.downsample[0], self.downsample[1], idt)
         y = _conv_bn(self.conv1, self.bn1, x, relu=True)
         y = _conv_bn(self.conv2, self.bn2, y, relu=True)
-        return _conv_bn(self.conv3, self.bn3, y, residual=idt, relu=True)
+        return _conv_bn(self.conv3, self.bn3, y, residual=idt, relu=True, fan=2 if two_consumers else 1)
 
 
-def _conv_bn(conv, bn, x, residual=None, relu=False):
+def _conv_bn(conv, bn, x, residual=None, relu=False, fan=1):
     """bn(conv(x)) (+ residual) (+ ReLU) with the frozen-BN affine riding on the convolution's contraction (hipops.conv2d_nhwc_bn_act)"""
     scale, shift = bn.folded()
-    return ops.conv2d_nhwc_bn_act(x, conv.weight, scale, shift, residual, relu, conv.stride, conv.padding, conv.dilation)
+    return ops.conv2d_nhwc_bn_act(x, conv.weight, scale, shift, residual, relu, conv.stride, conv.padding, conv.dilation, fan)
 
 
 def _make_layer(inplanes, planes, blocks, stride, first_dilation, dilation):
@@ -101,9 +104,10 @@ class ResNet50Body(nn.Module):
 
     def forward(self, frames_nchw, stem=None):
         x = stem if stem is not None else self.frozen_stem(frames_nchw)
-        x = self.layer2(x)
-        x = self.layer3(x)
-        return self.layer4(x)
+        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
+        for i, blk in enumerate(blocks):   # (every tail but the last hands its output to the next block's two branches)
+            x = blk(x, two_consumers=i + 1 < len(blocks))
+        return x
 
 
 class Backbone(nn.Module):

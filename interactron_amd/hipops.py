@@ -1467,6 +1467,36 @@ class ReluBwd(Function):
         return ReluBwd.call(G, y), None
 
 
+class ReluBwdSum(Function):
+    """(ga + gb) * [y > 0]: ReluBwd of an activation with two consumers, the sum of their gradients in the same pass."""
+
+    @staticmethod
+    def forward(ctx, ga, gb, y):
+        ga, gb, y = _req(ga), _req(gb), _req(y)
+        ctx.save_for_backward(y)
+        out = torch.empty_like(ga)
+        _chk(_L().ix_relu_bwd_sum_f32(ga.data_ptr(), gb.data_ptr(), y.data_ptr(), out.data_ptr(), ga.numel(), _stream()),
+             "ix_relu_bwd_sum_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        (y,) = ctx.saved_tensors
+        t = ReluBwd.call(G, y)
+        return t, t, None
+
+
+def _two_gradients(gs, y, relu):
+    """the gradient(s) of a fused contraction + BN node's output(s) -> the ReLU-masked (if relu) single gradient.  Two outputs
+    (fan = 2: the node handed out two aliases of its result) with two gradients: summed inside the ReLU derivative's pass."""
+    gs = [g for g in gs if g is not None]
+    if len(gs) == 2:
+        if relu:
+            return ReluBwdSum.call(gs[0].contiguous(), gs[1].contiguous(), y), True
+        return SumN.call(gs[0], gs[1]), False
+    return gs[0].contiguous(), False
+
+
 class ReluBwdScaled(Function):
     """dy * [y > 0] * scale; linear in dy."""
 
@@ -1800,7 +1830,8 @@ class GemmBnAct(Function):
     backward = BnAct's backward followed by Gemm's (all differentiable nodes: closed under the MAML double backward)."""
 
     @staticmethod
-    def forward(ctx, a, b, scale, shift, residual, relu, sp):
+    def forward(ctx, a, b, scale, shift, residual, relu, sp, fan=1):
+        ctx.set_materialize_grads(False)
         ctx.a_key, ctx.b_key = _param_key(a), _param_key(b)
         a, b, scale, shift = _req(a, "gemm A"), _req(b, "gemm B"), _req(scale), _req(shift)
         if residual is not None:
@@ -1817,17 +1848,19 @@ class GemmBnAct(Function):
         ctx.sp, ctx.relu, ctx.has_res = sp, relu, residual is not None
         ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
         ctx.save_for_backward(a, b, scale, out if relu else None)
-        return out
+        return out if fan == 1 else (out, out.view_as(out))   # (fan = 2: two aliases for two consumers, see _two_gradients)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         a, b, scale, y = ctx.saved_tensors
+        if all(g is None for g in gs):
+            return (None,) * 8
         need_a = ctx.needs_input_grad[0] and not _is_unwanted(ctx.a_key, _unwanted)
         need_b = ctx.needs_input_grad[1] and not _is_unwanted(ctx.b_key, _unwanted)
         da = db = None
         if _bn_scale_on_weights(ctx.relu, ctx.has_res, b, 1):
-            g = g.contiguous()
-            g1 = ReluBwd.call(g, y) if ctx.relu else g
+            g, masked = _two_gradients(gs, y, ctx.relu)
+            g1 = ReluBwd.call(g, y) if (ctx.relu and not masked) else g
             want_res = ctx.has_res and ctx.needs_input_grad[4]
             gs = list(fanout(g1, int(need_a) + int(need_b) + int(want_res)))   # (one sum of its consumers' gradients in the outer backward)
             gres = gs.pop() if want_res else None
@@ -1835,14 +1868,15 @@ class GemmBnAct(Function):
                 da = _gemm_backward(ctx.sp, a, RowScale.call(b, scale, 1), ctx.a_shape, ctx.b_shape, gs.pop(), True, False)[0]
             if need_b:
                 db = RowScale.call(_gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, gs.pop(), False, True)[1], scale, 1)
-            return da, db, None, None, gres, None, None
+            return da, db, None, None, gres, None, None, None
+        g, _ = _two_gradients(gs, None, False)
         gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, need_a or need_b, ctx.needs_input_grad[4])
         if gz is not None:
             da, db = _gemm_backward(ctx.sp, a, b, ctx.a_shape, ctx.b_shape, gz, need_a, need_b)
-        return da, db, None, None, gres, None, None
+        return da, db, None, None, gres, None, None, None
 
 
-def linear_bn_act(x, weight, scale, shift, residual, relu):
+def linear_bn_act(x, weight, scale, shift, residual, relu, fan=1):
     """[relu](linear(x, weight) * scale + shift (+ residual)) -- `linear` without bias, episode-batched weights included"""
     if weight.dim() == 3:
         E, N, K = weight.shape
@@ -1853,7 +1887,7 @@ def linear_bn_act(x, weight, scale, shift, residual, relu):
         K, N = x.shape[-1], weight.shape[0]
         sp = GemmSpec(x.numel() // K, N, K, 1, 1, View(0, K, False, 0, 0), View(0, K, True, 0, 0), View(0, N, False, 0, 0),
                       tuple(x.shape[:-1]) + (N,), 1.0)
-    return GemmBnAct.call(x, weight, scale, shift, residual, relu, sp)
+    return GemmBnAct.call(x, weight, scale, shift, residual, relu, sp, fan)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -2017,7 +2051,8 @@ class ConvFwdBnAct(Function):
     """y = [relu](conv(x, w) * scale[c] + shift[c] (+ residual)): ConvFwd with the frozen-BN affine in the contraction's store"""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, residual, relu, cg):
+    def forward(ctx, x, w, scale, shift, residual, relu, cg, fan=1):
+        ctx.set_materialize_grads(False)
         ctx.w_key = _param_key(w)
         x, w, scale, shift = _req(x, "conv x"), _req(w, "conv weight"), _req(scale), _req(shift)
         if residual is not None:
@@ -2037,16 +2072,18 @@ class ConvFwdBnAct(Function):
              "ix_conv_gemm_bn_act_f32")
         ctx.cg, ctx.relu, ctx.has_res = cg, relu, residual is not None
         ctx.save_for_backward(x, w, scale, out if relu else None)
-        return out
+        return out if fan == 1 else (out, out.view_as(out))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         x, w, scale, y = ctx.saved_tensors
+        if all(g is None for g in gs):
+            return (None,) * 8
         need_w = ctx.needs_input_grad[1] and not _is_unwanted(ctx.w_key, _unwanted)
         dx = dw = None
         if _bn_scale_on_weights(ctx.relu, ctx.has_res, w, 3):
-            g = g.contiguous()
-            g1 = ReluBwd.call(g, y) if ctx.relu else g
+            g, masked = _two_gradients(gs, y, ctx.relu)
+            g1 = ReluBwd.call(g, y) if (ctx.relu and not masked) else g
             want_res = ctx.has_res and ctx.needs_input_grad[4]
             gs = list(fanout(g1, int(bool(ctx.needs_input_grad[0])) + int(need_w) + int(want_res)))
             gres = gs.pop() if want_res else None
@@ -2054,15 +2091,16 @@ class ConvFwdBnAct(Function):
                 dx = ConvBwdData.call(gs.pop(), RowScale.call(w, scale, 3), ctx.cg)
             if need_w:
                 dw = RowScale.call(ConvBwdWeight.call(gs.pop(), x, ctx.cg, tuple(w.shape)), scale, 3)
-            return dx, dw, None, None, gres, None, None
+            return dx, dw, None, None, gres, None, None, None
+        g, _ = _two_gradients(gs, None, False)
         gz, gres = _bn_act_backward(g, y, scale, ctx.relu, ctx.has_res, ctx.needs_input_grad[0] or need_w, ctx.needs_input_grad[4])
         if gz is not None:
             dx = ConvBwdData.call(gz, w, ctx.cg) if ctx.needs_input_grad[0] else None
             dw = ConvBwdWeight.call(gz, x, ctx.cg, tuple(w.shape)) if need_w else None
-        return dx, dw, None, None, gres, None, None
+        return dx, dw, None, None, gres, None, None, None
 
 
-def conv2d_nhwc_bn_act(x, weight, scale, shift, residual=None, relu=False, stride=1, pad=0, dil=1):
+def conv2d_nhwc_bn_act(x, weight, scale, shift, residual=None, relu=False, stride=1, pad=0, dil=1, fan=1):
     """[relu](conv2d_nhwc(x, weight) * scale + shift (+ residual)): one launch where the contraction kernel takes the affine
     (1 x 1 / stride 1 and implicit-GEMM geometries, output channels % 4 == 0), else the two separate nodes"""
     n, H, W, C = x.shape
@@ -2072,12 +2110,13 @@ def conv2d_nhwc_bn_act(x, weight, scale, shift, residual=None, relu=False, strid
     if FUSE_CONV_BN and Cout % 4 == 0:
         if KH == 1 and KW == 1 and stride == 1 and pad == 0:
             wv = weight_view(weight, E, Cout, C) if batched else weight_view(weight, Cout, C)
-            return linear_bn_act(x, wv, scale, shift, residual, relu)
+            return linear_bn_act(x, wv, scale, shift, residual, relu, fan)
         g = conv_geom(n, H, W, C, KH, KW, stride, pad, dil)
         cg = ConvGemmGeom(E, n // E, H, W, C, g.OH, g.OW, Cout, KH, KW, stride, pad, dil)
         if conv_gemm_supported(cg):
-            return ConvFwdBnAct.call(x, weight, scale, shift, residual, relu, cg)
-    return BnAct.apply(conv2d_nhwc(x, weight, stride, pad, dil), scale, shift, residual, relu)
+            return ConvFwdBnAct.call(x, weight, scale, shift, residual, relu, cg, fan)
+    y = BnAct.apply(conv2d_nhwc(x, weight, stride, pad, dil), scale, shift, residual, relu)
+    return y if fan == 1 else fanout(y, fan)
 
 
 def conv2d_nhwc(x, weight, stride=1, pad=0, dil=1):
