@@ -179,6 +179,10 @@ int ix_bn_fold_f32(const float* w, const float* b, const float* rm, const float*
  * ix_gemm_bn_act_f32: operands as ix_gemm_f32_ws (one batch level).  ix_conv_gemm_bn_act_f32: kind 0 of ix_conv_gemm_f32.
  * Workspace sizes: ix_workspace_bytes_gemm_f32 / ix_workspace_bytes_conv_gemm_f32 of the same problem. */
 int ix_gemm_epilogue_stats(int64_t* in_reduction, int64_t* separate, int reset); /* where the affine of the fused calls ran */
+/* ... and the third place: in the store of the contraction kernel itself (unsplit forward contractions on the fp16x3 form, a
+ * separate kernel instance); ix_gemm_set_epilogue_in_store(0) / IX_GEMM_EPI_IN_STORE=0 sends those back to the separate launch */
+int ix_gemm_epilogue_in_store(int64_t* count, int reset);
+int ix_gemm_set_epilogue_in_store(int on);
 int ix_gemm_bn_act_f32(const float* A, const float* B, float* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
                        int64_t ldb, int batch_outer, int64_t sAo, int64_t sBo, const float* scale, const float* shift,
                        const float* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);

@@ -88,6 +88,10 @@ struct GemmArgs {
     int a_vec, b_vec, c_vec;
     int tiles_m, tiles_n;
     struct ConvGather cg;   // implicit-GEMM convolution operands (ix_conv_gemm_f32); mode 0 for plain contractions
+    // affine epilogue of an UNSPLIT launch in the store of the fp16x3 kernel's EPI instances (frozen BN + identity + ReLU riding on a
+    // forward convolution): C = [relu](acc * scale[n] + shift[n] (+ res[same place as C]))
+    const float *epi_scale, *epi_shift, *epi_res;
+    int epi_relu;
     float* rowsum;          // optional side output (bf16x6 kernel, A stored m-contiguous): rowsum[bo][m] = sum_k A(m, k)
     int64_t sRowsum;
     int64_t sSplitRowsum;   // plane stride of the per-split partial row sums (0 with atomics)
@@ -1780,7 +1784,7 @@ __global__ __launch_bounds__((NC + 8) * 64, 1) void gemm_f32_bf16x6_p12_kernel(G
 // ------------------------------------------------------------------------------------------------------------
 typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
 
-template <bool A_KC, bool B_KC, int GA = 0, int GB = 0, bool ONE = false, bool CMAP = false>
+template <bool A_KC, bool B_KC, int GA = 0, int GB = 0, bool ONE = false, bool CMAP = false, bool EPI = false>
 __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, int total_items) {
     constexpr int BN = 128, BM = X6_BT, ROWB = X6_ROWB, NC = 4;
     constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB, BUF = 2 * (PLANE_A + PLANE_B);
@@ -2111,6 +2115,29 @@ __global__ __launch_bounds__(768, 1) void gemm_f32_f16x3_p12_kernel(GemmArgs p, 
                 }
                 __builtin_amdgcn_wave_barrier();
                 const int r0 = it.m0 + wm + i * 32, c0 = it.n0 + wn;
+                if (EPI) {
+                    // affine epilogue (N % 4 == 0, ldc % 4 == 0: whole float4 chunks are inside or outside): the residual chunks are
+                    // requested first, the strip is read while they fly
+                    const float* rbase = p.epi_res ? p.epi_res + (it.C - p.C) : nullptr;
+                    const int gc = c0 + (lane % CPR) * 4;
+                    const bool cin = gc < p.N;
+                    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc, rr[NQ];
+                    if (cin) { sc = *reinterpret_cast<const float4*>(p.epi_scale + gc); sh = *reinterpret_cast<const float4*>(p.epi_shift + gc); }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int gr = r0 + (lane + 64 * q) / CPR;
+                        rr[q] = (rbase && cin && gr < p.M) ? *reinterpret_cast<const float4*>(rbase + (int64_t)gr * p.ldc + gc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q, gr = r0 + c / CPR;
+                        float4 v = *reinterpret_cast<const float4*>(&ct[(c / CPR) * CP + (c % CPR) * 4]);
+                        v.x = v.x * sc.x + sh.x + rr[q].x; v.y = v.y * sc.y + sh.y + rr[q].y;
+                        v.z = v.z * sc.z + sh.z + rr[q].z; v.w = v.w * sc.w + sh.w + rr[q].w;
+                        if (p.epi_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                        if (cin && gr < p.M) *reinterpret_cast<float4*>(it.C + (int64_t)gr * p.ldc + gc) = v;
+                    }
+                } else
                 if (r0 + 32 <= p.M && c0 + WN <= p.N) {
                     float4 v[NQ];
 #pragma unroll
@@ -2568,6 +2595,17 @@ static void launch_x3q_(const GemmArgs& a, int a_kc, int b_kc, int items, hipStr
         hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, true, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
     else
         hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<false, false, 0, 0, ONE>), grid, dim3(768), 0, stream, a, items);
+}
+
+// forward contraction (both operands k-contiguous) with the affine epilogue in its store
+static void launch_x3q_epi(const GemmArgs& a, int items, hipStream_t stream) {
+    int g = (items + 7) / 8 * 8;
+    if (g > 256) g = 256;
+    if (g_single_pass) hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 0, 0, true, false, true>), dim3(g), dim3(768), 0, stream, a, items);
+    else hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 0, 0, false, false, true>), dim3(g), dim3(768), 0, stream, a, items);
+}
+static bool persistent_ok_pre(const GemmArgs& a, int nbatch, int split) {
+    return (int64_t)a.tiles_m * a.tiles_n * nbatch * split < (1 << 30);
 }
 
 static void launch_x3q(const GemmArgs& a, int a_kc, int b_kc, int items, hipStream_t stream) {
@@ -3217,12 +3255,44 @@ struct EpiReq {
     int relu, applied;
 };
 static thread_local EpiReq g_epi = {nullptr, nullptr, nullptr, 0, 0};
-static int64_t g_epi_count[2] = {0, 0};   // fused calls whose affine ran: in the split-K reduction | as a separate launch
+static int64_t g_epi_count[3] = {0, 0, 0};   // fused calls whose affine ran: in the split-K reduction | as a separate launch | in the kernel's store
 extern "C" int ix_gemm_epilogue_stats(int64_t* in_reduction, int64_t* separate, int reset) {
     if (in_reduction) *in_reduction = g_epi_count[0];
     if (separate) *separate = g_epi_count[1];
     if (reset) g_epi_count[0] = g_epi_count[1] = 0;
     return IX_OK;
+}
+extern "C" int ix_gemm_epilogue_in_store(int64_t* count, int reset) {
+    if (count) *count = g_epi_count[2];
+    if (reset) g_epi_count[2] = 0;
+    return IX_OK;
+}
+// The affine in the contraction kernel's own store (EPI instances of the fp16x3 kernel: forward contractions with both operands
+// k-contiguous, plain and gathering).  Rounds 2 and 3 measured this behind a run-time flag in the shared kernel and found nothing
+// won; as a separate instance it cannot touch the launches that do not use it.  0: never (IX_GEMM_EPI_IN_STORE=0, tests), 1: default.
+static int g_epi_in_store = -1;
+extern "C" int ix_gemm_set_epilogue_in_store(int on) {
+    const int old = g_epi_in_store;
+    g_epi_in_store = on ? 1 : 0;
+    return old < 0 ? 1 : old;
+}
+static bool epi_in_store_enabled() {
+    if (g_epi_in_store < 0) {
+        const char* e = getenv("IX_GEMM_EPI_IN_STORE");
+        g_epi_in_store = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_epi_in_store != 0;
+}
+// an unsplit launch of the fp16x3 kernel with a pending affine takes it in its store
+static bool epi_in_store(GemmArgs& a, bool x3_forward_kind) {
+    a.epi_scale = a.epi_shift = a.epi_res = nullptr;
+    a.epi_relu = 0;
+    if (!g_epi.scale || !x3_forward_kind || a.split_k != 1 || a.atomic || !a.c_vec || a.N % 4 || a.ldc % 4 || !epi_in_store_enabled()) return false;
+    if (!aligned16(g_epi.scale) || !aligned16(g_epi.shift) || (g_epi.res && !aligned16(g_epi.res)) || a.bias) return false;
+    a.epi_scale = g_epi.scale; a.epi_shift = g_epi.shift; a.epi_res = g_epi.res; a.epi_relu = g_epi.relu;
+    g_epi.applied = 1;
+    ++g_epi_count[2];
+    return true;
 }
 
 // called once the plan is known and splitk_begin has run: a split-K launch takes the epilogue in its ordered reduction
@@ -3450,6 +3520,13 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     g_launches += 1;
     const bool use_x3 = use_x6 && bn == 128 && x3k_enabled() && g_x6 == 3;
     const SplitEpi sep = epi_place(a, real);
+    // (the 256 x 128 tiles have no such instance: an unsplit launch with a pending affine goes back to 128 x 128 tiles -- the pass
+    //  it saves is worth more than their 4-8 %)
+    if (use_w2 && g_epi.scale && !g_epi.applied && split == 1 && a_kcontig && b_kcontig && batch_inner == 1 && !bias && epi_in_store_enabled()) {
+        use_w2 = false;
+        a.tiles_m = ix_div_up(M, bm);
+    }
+    const bool epi_store = !use_w2 && epi_in_store(a, use_x3 && a_kcontig && b_kcontig && batch_inner == 1 && persistent_ok_pre(a, nbatch, split));
     if (g_prof_on) {
         ProfRec r = {M, N, K, nbatch, a_kcontig, b_kcontig, use_x3 ? 1129 : (use_x6 ? 1128 : bm), split};
         r.flops = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
@@ -3474,6 +3551,8 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
 #endif
     if (use_w2)
         launch_w256(a, a_kcontig, b_kcontig, items, stream);
+    else if (epi_store)
+        launch_x3q_epi(a, items, stream);
     else if (use_x3)
         launch_x3q(a, a_kcontig, b_kcontig, items, stream);
     else if (use_x6)
@@ -3520,10 +3599,15 @@ static int x6_pick_split(int M, int N, int K, int nbatch) {
 }
 
 template <int BN>
-static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t stream, bool x3 = false) {
+static void launch_conv_bn(const GemmArgs& a, int kind, int items, hipStream_t stream, bool x3 = false, bool epi = false) {
     int g = (items + 7) / 8 * 8;
     if (g > 256) g = 256;
     const dim3 grid(g);
+    if (epi && x3 && BN == 128) {   // forward convolution with the affine epilogue in its store
+        if (g_single_pass) hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, true, false, true>), grid, dim3(768), 0, stream, a, items);
+        else hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, false, false, true>), grid, dim3(768), 0, stream, a, items);
+        return;
+    }
     if (x3 && BN == 128 && a.cg.cmap) {   // a parity class of conv_bwd_data_s2 written in place (forward kind)
         if (g_single_pass) hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, true, true>), grid, dim3(768), 0, stream, a, items);
         else hipLaunchKernelGGL((gemm_f32_f16x3_p12_kernel<true, true, 1, 0, false, true>), grid, dim3(768), 0, stream, a, items);
@@ -3769,7 +3853,8 @@ static int conv_gemm_core(int kind, const float* src, const float* other, float*
     set_item_divs(a);
     prof_mark(stream);
     const SplitEpi sep = epi_place(a, real);
-    if (bn == 128) launch_conv_bn<128>(a, kind, items, stream, conv_x3);
+    const bool epi_store = epi_in_store(a, kind == 0 && conv_x3 && !map);
+    if (bn == 128) launch_conv_bn<128>(a, kind, items, stream, conv_x3, epi_store);
     else launch_conv_bn<64>(a, kind, items, stream);
     splitk_finish(a, groups, groups, false, real, stream, sep);
     prof_mark(stream);

@@ -299,9 +299,11 @@ def test_conv_bn_act_rides_on_the_contraction(ops, fused, cin, cout, k, stride, 
         import ctypes
         lib = ops._L()
         lib.ix_gemm_epilogue_stats(None, None, 1)
+        lib.ix_gemm_epilogue_in_store(None, 1)
         check_op(hip, ref, inputs, name="conv + bn + act (%s)" % ("fused" if fused else "separate"))
-        c = [ctypes.c_int64() for _ in range(2)]
+        c = [ctypes.c_int64() for _ in range(3)]
         lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
+        lib.ix_gemm_epilogue_in_store(ctypes.byref(c[2]), 1)
         counts = [v.value for v in c]
         assert (sum(counts) > 0) == fused, counts
     finally:
@@ -342,26 +344,41 @@ def test_conv_bn_act_tail_with_two_consumers(ops, k):
         close(a, b, 1e-5, "fan = 2 vs fanout, tensor %d" % i)
 
 
-def test_conv_bn_act_reaches_both_places_the_affine_can_run(ops):
-    """forward only, a launch-bound and a large geometry: the affine of the first must run inside the split-K reduction, the
-    affine of the second as the library's own launch after an unsplit plan (ix_gemm_epilogue_stats)"""
+def test_conv_bn_act_reaches_all_three_places_the_affine_can_run(ops):
+    """forward only, launch-bound and large geometries: a split-K plan applies the affine in its ordered reduction, an unsplit
+    launch of the fp16x3 form (128-wide tiles) in the kernel's own store (a separate kernel instance), an unsplit launch on narrow
+    tiles as the library's own pass afterwards; with the in-store instances switched off the second goes back to that pass
+    (ix_gemm_epilogue_stats / ix_gemm_epilogue_in_store)."""
     import ctypes
     lib = ops._L()
-    seen = []
-    for (n, hw, cin, cout, k) in ((2, 19, 256, 64, 1), (16, 75, 64, 256, 1), (2, 19, 64, 64, 3), (16, 75, 64, 64, 3)):
-        x = rnd(n, hw, hw, cin, seed=1).cuda()
-        w = rnd(cout, k, k, cin, seed=2, scale=(cin * k * k) ** -0.5).cuda()
-        scale, shift = (rnd(cout, seed=3).abs() + 0.5).cuda(), rnd(cout, seed=4).cuda()
-        lib.ix_gemm_epilogue_stats(None, None, 1)
-        y = ops.conv2d_nhwc_bn_act(x, w, scale, shift, None, True, 1, k // 2, 1)
-        ref = torch.relu(ops.conv2d_nhwc(x, w, 1, k // 2, 1) * scale + shift)
-        close(y, ref, 1e-6, "fused vs separate")
-        c = [ctypes.c_int64(), ctypes.c_int64()]
-        lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
-        assert c[0].value + c[1].value == 1, (c[0].value, c[1].value)
-        seen.append(c[0].value)
-    assert 1 in seen and 0 in seen, seen   # (a launch-bound plan splits K: in the reduction; a large one: separate launch)
-    assert seen[1] == 0 and seen[3] == 0, seen
+
+    def places(in_store):
+        old = lib.ix_gemm_set_epilogue_in_store(1 if in_store else 0)
+        seen = []
+        try:
+            for (n, hw, cin, cout, k) in ((2, 19, 256, 64, 1), (16, 75, 64, 256, 1), (2, 19, 64, 64, 3), (16, 75, 64, 64, 3), (16, 38, 128, 128, 3)):
+                x = rnd(n, hw, hw, cin, seed=1).cuda()
+                w = rnd(cout, k, k, cin, seed=2, scale=(cin * k * k) ** -0.5).cuda()
+                res = rnd(n, hw, hw, cout, seed=5).cuda()
+                scale, shift = (rnd(cout, seed=3).abs() + 0.5).cuda(), rnd(cout, seed=4).cuda()
+                lib.ix_gemm_epilogue_stats(None, None, 1)
+                lib.ix_gemm_epilogue_in_store(None, 1)
+                y = ops.conv2d_nhwc_bn_act(x, w, scale, shift, res, True, 1, k // 2, 1)
+                ref = torch.relu(ops.conv2d_nhwc(x, w, 1, k // 2, 1) * scale + shift + res)
+                close(y, ref, 1e-6, "fused vs separate")
+                c = [ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()]
+                lib.ix_gemm_epilogue_stats(ctypes.byref(c[0]), ctypes.byref(c[1]), 1)
+                lib.ix_gemm_epilogue_in_store(ctypes.byref(c[2]), 1)
+                assert sum(v.value for v in c) == 1, [v.value for v in c]
+                seen.append(("reduction", "separate", "store")[[v.value for v in c].index(1)])
+        finally:
+            lib.ix_gemm_set_epilogue_in_store(old)
+        return seen
+
+    # (the first, N = 64 and few rows: whatever the plan decides; the others are pinned)
+    on, off = places(True), places(False)
+    assert on[1:] == ["store", "reduction", "separate", "store"], on
+    assert off[1:] == ["separate", "reduction", "separate", "separate"], off
 
 
 def test_stem_conv_and_maxpool(ops):
