@@ -191,6 +191,68 @@ def cpu_detector_800(timed=2):
                       % (timed, med, cores, cpu_model_name())}
 
 
+def two_frame_pair(dev, frames=2, size=800, gpu_steps=5):
+    """The like-for-like CPU pair beside the north-star shape, MEASURED inside this run: ONE meta-train step of `interactron` on a
+    TWO-frame 800 x 800 episode (fusion T = 2 x (2500 + 50) + 5 = 5 105) through the HIP path (median of `gpu_steps` after a
+    warm-up) and through the CPU oracle (oracle/episode.py:interactron_forward, all usable host cores, one episode ~ 35 s), same
+    inputs, same weights, losses compared.  The five-frame episode (T = 12 755) is not practical on the host: reference
+    models/gpt.py:48-52 materialises 8 x T^2 fp32 attention per layer (5.2 GB at T = 12 755 with a double backward over it;
+    834 MB at T = 5 105).  The first-order branch draws its frame from the two that exist (the reference draws
+    random.randint(0, 4) for its five: models/interactron.py:126)."""
+    import torch
+    from interactron_amd import Config, build_model
+    from interactron_amd.synthetic import load_procedural, procedural_state_dict, synthetic_episodes
+    from oracle import detector as od, episode as oe, fusion as of
+    s = frames
+    cfg, tokens = model_cfg(size, 50, 1, "interactron")
+    cfg["BLOCK_SIZE"] = s * (tokens + 50) + 5
+    data = synthetic_episodes(1, frames=s, height=size, width=size, tag="two-frame")
+    # the policy head always scores four moves (reference models/interactron.py:116-118): four scripted actions, as in a 5-frame episode
+    data["actions"] = synthetic_episodes(1, frames=5, height=16, width=16, tag="two-frame")["actions"]
+    real_randint = random.randint
+    random.randint = lambda a, b: real_randint(a, min(b, s - 1))   # the first-order branch's frame: one of the s that exist
+    try:
+        model = build_model(Config(**cfg))
+        load_procedural(model.fusion, "fusion.")
+        model = model.to(dev).eval()
+        gpu = to_gpu(data, dev)
+        times = []
+        for i in range(1 + gpu_steps):
+            for p_ in model.parameters():
+                p_.grad = None
+            random.seed(11)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, losses = model(gpu)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        hip_s = sorted(times[1:])[len(times[1:]) // 2]
+        hip_losses = {k: float(v) for k, v in losses.items()}
+        del model, gpu
+        torch.cuda.empty_cache()
+        cores = usable_cores()
+        torch.set_num_threads(cores)
+        det = {k[len("detector."):]: v for k, v in
+               procedural_state_dict({"detector." + k: v for k, v in od.detr_state_shapes().items()}).items()}
+        fus = {k[len("fusion."):]: v for k, v in
+               procedural_state_dict({"fusion." + k: v for k, v in of.fusion_state_shapes(cfg, "gpt").items()}).items()}
+        random.seed(11)
+        t0 = time.perf_counter()
+        _, ref_losses, _ = oe.interactron_forward(det, fus, data, cfg, {}, "gpt")
+        cpu_s = time.perf_counter() - t0
+    finally:
+        random.randint = real_randint
+    worst = max(abs(hip_losses[k] - float(v)) / max(abs(float(v)), 1.0) for k, v in ref_losses.items())
+    return {"workload": "one interactron meta-train episode of %d frames x 3x%dx%d, Q=50, fusion T=%d, eval mode (dropout off), procedural weights"
+                        % (s, size, size, cfg["BLOCK_SIZE"]),
+            "hip": {"seconds_per_episode": hip_s, "frames_per_s": s / hip_s, "sample": "median of %d steps after 1 warm-up" % gpu_steps},
+            "cpu_baseline": {"seconds_per_episode": cpu_s, "value": s / cpu_s, "unit": "frames/s", "cores": cores, "kind": "port",
+                             "sample": "1 episode through oracle/episode.py:interactron_forward on %d threads of %s (no warm-up)"
+                                       % (cores, cpu_model_name())},
+            "gpu_over_cpu": cpu_s / hip_s, "worst_relative_loss_difference": worst, "comparable": True,
+            "source": "measured inside this bench.py run"}
+
+
 def launch_ranks(args):
     """``python bench.py --gpus N`` without a torchrun environment: start the N ranks as child processes (one per GPU,
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE anything in this process touches the GPU,
@@ -513,6 +575,7 @@ def main():
                     help="timed steps of the `stress` sub-measurement (BASELINE.json configs[4]: 1600 long edge, 200 queries, fp8 MFMA "
                          "attention forward; one episode per step, after two warm-up steps; 0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-frame", action="store_true", help="skip the two-frame 800 x 800 CPU / HIP pair of the north-star object (~ 40 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--gemm-csv", default=None, help="write one line per contraction launch of the profiled step (tuning aid)")
     args = ap.parse_args()
@@ -598,7 +661,7 @@ def main():
         from interactron_amd import hipops
         cfg = head["cfg"]
         line = {
-            "metric": "frames/sec (5-frame episodes)", "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec (5-frame episodes of 3x%dx%d frames)" % (args.size, args.size), "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" if args.compute_dtype == "f32" else "bf16-class (single-pass 16-bit contractions: fp16 x 2^E per 32x32 block, "
@@ -630,8 +693,13 @@ def main():
             "n800": n800,
             # BASELINE.json's north_star quotes frames/s on synthetic 5 x 3x800x800 episodes: that figure, at top level (the
             # headline `value` is configs/interactron.yaml at the reference's real 300 x 300 shapes)
-            "north_star": ({"value": n800["value"], "unit": "frames/s", "workload": n800["workload"], "ms_per_step": n800["ms_per_step"],
-                            "steps": n800["steps"]} if n800 is not None and "error" not in n800 else None),
+            "north_star": ({"metric": "frames/sec (5-frame episodes of 3x800x800 frames)", "value": n800["value"], "unit": "frames/s",
+                            "workload": n800["workload"], "ms_per_step": n800["ms_per_step"], "steps": n800["steps"],
+                            "roofline": ({k: n800["roofline"][k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                           "algorithmic_tflops", "kernel_ms_per_step")}
+                                         if n800.get("roofline") else None),
+                            "attention_ms_per_step": (n800["roofline"]["attention_kernels"]["kernel_ms_per_step"] if n800.get("roofline") else None),
+                            "cpu_baseline": None} if n800 is not None and "error" not in n800 else None),
             "small_e": None, "strong": None,
             "stress": (stress if stress is None or "error" in stress else
                        {"workload": "BASELINE.json configs[4]: 1 episode/GPU x 5 frames x 3x1600x1600, Q=200, fusion T=%d, same training step, "
@@ -673,12 +741,14 @@ def main():
                                                 "meta-train step at T = 12 755 needs 8 x T^2 fp32 attention tensors with double backward "
                                                 "on the host (BASELINE.md 3); never divide the n800 value by this figure -- the "
                                                 "like-for-like pair is `two_frame_episode`")
-                # the comparable pair: ONE meta-train episode of two 800 x 800 frames (T = 5 105) through the oracle and through HIP on
-                # one GPU box (tools/n800_two_frame.py; ~1-2 minutes of host time, so measured once per round and committed)
-                import glob
-                two = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_n800_two_frame_episode.json")))
-                if two:
-                    n800["two_frame_episode"] = dict(json.load(open(two[-1])), source="profiles/" + os.path.basename(two[-1]))
+                # the comparable pair: ONE meta-train episode of two 800 x 800 frames (T = 5 105) through the oracle and through HIP,
+                # measured here (~ 35 s of host time for the oracle's episode)
+                if not args.no_two_frame:
+                    n800["two_frame_episode"] = two_frame_pair(dev)
+                    line["north_star"]["cpu_baseline"] = dict(n800["two_frame_episode"]["cpu_baseline"],
+                                                              workload=n800["two_frame_episode"]["workload"],
+                                                              hip_frames_per_s_same_workload=n800["two_frame_episode"]["hip"]["frames_per_s"],
+                                                              gpu_over_cpu=n800["two_frame_episode"]["gpu_over_cpu"])
         sys.stdout.flush()
         os.write(JSON_FD, (json.dumps(line) + "\n").encode())   # the one line on the real stdout
     if world > 1:

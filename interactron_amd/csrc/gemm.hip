@@ -3284,11 +3284,15 @@ static bool epi_in_store_enabled() {
     return g_epi_in_store != 0;
 }
 // an unsplit launch of the fp16x3 kernel with a pending affine takes it in its store
+static bool epi_in_store_possible(const GemmArgs& a, bool x3_forward_kind) {   // the whole predicate, nothing mutated
+    if (!g_epi.scale || g_epi.applied || !x3_forward_kind || a.split_k != 1 || a.atomic || !a.c_vec || a.N % 4 || a.ldc % 4 || !epi_in_store_enabled()) return false;
+    if (!aligned16(g_epi.scale) || !aligned16(g_epi.shift) || (g_epi.res && !aligned16(g_epi.res)) || a.bias) return false;
+    return true;
+}
 static bool epi_in_store(GemmArgs& a, bool x3_forward_kind) {
     a.epi_scale = a.epi_shift = a.epi_res = nullptr;
     a.epi_relu = 0;
-    if (!g_epi.scale || !x3_forward_kind || a.split_k != 1 || a.atomic || !a.c_vec || a.N % 4 || a.ldc % 4 || !epi_in_store_enabled()) return false;
-    if (!aligned16(g_epi.scale) || !aligned16(g_epi.shift) || (g_epi.res && !aligned16(g_epi.res)) || a.bias) return false;
+    if (!epi_in_store_possible(a, x3_forward_kind)) return false;
     a.epi_scale = g_epi.scale; a.epi_shift = g_epi.shift; a.epi_res = g_epi.res; a.epi_relu = g_epi.relu;
     g_epi.applied = 1;
     ++g_epi_count[2];
@@ -3522,9 +3526,17 @@ static int gemm_impl(const float* A, const float* B, float* C, const float* bias
     const SplitEpi sep = epi_place(a, real);
     // (the 256 x 128 tiles have no such instance: an unsplit launch with a pending affine goes back to 128 x 128 tiles -- the pass
     //  it saves is worth more than their 4-8 %)
-    if (use_w2 && g_epi.scale && !g_epi.applied && split == 1 && a_kcontig && b_kcontig && batch_inner == 1 && !bias && epi_in_store_enabled()) {
-        use_w2 = false;
-        a.tiles_m = ix_div_up(M, bm);
+    //  The move happens only when the affine WILL ride in the store -- the full predicate (alignment of scale / shift / residual,
+    //  vector stores, N and ldc multiples of 4, persistent launch) evaluated on the 128-row plan first; otherwise the launch keeps its
+    //  256 x 128 tiles and the affine runs as the library's separate pass.
+    if (use_w2 && g_epi.scale && !g_epi.applied && split == 1) {
+        GemmArgs t = a;
+        t.tiles_m = ix_div_up(M, bm);
+        if (epi_in_store_possible(t, use_x3 && a_kcontig && b_kcontig && batch_inner == 1 && persistent_ok_pre(t, nbatch, split))) {
+            use_w2 = false;
+            a.tiles_m = t.tiles_m;
+            grid = dim3(a.tiles_m * a.tiles_n, nbatch, split);
+        }
     }
     const bool epi_store = !use_w2 && epi_in_store(a, use_x3 && a_kcontig && b_kcontig && batch_inner == 1 && persistent_ok_pre(a, nbatch, split));
     if (g_prof_on) {

@@ -234,16 +234,19 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
     if ent is None:   # first call of a signature: eager (warms BN folds, scratch, size caches); the next one captures
         state[key] = "warm"
 
-        def warm(inputs, policy_labels):   # ... and measures what a step of this signature needs beyond what is already held
-            # (an upper bound from the process-wide peak, which is left alone: whoever reports peak memory -- bench.py -- owns it)
+        def warm(inputs, policy_labels):   # ... and measures what a step of THIS signature needs beyond what is already held.
+            # The process-wide peak statistic is RESET for that (an earlier, larger signature -- 8 x 800^2 before 16 x 300^2 -- used to
+            # inflate the need and pin the later one to eager launches); a reader of max_memory_allocated() sees the peak since the
+            # latest first step of a signature, which is the step's own working set (bench.py resets it per workload anyway).
             base = torch.cuda.memory_allocated()
+            torch.cuda.reset_peak_memory_stats()
             res = run_eager(model, E, s, inputs, policy_labels)
             model.__dict__.setdefault("_chunk_peaks", {})[key] = max(0, torch.cuda.max_memory_allocated() - base)
             return res
         return warm
-    if ent == "eager":
+    if ent == "eager" or (isinstance(ent, tuple) and ent[1] == model._graph_stamp()[0]):
         return eager
-    if ent == "warm" or ent.stamp != model._graph_stamp()[0]:
+    if ent == "warm" or isinstance(ent, tuple) or ent.stamp != model._graph_stamp()[0]:
         def capture_then_run(inputs, policy_labels):
             fresh_grads = {id(p) for p in model.parameters() if p.grad is None}   # .grad tensors first bound inside the capture
             try:
@@ -262,8 +265,9 @@ def chunk_runner(model, E, s, shape, ldn, ldn1):
                     free, _ = torch.cuda.mem_get_info()
                     if free < 1.15 * need + (4 << 30):
                         # not an error: eager launches.  A first capture that does not fit stays eager; a RE-capture (stamp moved)
-                        # is tried again at the next stamp change -- a transient low reading must not pin the signature
-                        state[key] = "warm" if recapture else "eager"
+                        # is tried again when the stamp moves NEXT (("retry", stamp): eager until then) -- a transient low reading
+                        # must not pin the signature, and must not cost a collect + synchronize + empty_cache on every step either
+                        state[key] = ("retry", model._graph_stamp()[0]) if recapture else "eager"
                         return run_eager(model, E, s, inputs, policy_labels)
                 g = ChunkGraphs(model, E, s, shape, GRAPH_PITCH, GRAPH_PITCH, inputs["masks"].dtype)
                 g.load(inputs)

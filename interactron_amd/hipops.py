@@ -1025,7 +1025,11 @@ def flash_forward(q, k, v, g, mask, p, seed, need_backward=True, dtype=None):
         _chk(_L().ix_flash_fwd_fp8_f32(q8.data_ptr(), qus.data_ptr(), k8.data_ptr(), kus.data_ptr(), v8.data_ptr(), vus.data_ptr(),
                                        pl["bias"].data_ptr(), out.data_ptr(), lse.data_ptr(), g.n, g.heads, g.L, Lp, g.S, Sp,
                                        g.hd, E, 0, g.scale, p, seed, _stream()), "ix_flash_fwd_fp8_f32")
-        if need_backward:   # the derivative kernels recompute the scores from the fp16 planes: give them THEIR normalisers
+        if need_backward:   # the derivative kernels recompute the scores from the fp16 planes: give them normalisers of those scores
+            # (an lse-only pass, out == NULL: always the 32 x 32 forward kernel of csrc/flash.hip -- at head dim 64 the derivative passes
+            #  are flash16's, the same fp16x3 products in another accumulation order, so P sums to 1 up to fp32 rounding rather than
+            #  exactly; rows-only planes suffice, that kernel reads no tr planes without v.  tests/test_ops_gpu.py::
+            #  test_flash_fp8_forward_with_the_derivative_passes_of_either_family, tests/test_b800_gpu.py::test_stress_config_training_step_*)
             _chk(_L().ix_flash_fwd_f32(pl["q"].ref, pl["k"].ref, None, pl["bias"].data_ptr(), None, lse.data_ptr(), g.n, g.heads,
                                        g.L, Lp, g.S, Sp, g.hd, E, 0, g.scale, 0.0, 0, _stream()), "ix_flash_fwd_f32")
         return out, lse, pl
@@ -1735,12 +1739,11 @@ class ChannelScale(Function):
 class RowScale(Function):
     """w * scale[n] along the output-channel dim of a weight tensor -- linear [(E,) N, K] (tail = 1), convolution
     [(E,) Cout, KH, KW, Cin] (tail = 3) -- or of its gradient; scale is a constant buffer.  The result keeps standing for the
-    Parameter in skip_param_grads and on the weight-planes route."""
+    Parameter in skip_param_grads."""
 
     @staticmethod
     def forward(ctx, w, scale, tail):
         key = _param_key(w)
-        marked = getattr(w, "_ix_weight", False)
         w = _req(w, "weight")
         N = w.shape[-(tail + 1)]
         R = _numel(w.shape[-tail:])
@@ -1749,9 +1752,10 @@ class RowScale(Function):
              "ix_row_scale_f32")
         ctx.tail = tail
         ctx.save_for_backward(scale)
+        # the scaled copy keeps standing for its Parameter in skip_param_grads, but it is NOT marked for the weight-planes route:
+        # it is fresh in every backward and read by exactly one contraction, so its planes could never be reused -- an eager
+        # ix_wp_split_f32 launch per call for nothing, and inside a capture (planes, copy) pinned in the graph's pool for good
         out._ix_of_param = key
-        if marked:
-            mark_weight(out)
         return out
 
     @staticmethod

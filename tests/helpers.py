@@ -26,6 +26,10 @@ def _judge(kind, what, value, bound, detail):
         assert value <= bound, (what, kind) + tuple(detail)
         return
     r = value / max(bound, 1e-300)
+    if os.environ.get("IX_TEST_RECORD_ALL") and r > 0.2:   # every check above a fifth of its bound (per-tensor tolerance survey)
+        with open(path, "a") as f:
+            f.write("%s %.4f %s\n" % (kind, r, what))
+        return
     if r > _RATIOS.get(kind, (0.0, ""))[0]:
         _RATIOS[kind] = (r, what)
         with open(path, "a") as f:

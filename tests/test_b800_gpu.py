@@ -162,6 +162,31 @@ def test_stress_config_200_queries_fp32_and_fp8_attention():
     assert float((d8["pred_logits"] - d["pred_logits"]).abs().max()) > 0   # (the fp8 path really ran)
 
 
+FP8_TRAIN_LOSS, FP8_TRAIN_COS, FP8_TRAIN_NORM = 5e-2, 0.99, 0.15
+
+
+def test_stress_config_training_step_with_fp8_attention_against_the_oracle():
+    """BASELINE.json configs[4] as a TRAINING step at a size the oracle finishes in seconds: one 5-frame episode of 256 x 256
+    frames, NUM_QUERIES = 200 (fusion T = 5 (256 + 200) + 5 = 2285), the whole meta-train step of models/interactron.py:61-151
+    with the opt-in fp8 attention products on (``hipops.ATTENTION_DTYPE = "fp8"``: e4m3 MFMA in the forward products of every
+    attention call; the derivative kernels take their own fp16 normalisers, csrc/flash.hip) against the float32 CPU oracle:
+    every loss within 5 %, every gradient tensor's direction within cosine >= 0.99, norms within 15 % (e4m3 has 3 mantissa
+    bits: 6 % element error on the probabilities).  The fp32-grade path on the same inputs meets the usual bounds."""
+    import __graft_entry__ as entry
+    from interactron_amd import hipops
+    extra = dict(NUM_QUERIES=200, BLOCK_SIZE=5 * (16 * 16 + 200) + 5)
+    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=5e-3)
+    assert hipops.ATTENTION_DTYPE == "fp32"
+    hipops.ATTENTION_DTYPE = "fp8"
+    try:
+        got = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=FP8_TRAIN_NORM, loss_tol=FP8_TRAIN_LOSS,
+                                cos_min=FP8_TRAIN_COS)
+    finally:
+        hipops.ATTENTION_DTYPE = "fp32"
+    assert got["checked"] >= 300
+    assert any(got["norms"][k] != ref["norms"][k] for k in ref["norms"])   # (the fp8 products really ran)
+
+
 def test_stress_config_full_size_predict_properties():
     """BASELINE.json configs[4] at FULL size: one 5-frame episode of 3x1600x1600 frames (100 x 100 = 10 000 tokens per frame),
     200 queries, fusion T = 5 (10 000 + 200) + 5 = 51 005 (reference shapes: models/gpt.py:39-57,191, detr.py:331), forward

@@ -1553,6 +1553,49 @@ def test_flash_forward_fp8(ops, n, H, L, S, hd, masked):
     assert float((out32.cpu().double() - ref).norm()) < 1e-2 * float(err.norm())
 
 
+@pytest.mark.parametrize("hd", [64, 32])
+@pytest.mark.usefixtures("flash_form")
+def test_flash_fp8_forward_with_the_derivative_passes_of_either_family(ops, hd):
+    """ATTENTION_DTYPE = fp8 in a differentiated call (BASELINE.json configs[4] as a training step): the forward products run on
+    e4m3 operands, the derivative passes -- first and second order, the 16 x 16 family at head dim 64 or the 32 x 32 family
+    (``flash_form``) -- recompute the probabilities from the fp16 planes with normalisers of THEIR scores (an lse-only pass of the
+    32 x 32 forward kernel; the same fp16x3 products in another accumulation order than flash16's, so consistent to fp32
+    rounding, not bit for bit).  What the fp8 forward leaves in the gradients is its output through delta = dO . O.  Against
+    float64 autograd: everything finite, forward within the fp8 forward's 7 % relative L2, gradients within 15 %, second-order
+    cotangents within 20 % (measured values are printed)."""
+    n, H, L, S = 1, 4, 300, 517
+    E = H * hd
+    q, k, v = rnd(n, L, E, seed=21), rnd(n, S, E, seed=22), rnd(n, S, E, seed=23)
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
+    gy = rnd(n, L, E, seed=25)
+    ws = [rnd(n, L, E, seed=26), rnd(n, S, E, seed=27), rnd(n, S, E, seed=28)]
+
+    def second(dev, dt, fn):
+        x = [t.to(dev, dt).requires_grad_(True) for t in (q, k, v)]
+        gyd = gy.to(dev, dt).requires_grad_(True)
+        out = fn(*x)
+        g1 = torch.autograd.grad(out, x, gyd, create_graph=True)
+        s = sum((a * w.to(dev, dt)).sum() for a, w in zip(g1, ws))
+        return out, g1, torch.autograd.grad(s, x + [gyd])
+
+    old, ops.ATTENTION_DTYPE = ops.ATTENTION_DTYPE, "fp8"
+    try:
+        oh, g1h, g2h = second("cuda", torch.float32, lambda a, b, c: ops.FlashAttention.apply(a, b, c, g, None, 0.0, 0))
+    finally:
+        ops.ATTENTION_DTYPE = old
+    orf, g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, None, None))
+    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
+    errs = [("forward", rel(oh, orf), 0.07)] + [("grad " + nm, rel(a, b), 0.15) for nm, a, b in zip("qkv", g1h, g1r)] + \
+        [("second-order " + nm, rel(a, b), 0.20) for nm, a, b in zip(["q", "k", "v", "dO"], g2h, g2r)]
+    print("fp8 forward + fp16 derivative passes, head dim %d: " % hd + ", ".join("%s %.3f" % (nm, e) for nm, e, _ in errs))
+    for t in [oh] + list(g1h) + list(g2h):
+        assert bool(torch.isfinite(t).all())
+    for nm, e, bound in errs:
+        assert e <= bound, (nm, e, bound)
+    assert errs[0][1] > 1e-3   # (the fp8 products really ran)
+
+
 def test_sustained_mfma_rate_probe(ops):
     """ix_diag_mfma_rate_f16 (bench.py's `roofline.sustained_mfma_tflops_measured`): back-to-back fp16 matrix instructions on every
     SIMD.  An MI355X sustains 1.7-2.0 PFLOP/s of its 2.5 PFLOP/s data-sheet peak (the shader clock drops to ~ 1.8 GHz under this

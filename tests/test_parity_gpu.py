@@ -303,6 +303,58 @@ def test_g7_detector_forward(golden, interactron_model, episode1):
         check_record(rec, out[k], atol=rec_tol(rec), rtol=1e-3, what="g7/" + k)
 
 
+def _hash_tensor(tag, *shape):
+    import numpy as np
+    from interactron_amd.synthetic import hash_normal
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.from_numpy(hash_normal(tag, n).astype(np.float32)).reshape(*shape)
+
+
+@pytest.mark.usefixtures("kernel_form")
+def test_g5_bottlenecks_on_the_hip_modules(golden, interactron_model):
+    """G5 (reference backbone.py:88-90 = torchvision v1.5 bottlenecks + FrozenBatchNorm2d backbone.py:19-54, recorded by running
+    the reference's own modules): the strided block layer2.0 (stride on the 3x3, strided 1x1 downsample), layer4.0 (first block
+    of the dilated layer: keeps dilation 1, 1x1 downsample without stride) and layer4.1 (dilation 2) on the HIP modules alone --
+    implicit-GEMM convolutions with the frozen-BN affine / residual / ReLU riding on the contraction -- not through the whole
+    detector (G7)."""
+    M = golden("golden_model.pt")
+    body = interactron_model.detector.backbone[0].body
+    x = _hash_tensor("g5/x", 2, 256, 20, 20).abs().cuda()
+    x4 = _hash_tensor("g5/x4", 2, 1024, 10, 10).abs().cuda()
+    with torch.no_grad():
+        y2 = body.layer2[0](x.permute(0, 2, 3, 1).contiguous())
+        y40 = body.layer4[0](x4.permute(0, 2, 3, 1).contiguous())
+        y41 = body.layer4[1](y40)
+    for name, y in (("g5_layer2_0", y2), ("g5_layer4_0", y40), ("g5_layer4_1", y41)):
+        rec = M[name]
+        check_record(rec, y.permute(0, 3, 1, 2), atol=rec_tol(rec), rtol=1e-3, what=name)
+
+
+@pytest.mark.usefixtures("kernel_form")
+def test_g6_encoder_and_decoder_layer_on_the_hip_modules(golden, interactron_model):
+    """G6 (reference transformer.py:148-161 forward_post of the encoder layer, :211-232 of the decoder layer, eval mode, recorded
+    from the reference's own layers): 30 tokens x 2 sequences with a key-padding mask on the second one, 7 queries with a
+    per-sequence query position table -- the HIP layers alone (packed in_proj contraction, flash attention at head dim 32 with a
+    key bias, add + LayerNorm, FFN)."""
+    M = golden("golden_model.pt")
+    tr = interactron_model.detector.transformer
+    src, pos = _hash_tensor("g6/src", 30, 2, 256).cuda(), _hash_tensor("g6/pos", 30, 2, 256).cuda()
+    tgt, qp = _hash_tensor("g6/tgt", 7, 2, 256).cuda(), _hash_tensor("g6/qp", 7, 2, 256).cuda()
+    kpm = torch.zeros(2, 30, dtype=torch.uint8, device="cuda")
+    kpm[1, 25:] = 1
+    bf = lambda t: t.permute(1, 0, 2).contiguous()   # the reference is sequence-first, the HIP modules batch-first
+    with torch.no_grad():
+        enc = tr.encoder.layers[0](bf(src), kpm, bf(pos))
+        check_record(M["g6_enc"], enc.permute(1, 0, 2), atol=rec_tol(M["g6_enc"]), rtol=1e-3, what="g6_enc")
+        # decoder layer: the memory is the REFERENCE's encoder output only up to fp32 rounding -- use ours (as the reference did its own)
+        from interactron_amd import hipops
+        memory_key = hipops.add(enc, bf(pos))
+        dec = tr.decoder.layers[0](bf(tgt), enc, memory_key, kpm, bf(qp).reshape(2, 7 * 256))
+        check_record(M["g6_dec"], dec.permute(1, 0, 2), atol=rec_tol(M["g6_dec"]), rtol=1e-3, what="g6_dec")
+
+
 @pytest.mark.usefixtures("kernel_form")
 def test_g8_g9_fusion_and_learned_loss_gradient(golden, interactron_model, episode1):
     from interactron_amd import NestedTensor, hipops
@@ -360,6 +412,43 @@ F64_TIGHT = (3e-3, 5e-3)
 F64_KINK_TENSORS = 2
 
 
+# Second-order gradients (G13, config 3): SURVEY 8d's 1e-3 per tensor + 3 x the reference's OWN float32 error on that tensor
+# (|fp32 - fp64| from tests/golden/golden_train_f64.pt, passed to check_grad as norm64 / sample64) -- round 5 used a blanket
+# 5e-3.  The tensors below need more than that in at least one contraction form (measured with IX_TEST_RECORD_ALL=1, the
+# worst ratio over the three forms rounded up; BASELINE.md section 4 lists them with the measurements): elements of the
+# clipped inner step and ReLUs upstream of them sit on kinks and flip under any other float32 summation order.
+SECOND_ORDER_REL = {
+}
+
+
+def second_order_rel(what):
+    return SECOND_ORDER_REL.get(what, 1e-3)
+
+
+def _decompress(rec):
+    return rec["half"].float() * 2.0 ** rec["exp"]
+
+
+def check_full_gradients(F, model, cos_min=0.9999, norm_rel=2e-3):
+    """G13b (tests/golden/golden_train_full.pt, make_golden_full.py): WHOLE gradient tensors of the reference's step for a dozen
+    representative parameters at the real 300 x 300 / T = 2060 shape: cosine >= 0.9999 over every element, norm within 2e-3."""
+    worst = (1.0, "")
+    for grp, mod in (("detector", model.detector), ("fusion", model.fusion)):
+        named = dict(mod.named_parameters())
+        for k, rec in F[grp].items():
+            g = named[k].grad.detach().cpu()
+            if g.dim() == 4 and tuple(g.shape) != tuple(rec["shape"]):
+                g = g.permute(0, 3, 1, 2).contiguous()   # conv weights are stored [out, kh, kw, in]
+            assert tuple(g.shape) == tuple(rec["shape"]), (k, tuple(g.shape), rec["shape"])
+            ref = _decompress(rec).double()
+            cos = float((g.double() * ref).sum() / (g.double().norm() * ref.norm()))
+            worst = min(worst, (cos, grp + "." + k))
+            assert cos >= cos_min, (grp, k, "direction over the whole tensor", cos)
+            n = float(g.double().norm())
+            assert abs(n - rec["norm"]) <= max(norm_rel, 2 * second_order_rel("g13/%s.%s" % (grp, k))) * rec["norm"] + 1e-9, (grp, k, n, rec["norm"])
+    print("G13b: %d whole gradient tensors, smallest cosine %.7f on %s" % (len(F["detector"]) + len(F["fusion"]), worst[0], worst[1]))
+
+
 def test_g13_g16_meta_train_step_and_outer_update(golden, kernel_form):
     T = golden("golden_train.pt")
     F64 = golden("golden_train_f64.pt")   # exact (float64 oracle) norms: bounds the reference's own float32 noise
@@ -377,11 +466,12 @@ def test_g13_g16_meta_train_step_and_outer_update(golden, kernel_form):
     for k, v in T["g13"]["losses"].items():
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), (k, float(losses[k]), float(v))
     for k, p in m.detector.named_parameters():
-        check_grad(T["g13"]["detector_grads"][k], p.grad, rel=5e-3, what="g13/detector." + k,
+        check_grad(T["g13"]["detector_grads"][k], p.grad, rel=second_order_rel("g13/detector." + k), what="g13/detector." + k,
                    norm64=F64["detector_grads"].get(k), sample64=F64["detector_grads_sample64"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(T["g13"]["fusion_grads"][k], p.grad, rel=5e-3, what="g13/fusion." + k,
+        check_grad(T["g13"]["fusion_grads"][k], p.grad, rel=second_order_rel("g13/fusion." + k), what="g13/fusion." + k,
                    norm64=F64["fusion_grads"].get(k), sample64=F64["fusion_grads_sample64"].get(k))
+    check_full_gradients(golden("golden_train_full.pt"), m)
     # "Is HIP as close to the truth as the reference is?"  Against the float64 oracle, per tensor, on the norm and on the 256
     # strided positions: |HIP - f64| <= 2 |reference fp32 - f64| + F64_SLACK |f64|  (the excess over twice the reference's
     # own float32 error, relative to the tensor; the worst tensors are printed).
@@ -789,10 +879,10 @@ def test_config3_interactron_random(golden, episode1):
         assert abs(float(losses[k]) - float(v)) <= 2e-3 * max(abs(float(v)), 1.0), k
     F64 = golden("golden_train_f64.pt")["configs"]["random_forward"]
     for k, p in m.detector.named_parameters():
-        check_grad(O["random_forward"]["detector_grads"][k], p.grad, rel=5e-3, what="rand/detector." + k,
+        check_grad(O["random_forward"]["detector_grads"][k], p.grad, rel=second_order_rel("rand/detector." + k), what="rand/detector." + k,
                    norm64=F64["detector_grads"].get(k))
     for k, p in m.fusion.named_parameters():
-        check_grad(O["random_forward"]["fusion_grads"][k], p.grad, rel=5e-3, what="rand/fusion." + k,
+        check_grad(O["random_forward"]["fusion_grads"][k], p.grad, rel=second_order_rel("rand/fusion." + k), what="rand/fusion." + k,
                    norm64=F64["fusion_grads"].get(k))
 
 
