@@ -436,6 +436,29 @@ int ix_sine_pos_f32(const uint8_t* mask, float* pos, int n, int h, int w, int nu
                     float scale, ix_stream_t stream);
 int ix_mask_nearest_u8(const uint8_t* in, uint8_t* out, int n, int H, int W, int h, int w, ix_stream_t stream);
 
+/* ---- The 16-bit activation mode (MODEL.COMPUTE_DTYPE: bf16 -- BASELINE.json configs[1] "multi_frame_baseline ... bf16"; the reference
+ * computes all of it in fp32: models/gpt.py:39-78, models/detr_models/transformer.py:148-232, backbone.py:88-90).  Activations live in
+ * HBM as bf16 (device pointers to 2-byte elements, passed as void*); statistics, accumulation and parameters stay fp32.
+ *   ix_gemm_b16   : C[b] = act((alpha A[b] B[b] + bias[n]) scale[n] + shift[n] + residual) with bf16 A, B (csrc/gemm16.hip: both
+ *                   operand tiles HBM -> LDS by LDS-DMA, one v_mfma_f32_16x16x32_bf16 per k-slice, fp32 accumulation).  Layouts and
+ *                   batch strides as ix_gemm_f32 (a_kcontig: A(m, k) = A[m lda + k], else A[k lda + m]; likewise B(k, n)); C and
+ *                   `residual` (same indexing as C) are bf16, or fp32 when c_f32; bias [N] per outer slice (bias_stride), scale /
+ *                   shift [N] (a frozen-BN affine, backbone.py:19-54) or null; act 0 none, 1 ReLU, 2 GELU (erf form).  Contractions
+ *                   with few output tiles and a long K are cut along K into fp32 planes in `workspace` (ticket layout, see
+ *                   ix_colsum_f32) and added in order.  Requirements: ix_gemm_b16_supported (16-byte aligned rows).
+ *   ix_cast_*     : elementwise fp32 <-> bf16 (round to nearest even), n elements, 16-byte aligned pointers.
+ *   ix_prof_b16   : profiled ix_gemm_b16 launches (summed event ms, FLOPs, algorithmic HBM bytes, launches). */
+int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int a_kcontig, int b_kcontig,
+                int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo, int64_t sAi, int64_t sBo,
+                int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride, float alpha, int c_f32, const float* scale,
+                const float* shift, const void* residual, int act, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_gemm_b16_supported(const void* A, const void* B, const void* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
+                          int64_t ldb, int64_t ldc, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi);
+int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out_host);
+int ix_cast_f32_b16(const float* x, void* y, int64_t n, ix_stream_t stream);
+int ix_cast_b16_f32(const void* x, float* y, int64_t n, ix_stream_t stream);
+int ix_prof_b16(double* ms, double* flops, double* bytes, int64_t* launches);
+
 /* Episode expansion of a parameter list and its adjoint, all tensors in one launch set (HOST arrays of device pointers;
  * sizes[i] = elements of one copy).  expand: out_i[E][n_i] = E copies of src_i[n_i] -- the per-episode copies of theta the
  * episode-batched step differentiates (reference models/interactron.py:86-90, clone_parameters per task);  reduce:

@@ -52,18 +52,13 @@ def arg_check(arg, choices, argname):
 def build_model(args):
     arg_check(args.TYPE, MODEL_TYPES, "model")
     from . import episode
-    # MODEL.COMPUTE_DTYPE: f32 (default, the parity path) | bf16 / fp16 (single-pass 16-bit contractions).  The mode is process-wide
-    # (it is a switch of the kernel library): it is set on EVERY build, so that a model built without the key after a 16-bit one
-    # is back on the fp32-grade path, and a change is said once.
-    from . import hipops
-    dtype = getattr(args, "COMPUTE_DTYPE", "f32")
-    old = hipops.set_compute_dtype(dtype)
-    if old != hipops.COMPUTE_DTYPE:
-        import warnings
-        warnings.warn("MODEL.COMPUTE_DTYPE %r: contractions of this process now run in the %s mode (was %s)%s"
-                      % (dtype, hipops.COMPUTE_DTYPE, old, "; 'fp16' / 'half' select the same single-pass 16-bit mode as 'bf16'"
-                         if str(dtype).lower() in ("fp16", "half", "f16") else ""))
-    return getattr(episode, args.TYPE)(args)
+    # MODEL.COMPUTE_DTYPE: f32 (default, the parity path) | bf16 (16-bit activations, b16.py) | single_pass / fp16 (fp32 storage,
+    # single-pass 16-bit contractions).  It is the MODEL's mode: stored on it and put in force at each of its entry points
+    # (hipops.compute_mode) -- building a model neither loads the kernel library nor touches any other model's arithmetic.
+    from .hipops import normalize_compute_dtype
+    model = getattr(episode, args.TYPE)(args)
+    model.compute_dtype = normalize_compute_dtype(getattr(args, "COMPUTE_DTYPE", "f32"))
+    return model
 
 
 def build_trainer(model, args, evaluator=None):

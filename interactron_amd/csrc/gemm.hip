@@ -2751,7 +2751,7 @@ static int64_t g_launches = 0;
 static bool g_prof_on = false;
 static std::vector<hipEvent_t> g_ev;
 static size_t g_ev_used = 0;
-struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; double flops = 0.0, mfma_flops = 0.0; };   // bm 2002: a flash attention launch
+struct ProfRec { int M, N, K, nbatch, a_kc, b_kc, bm, split; double flops = 0.0, mfma_flops = 0.0, bytes = 0.0; };   // bm 2002: a flash attention launch
 static std::vector<ProfRec> g_rec;
 static double g_flash_flops = 0.0;
 static int64_t g_flash_launches = 0;
@@ -2870,7 +2870,7 @@ extern "C" int ix_prof_kinds3(double* ms3, double* flops3, int64_t* launches3) {
         float t = 0.f;
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
         const ProfRec& r = g_rec[i / 2];
-        if (r.bm == 3128) continue;   // pre-split fp16x3 kernel: reported by ix_prof_x3
+        if (r.bm == 3128 || r.bm == 1616) continue;   // pre-split fp16x3 kernel: reported by ix_prof_x3; bf16 GEMM: ix_prof_b16
         const int k = r.bm == 2002 ? 2 : ((r.bm == 1128 || r.bm == 1129 || r.bm == 1131) ? 1 : 0);
         ms[k] += t;
         fl[k] += r.flops;
@@ -2892,7 +2892,7 @@ extern "C" int ix_prof_contractions(double* ms3, double* flops3, double* mfma_fl
     int64_t n[3] = {0, 0, 0};
     for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
         const ProfRec& r = g_rec[i / 2];
-        if (r.bm == 2002 || r.bm == 3128) continue;
+        if (r.bm == 2002 || r.bm == 3128 || r.bm == 1616) continue;
         hipEventSynchronize(g_ev[i + 1]);
         float t = 0.f;
         hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
@@ -2913,7 +2913,7 @@ extern "C" int ix_prof_contraction_bytes(double* bytes3) {
     double by[3] = {0, 0, 0};
     for (size_t i = 0; i / 2 < g_rec.size() && i + 1 < g_ev_used; i += 2) {
         const ProfRec& r = g_rec[i / 2];
-        if (r.bm == 2002 || r.bm == 3128) continue;
+        if (r.bm == 2002 || r.bm == 3128 || r.bm == 1616) continue;
         const int k = (r.bm == 1129 || r.bm == 1131) ? 2 : (r.bm == 1128 ? 1 : 0);
         by[k] += 4.0 * ((double)r.M * r.K + (double)r.K * r.N + (double)r.M * r.N) * (double)(r.nbatch > 0 ? r.nbatch : 1);
     }
@@ -3029,6 +3029,40 @@ void ix_prof_begin_wp(hipStream_t stream, int M, int N, int K, int nbatch) {
     r.mfma_flops = 3.0 * fl;
     g_rec.push_back(r);
     prof_mark(stream);
+}
+
+// ... and for the bf16 GEMM of the 16-bit mode (csrc/gemm16.hip): tile code 1616, one matrix instruction per multiply-add, `bytes` =
+// its algorithmic HBM bytes (bf16 operands, bf16 / fp32 result); counted by ix_gemm_stats like every contraction
+void ix_prof_begin_b16(hipStream_t stream, int M, int N, int K, int nbatch, double bytes) {
+    const double fl = 2.0 * (double)M * (double)N * (double)K * (double)nbatch;
+    g_flops += fl;
+    g_launches += 1;
+    if (!g_prof_on) return;
+    ProfRec r = {M, N, K, nbatch, 1, 1, 1616, 1};
+    r.flops = fl;
+    r.mfma_flops = fl;
+    r.bytes = bytes;
+    g_rec.push_back(r);
+    prof_mark(stream);
+}
+// Profiled launches of the bf16 GEMM: summed event time (ms), algorithmic FLOPs (= executed: one term), algorithmic bytes, launches.
+// Call before ix_gemm_prof_read (which clears the records).
+extern "C" int ix_prof_b16(double* ms, double* flops, double* bytes, int64_t* launches) {
+    double m = 0, f = 0, b = 0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < g_ev_used && i / 2 < g_rec.size(); i += 2) {
+        const ProfRec& r = g_rec[i / 2];
+        if (r.bm != 1616) continue;
+        hipEventSynchronize(g_ev[i + 1]);
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_ev[i], g_ev[i + 1]);
+        m += t; f += r.flops; b += r.bytes; n += 1;
+    }
+    if (ms) *ms = m;
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+    if (launches) *launches = n;
+    return IX_OK;
 }
 
 // Profiled launches of the weight-planes kernel alone (they are ALSO part of slot [2], the fp16x3 arithmetic, of

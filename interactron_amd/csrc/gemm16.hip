@@ -1,0 +1,400 @@
+// bf16 GEMM for the 16-bit activation mode (MODEL.COMPUTE_DTYPE: bf16 -- BASELINE.json configs[1] "multi_frame_baseline ... bf16"):
+//
+//   C[b](M x N) = act( (alpha * A[b](M x K) * B[b](K x N) + bias[n]) * scale[n] + shift[n] + residual[m][n] )
+//
+// A, B live in HBM as bf16 -- activations written as bf16 by their producers, weights cast once per version -- so nothing is
+// converted on the way to the matrix cores: both operand tiles go HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane, no
+// registers, no VALU), one v_mfma_f32_16x16x32_bf16 per k-slice, fp32 accumulation, bf16 (or fp32) store.  This is the kernel form the
+// fp32-on-16-bit kernels of gemm.hip cannot be (their producers split every fp32 element into fp16 planes on the SIMDs that issue the
+// matrix instructions: DESIGN.md 4.1c).  Reference call sites: every nn.Linear / 1x1 convolution of models/detr_models/transformer.py:
+// 148-232, models/gpt.py:39-78, models/detr_models/detr.py:37-40,299-311, models/transformer.py:47-66 and the two gradients autograd
+// derives from each of them.
+//
+// Operand layouts (the same four the fp32 entry point takes):  A(m, k) = a_kc ? A[m * lda + k] : A[k * lda + m],
+// B(k, n) = b_kc ? B[n * ldb + k] : B[k * ldb + n];  C[m * ldc + n].  Rows must start on 16 bytes (ld, offsets, strides % 8 == 0).
+//
+// Tile 128 x 128 x 64, four waves of 64 x 64 outputs, ONE 32 KB LDS stage, <= 128 registers: four workgroups per CU cover each
+// other's DMA latency and barriers (the structure of gemm_wp.hip, measured there against a two-stage / two-workgroup predecessor).
+//   * k-contiguous operand: LDS image [128 rows][64 k] (128-byte rows), 16-byte chunks XOR-swizzled with (row >> 1) & 7 ON THE
+//     SOURCE ADDRESS (the DMA writes lane-linear); fragments by ds_read_b128, conflict-free.
+//   * m / n-contiguous operand (the transposed ones of the gradients: dW = dY^T X has BOTH): LDS image [64 k][128 m] (256-byte
+//     rows), 16-byte units XOR-swizzled with 2 ((k & 3) + 4 ((k >> 3) & 1)); fragments by ds_read_b64_tr_b16, the gfx950 transposing
+//     read (lane (i, g) receives k = kbase + 0..3 of column i: tools/micro/m16_layout.hip fact 2), conflict-free.
+//   * the matrix instruction computes C^T blocks (its A operand is the N-side fragment, its B operand the M-side one): a lane then
+//     holds FOUR CONSECUTIVE n of one row m -- 8-byte bf16 / 16-byte fp32 stores, and bias / scale / shift as one float4 per block.
+//   * K tails and rows beyond the operand are requested out of range (the buffer load returns zeros); M / N tails clamp the row.
+//   * split-K (small outputs with long K: the weight gradients): fp32 partial planes in the caller's workspace, added in order by
+//     gemm16_reduce_kernel together with the epilogue -- deterministic, like the fp32 kernels' split-K.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int G16_BM = 128, G16_BN = 128, G16_BK = 64;
+constexpr int G16_IMG = 128 * 64 * 2;   // one operand tile in LDS: 16 KB in either orientation
+
+void ix_prof_begin_b16(hipStream_t stream, int M, int N, int K, int nbatch, double bytes);
+
+struct G16Args {
+    const unsigned short* A;
+    const unsigned short* B;
+    void* C;
+    const float* bias;
+    const float *scale, *shift;
+    const void* res;
+    float* planes;          // split-K partial planes [split][batch][M][N] (fp32) or null
+    int64_t lda, ldb, ldc, sAo, sAi, sBo, sBi, sCo, sCi, sBias;
+    unsigned extA, extB;    // bytes addressable from a batch slice's base (buffer bounds)
+    int M, N, K, nk, kps, split, tiles_m, tiles_n, batch_inner;
+    float alpha;
+    int act;                // 0 none, 1 ReLU, 2 GELU (tanh-free erf form, as F.gelu)
+};
+
+__device__ __forceinline__ int g16_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ void g16_dma16(__amdgpu_buffer_rsrc_t r, int voff, int soff, void* lds) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ u32x2 g16_tr(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p)));
+}
+__device__ __forceinline__ unsigned g16_pack2(float a, float b) {   // two fp32 -> packed bf16 pair, round to nearest even
+    unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+    ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) & 0xffff0000u;
+    return ua | ub;
+}
+__device__ __forceinline__ float g16_bf(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ float g16_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+
+#define G16_OOB 0x7ffffff0
+
+// A_KC / B_KC: the operand's contracted index is contiguous in HBM.  F32OUT: C (and the residual) are fp32.
+template <bool A_KC, bool B_KC, bool F32OUT>
+__global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G16_IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, g = lane >> 4;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = g16_xcd_swizzle(blockIdx.x, nwg);
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (tile % group_size) % gm, tn = (tile % group_size) / gm;
+    const int m0 = tm * G16_BM, n0 = tn * G16_BN;
+    const int zb = blockIdx.y, bo = zb / p.batch_inner, bi = zb - bo * p.batch_inner;
+    const int ks = blockIdx.z;
+    const int kt0 = ks * p.kps, kt1 = min(p.nk, kt0 + p.kps);
+    const unsigned short* A = p.A + bo * p.sAo + bi * p.sAi;
+    const unsigned short* B = p.B + bo * p.sBo + bi * p.sBi;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, p.extA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, p.extB, 0x00020000);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // ---- DMA: pieces q = 4 wave .. 4 wave + 3 of each image; lane l of piece q fills the 16-byte slot q * 64 + l ----------------
+    // per-lane byte offset of the slot's source at k step 0, the k index (0..63) it holds, and the per-k-step advance (scalar)
+    int va[4], vb[4], ka[4], kb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int slot = (wave * 4 + q) * 64 + lane;
+        if (A_KC) {
+            const int row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
+            va[q] = (min(m0 + row, p.M - 1) * (int)p.lda + c * 8) * 2;
+            ka[q] = c * 8;
+        } else {
+            const int kr = slot >> 4, u = (slot & 15) ^ (2 * ((kr & 3) + 4 * ((kr >> 3) & 1)));
+            va[q] = (kr * (int)p.lda + m0 + u * 8) * 2;
+            ka[q] = kr;
+        }
+        if (B_KC) {
+            const int row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
+            vb[q] = (min(n0 + row, p.N - 1) * (int)p.ldb + c * 8) * 2;
+            kb[q] = c * 8;
+        } else {
+            const int kr = slot >> 4, u = (slot & 15) ^ (2 * ((kr & 3) + 4 * ((kr >> 3) & 1)));
+            vb[q] = (kr * (int)p.ldb + n0 + u * 8) * 2;
+            kb[q] = kr;
+        }
+    }
+    const int stepA = A_KC ? G16_BK * 2 : G16_BK * (int)p.lda * 2;
+    const int stepB = B_KC ? G16_BK * 2 : G16_BK * (int)p.ldb * 2;
+
+    // ---- fragment addresses (bytes inside an image) -------------------------------------------------------------------------------
+    // k-contiguous image: row (w + 16 rb + idx) * 128 + ((4 s + g) ^ swz) * 16, swz = (idx >> 1) & 7 (w and 16 rb are multiples of 16)
+    // m-contiguous image: k = 32 s + 8 g + 4 h + (idx >> 2); unit (w / 8 + 2 rb + ((idx & 3) >> 1)) ^ f, f = 2 ((idx >> 2) + 4 (g & 1))
+    const int swz = (idx >> 1) & 7;
+    const int kcA = (wm + idx) * 128, kcB = (wn + idx) * 128;
+    const int kc0 = ((g ^ swz) << 4), kc1 = (((4 + g) ^ swz) << 4);
+    const int trk = (8 * g + (idx >> 2)) * 256 + 8 * (idx & 1);
+    const int trf = 2 * ((idx >> 2) + 4 * (g & 1));
+    const int truA = (wm >> 3) + ((idx & 3) >> 1), truB = (wn >> 3) + ((idx & 3) >> 1);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    unsigned char* const imgA = lds;
+    unsigned char* const imgB = lds + G16_IMG;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        {
+            unsigned char* dA = imgA + wave * 4096;
+            unsigned char* dB = imgB + wave * 4096;
+            const int klim = p.K - kt * G16_BK;   // k indices >= klim of this stage do not exist: out-of-range request -> zeros
+            const int sa = kt * stepA, sb = kt * stepB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g16_dma16(rA, ka[q] < klim ? va[q] : G16_OOB, sa, dA + q * 1024);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g16_dma16(rB, kb[q] < klim ? vb[q] : G16_OOB, sb, dB + q * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+        __syncthreads();                                    // everybody's have
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fm[4], fn[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                if (A_KC) {
+                    fm[rb] = *reinterpret_cast<const u32x4*>(imgA + kcA + rb * 2048 + (s ? kc1 : kc0));
+                } else {
+                    const unsigned char* b0 = imgA + trk + s * 8192 + (((truA + 2 * rb) ^ trf) << 4);
+                    const u32x2 lo = g16_tr(b0), hi = g16_tr(b0 + 4 * 256);
+                    fm[rb] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+                if (B_KC) {
+                    fn[rb] = *reinterpret_cast<const u32x4*>(imgB + kcB + rb * 2048 + (s ? kc1 : kc0));
+                } else {
+                    const unsigned char* b0 = imgB + trk + s * 8192 + (((truB + 2 * rb) ^ trf) << 4);
+                    const u32x2 lo = g16_tr(b0), hi = g16_tr(b0 + 4 * 256);
+                    fn[rb] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fn[j]), __builtin_bit_cast(bf16x8, fm[i]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();   // the stage may be overwritten
+    }
+
+    // ---- epilogue: lane (idx, g) of block (i, j) holds row m = wm + 16 i + idx, columns n = wn + 16 j + 4 g .. + 3 -----------------
+    if (p.planes) {   // split-K: the raw partial sums of this split, fp32, dense [M][N]
+        float* P = p.planes + ((int64_t)ks * gridDim.y + zb) * (int64_t)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn + 16 * j + 4 * g;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(P + (int64_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+    const int64_t cbase = bo * p.sCo + bi * p.sCi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + 16 * j + 4 * g;
+        if (n >= p.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+        if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m >= p.M) continue;
+            const int64_t o = cbase + (int64_t)m * p.ldc + n;
+            f32x4 v = (acc[i][j] * p.alpha + bv) * sc + sh;
+            if (p.res) {
+                if (F32OUT) v += *reinterpret_cast<const f32x4*>((const float*)p.res + o);
+                else {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>((const unsigned short*)p.res + o);
+                    v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+                    v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+                }
+            }
+            v.x = g16_act(v.x, p.act); v.y = g16_act(v.y, p.act); v.z = g16_act(v.z, p.act); v.w = g16_act(v.w, p.act);
+            if (F32OUT) *reinterpret_cast<f32x4*>((float*)p.C + o) = v;
+            else *reinterpret_cast<u32x2*>((unsigned short*)p.C + o) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
+        }
+    }
+}
+
+// split-K tail: C = epilogue(sum over splits, in order); one thread per four consecutive n
+template <bool F32OUT>
+__global__ __launch_bounds__(256) void gemm16_reduce_kernel(G16Args p, int nbatch) {
+    const int64_t per = (int64_t)p.M * (p.N / 4);
+    const int64_t total = per * nbatch;
+    const int64_t plane = (int64_t)nbatch * p.M * p.N;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int zb = (int)(t / per);
+        const int64_t r = t - (int64_t)zb * per;
+        const int m = (int)(r / (p.N / 4)), n = (int)(r - (int64_t)m * (p.N / 4)) * 4;
+        const int bo = zb / p.batch_inner, bi = zb - bo * p.batch_inner;
+        const float* src = p.planes + ((int64_t)zb * p.M + m) * p.N + n;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        for (int s = 1; s < p.split; ++s) a += *reinterpret_cast<const f32x4*>(src + (int64_t)s * plane);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + bo * p.sBias + n);
+        if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+        const int64_t o = bo * p.sCo + bi * p.sCi + (int64_t)m * p.ldc + n;
+        f32x4 v = (a * p.alpha + bv) * sc + sh;
+        if (p.res) {
+            if (F32OUT) v += *reinterpret_cast<const f32x4*>((const float*)p.res + o);
+            else {
+                const u32x2 q = *reinterpret_cast<const u32x2*>((const unsigned short*)p.res + o);
+                v.x += __uint_as_float(q.x << 16); v.y += __uint_as_float(q.x & 0xffff0000u);
+                v.z += __uint_as_float(q.y << 16); v.w += __uint_as_float(q.y & 0xffff0000u);
+            }
+        }
+        v.x = g16_act(v.x, p.act); v.y = g16_act(v.y, p.act); v.z = g16_act(v.z, p.act); v.w = g16_act(v.w, p.act);
+        if (F32OUT) *reinterpret_cast<f32x4*>((float*)p.C + o) = v;
+        else *reinterpret_cast<u32x2*>((unsigned short*)p.C + o) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
+    }
+}
+
+// ---- plan: how many splits of K ------------------------------------------------------------------------------------------------
+static void g16_plan(int M, int N, int K, int nbatch, int* split, int* kps) {
+    const int nk = ix_div_up(K, G16_BK);
+    const int64_t tiles = (int64_t)ix_div_up(M, G16_BM) * ix_div_up(N, G16_BN) * nbatch;
+    int s = 1;
+    // 256 CUs x 4 resident workgroups: a launch with fewer than ~512 tiles and a long K is cut along K (at least 4 k steps a split)
+    if (tiles < 512 && nk >= 8) {
+        s = (int)((1024 + tiles - 1) / tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+    }
+    const int per = ix_div_up(nk, s);
+    *kps = per;
+    *split = ix_div_up(nk, per);
+}
+
+extern "C" int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out) {
+    IX_CHECK_ARG(out && M >= 0 && N >= 0 && K >= 0 && nbatch >= 0, "ix_workspace_bytes_gemm_b16: bad args");
+    int split = 1, kps = 1;
+    if (M > 0 && N > 0 && K > 0 && nbatch > 0) g16_plan(M, N, K, nbatch, &split, &kps);
+    *out = split > 1 ? IX_TICKET_BYTES + (size_t)split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float) : 0;
+    return IX_OK;
+}
+
+// 1 when ix_gemm_b16 takes these operands (16-byte aligned rows everywhere, 4-element aligned C rows), else 0: the caller then
+// converts and uses the fp32 entry point.
+extern "C" int ix_gemm_b16_supported(const void* A, const void* B, const void* C, int M, int N, int K, int a_kcontig, int b_kcontig,
+                                     int64_t lda, int64_t ldb, int64_t ldc, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi,
+                                     int64_t sCo, int64_t sCi) {
+    const bool al = ix_al16(A) && ix_al16(B) && (reinterpret_cast<uintptr_t>(C) & 15) == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                    sAo % 8 == 0 && sAi % 8 == 0 && sBo % 8 == 0 && sBi % 8 == 0 && ldc % 4 == 0 && sCo % 4 == 0 && sCi % 4 == 0 && N % 4 == 0;
+    if (!al || M <= 0 || N <= 0 || K <= 0) return 0;
+    if ((a_kcontig || b_kcontig) && K % 8 != 0) return 0;   // a 16-byte chunk of a k-contiguous row must not straddle the K edge
+    const int64_t extA = a_kcontig ? ((int64_t)(M - 1) * lda + K) : ((int64_t)(K - 1) * lda + M);
+    const int64_t extB = b_kcontig ? ((int64_t)(N - 1) * ldb + K) : ((int64_t)(K - 1) * ldb + N);
+    if (extA * 2 >= 0x7fffff00ll || extB * 2 >= 0x7fffff00ll) return 0;   // 32-bit DMA offsets
+    return 1;
+}
+
+extern "C" int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int a_kcontig, int b_kcontig,
+                           int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo, int64_t sAi,
+                           int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride, float alpha, int c_f32,
+                           const float* scale, const float* shift, const void* residual, int act, void* workspace,
+                           size_t workspace_bytes, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch_outer <= 0 || batch_inner <= 0) return IX_OK;
+    IX_CHECK_ARG(A && B && C && K > 0, "ix_gemm_b16: null operand or K <= 0");
+    IX_CHECK_ARG(ix_gemm_b16_supported(A, B, C, M, N, K, a_kcontig, b_kcontig, lda, ldb, ldc, sAo, sAi, sBo, sBi, sCo, sCi),
+                 "ix_gemm_b16: operands must have 16-byte aligned rows (ld, offsets, strides multiples of 8 elements; K %% 8 == 0 for "
+                 "k-contiguous operands; N, ldc multiples of 4) and fit 2 GB per batch slice");
+    IX_CHECK_ARG((scale == nullptr) == (shift == nullptr), "ix_gemm_b16: scale and shift come together");
+    IX_CHECK_ARG((!bias || ix_al16(bias)) && (!scale || (ix_al16(scale) && ix_al16(shift))) && bias_stride % 4 == 0,
+                 "ix_gemm_b16: bias / scale / shift must be 16-byte aligned");
+    IX_CHECK_ARG(act >= 0 && act <= 2, "ix_gemm_b16: act must be 0 (none), 1 (ReLU) or 2 (GELU)");
+    const int nbatch = batch_outer * batch_inner;
+    G16Args a;
+    a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.C = C; a.bias = bias; a.scale = scale; a.shift = shift; a.res = residual;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi; a.sBias = bias_stride;
+    a.extA = (unsigned)(2 * (a_kcontig ? ((int64_t)(M - 1) * lda + K) : ((int64_t)(K - 1) * lda + M)));
+    a.extB = (unsigned)(2 * (b_kcontig ? ((int64_t)(N - 1) * ldb + K) : ((int64_t)(K - 1) * ldb + N)));
+    a.M = M; a.N = N; a.K = K; a.nk = ix_div_up(K, G16_BK);
+    g16_plan(M, N, K, nbatch, &a.split, &a.kps);
+    a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN); a.batch_inner = batch_inner;
+    a.alpha = alpha; a.act = act; a.planes = nullptr;
+    if (a.split > 1) {
+        const size_t need = (size_t)a.split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float);
+        if (!workspace || workspace_bytes < need + IX_TICKET_BYTES) { a.split = 1; a.kps = a.nk; }   // no scratch: one pass over K
+        else a.planes = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+    }
+    IX_CHECK_ARG(nbatch <= 65535 && a.split <= 65535, "ix_gemm_b16: too many batch slices");
+    const dim3 grid(a.tiles_m * a.tiles_n, nbatch, a.split);
+    const double bytes = 2.0 * ((double)M * K + (double)K * N) * nbatch + (c_f32 ? 4.0 : 2.0) * (double)M * N * nbatch;
+    ix_prof_begin_b16(stream, M, N, K, nbatch, bytes);
+#define G16_LAUNCH(AK, BK_, F)                                                                           \
+    hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F>), grid, dim3(256), 0, stream, a)
+    const bool f = c_f32 != 0;
+    if (a_kcontig && b_kcontig) { if (f) G16_LAUNCH(true, true, true); else G16_LAUNCH(true, true, false); }
+    else if (a_kcontig && !b_kcontig) { if (f) G16_LAUNCH(true, false, true); else G16_LAUNCH(true, false, false); }
+    else if (!a_kcontig && b_kcontig) { if (f) G16_LAUNCH(false, true, true); else G16_LAUNCH(false, true, false); }
+    else { if (f) G16_LAUNCH(false, false, true); else G16_LAUNCH(false, false, false); }
+#undef G16_LAUNCH
+    if (a.planes) {
+        const int64_t work = (int64_t)nbatch * M * (N / 4);
+        const int g = ix_grid_1d(work, 256);
+        if (f) hipLaunchKernelGGL(gemm16_reduce_kernel<true>, dim3(g), dim3(256), 0, stream, a, nbatch);
+        else hipLaunchKernelGGL(gemm16_reduce_kernel<false>, dim3(g), dim3(256), 0, stream, a, nbatch);
+    }
+    ix_prof_end(stream);
+    IX_CHECK_LAUNCH("ix_gemm_b16");
+    return IX_OK;
+}
+
+// ---- dtype conversion passes (HBM-bound: 6 bytes per element) -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_b16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, int64_t n8, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        reinterpret_cast<u32x4*>(y)[i] = u32x4{g16_pack2(a.x, a.y), g16_pack2(a.z, a.w), g16_pack2(b.x, b.y), g16_pack2(b.z, b.w)};
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += 256) y[i] = (unsigned short)(g16_pack2(x[i], 0.f) & 0xffffu);
+}
+__global__ __launch_bounds__(256) void cast_b16_f32_kernel(const unsigned short* __restrict__ x, float* __restrict__ y, int64_t n8, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const u32x4 v = reinterpret_cast<const u32x4*>(x)[i];
+        reinterpret_cast<f32x4*>(y)[2 * i] = f32x4{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                  __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+        reinterpret_cast<f32x4*>(y)[2 * i + 1] = f32x4{__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                                      __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = n8 * 8 + threadIdx.x; i < n; i += 256) y[i] = g16_bf(x[i]);
+}
+
+extern "C" int ix_cast_f32_b16(const float* x, void* y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && y && ix_al16(x) && ix_al16(y), "ix_cast_f32_b16: null or unaligned pointer");
+    hipLaunchKernelGGL(cast_f32_b16_kernel, dim3(ix_grid_1d(n / 8 + 1, 256)), dim3(256), 0, stream, x, (unsigned short*)y, n / 8, n);
+    IX_CHECK_LAUNCH("ix_cast_f32_b16");
+    return IX_OK;
+}
+extern "C" int ix_cast_b16_f32(const void* x, float* y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return IX_OK;
+    IX_CHECK_ARG(x && y && ix_al16(x) && ix_al16(y), "ix_cast_b16_f32: null or unaligned pointer");
+    hipLaunchKernelGGL(cast_b16_f32_kernel, dim3(ix_grid_1d(n / 8 + 1, 256)), dim3(256), 0, stream, (const unsigned short*)x, y, n / 8, n);
+    IX_CHECK_LAUNCH("ix_cast_b16_f32");
+    return IX_OK;
+}

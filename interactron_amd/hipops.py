@@ -66,15 +66,41 @@ class _NullCtx:
         pass
 
 
+_b16_seen = [False]   # a bf16 activation exists in this process (the 16-bit mode, b16.py); until then no call looks at dtypes
+
+
+def _any_b16(args):
+    for a in args:
+        if torch.is_tensor(a) and a.dtype == torch.bfloat16:
+            return True
+    return False
+
+
 class Function(_TorchFunction):
     """torch.autograd.Function plus ``call``: inside backward passes that are not themselves recorded (grad mode off:
     the final second-order / first-order backward) the nested nodes skip the autograd bookkeeping and run their
-    forward directly -- same kernels, roughly half the host time per node."""
+    forward directly -- same kernels, roughly half the host time per node.
+
+    ``b16``: what the op does with bf16 tensors of the 16-bit activation mode (b16.py) -- "native": its forward takes them;
+    "adapt" (default): it is computed by its fp32 kernels between two conversion passes.  ``b16_out``: which fp32 results of an
+    adapted call come back as bf16 (True: all; False: none -- reductions to scalars, parameter gradients; or one flag per output)."""
+    b16 = "adapt"
+    b16_out = True
+
+    @classmethod
+    def apply(cls, *args):
+        if _b16_seen[0] and cls.b16 != "native" and _any_b16(args):
+            from . import b16
+            return b16.adapt(cls, args, lambda up: super(Function, cls).apply(*up))
+        return super().apply(*args)
 
     @classmethod
     def call(cls, *args):
         if torch.is_grad_enabled():
             return cls.apply(*args)
+        if _b16_seen[0] and cls.b16 != "native" and _any_b16(args):
+            from . import b16
+            return b16.adapt(cls, args, lambda up: cls.forward(_NullCtx(), *up))
         return cls.forward(_NullCtx(), *args)
 
 
@@ -103,7 +129,8 @@ def _req(t, name="tensor"):
 # A strided matrix view into a flat tensor: elem(r, c) = base[offset + bo*so + bi*si + (c*ld + r if trans else r*ld + c)]
 View = namedtuple("View", "offset ld trans so si")
 # One batched contraction C = alpha * A(MxK) B(KxN): views for A, B and for C inside a fresh tensor `out_shape`
-GemmSpec = namedtuple("GemmSpec", "M N K bo bi A B C out_shape alpha")
+# (odt: dtype of C in the 16-bit mode -- None = bf16 when an operand is bf16; torch.float32: heads, parameter gradients)
+GemmSpec = namedtuple("GemmSpec", "M N K bo bi A B C out_shape alpha odt", defaults=(None,))
 
 
 def attn_pitch(S):
@@ -451,10 +478,14 @@ def _param_key(t):
 class Gemm(Function):
     """out = alpha * A B (+ bias) for strided views A of `a` and B of `b`; see GemmSpec."""
 
+    b16 = "native"
+
     @staticmethod
     def forward(ctx, a, b, bias, sp):
         ctx.a_key, ctx.b_key = _param_key(a), _param_key(b)
         ctx.bias_key = _param_key(bias) if bias is not None else None
+        if a.dtype == torch.bfloat16 or b.dtype == torch.bfloat16:
+            return Gemm._forward_b16(ctx, a, b, bias, sp)
         a, b = _req(a, "gemm A"), _req(b, "gemm B")
         ctx.sp = sp
         ctx.has_bias = bias is not None
@@ -467,6 +498,27 @@ class Gemm(Function):
         return _run_gemm(a, b, bias, sp)
 
     @staticmethod
+    def _forward_b16(ctx, a, b, bias, sp):
+        """the 16-bit mode: bf16 operands (an fp32 weight is read through its cached bf16 copy), C in sp.odt; the gradients come back
+        in each operand's OWN dtype -- bf16 for activations, fp32 for parameters"""
+        from . import b16
+        wa, wb = getattr(a, "_ix_weight", False), getattr(b, "_ix_weight", False)
+        a, b = b16._reqd(a, "gemm A"), b16._reqd(b, "gemm B")
+        if wa:
+            mark_weight(a)
+        if wb:
+            mark_weight(b)
+        ctx.sp = sp
+        ctx.has_bias = bias is not None
+        ctx.bias_groups = bias.shape[0] if (bias is not None and bias.dim() == 2) else 0
+        if bias is not None:
+            bias = _req(bias, "gemm bias")
+            assert bias.numel() == (sp.bo if ctx.bias_groups else 1) * sp.N, (tuple(bias.shape), sp.bo, sp.N)
+        ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
+        ctx.save_for_backward(a, b)
+        return b16.run_gemm(a, b, bias, sp)
+
+    @staticmethod
     def backward(ctx, dc):
         a, b = ctx.saved_tensors
         sp = ctx.sp
@@ -477,7 +529,8 @@ class Gemm(Function):
         need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not _is_unwanted(ctx.bias_key, skip)
         # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
         # A-producer waves of that launch sum the dC tiles they stream anyway) whenever dC is its plain m-contiguous A operand
-        fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
+        fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0 and dc.dtype == torch.float32
+                and a.dtype == torch.float32
                 and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
                 and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
         # (recorded backward: dC feeds up to three nodes -- one alias each, so that ITS gradient is one sum, Fanout)
@@ -498,25 +551,28 @@ def _gemm_backward(sp, a, b, a_shape, b_shape, dc, need_a, need_b, dcs=None):
     """Gradients of C = alpha A B w.r.t. the storage of A and of B (each again one strided contraction).  `dcs`: aliases of dC
     to consume, one per node (hipops.fanout), or None."""
     da = db = None
+    # (16-bit mode: a gradient has its operand's own dtype -- bf16 activations, fp32 parameters; None outside the mode)
+    mixed = dc.dtype == torch.bfloat16 or a.dtype == torch.bfloat16 or b.dtype == torch.bfloat16
+    oa, ob = (a.dtype, b.dtype) if mixed else (None, None)
     if need_a:
         dc = dcs.pop() if dcs else dc
         if not sp.A.trans:   # dA (MxK) = alpha * dC (MxN) * B^T (NxK)
             s = GemmSpec(sp.M, sp.K, sp.N, sp.bo, sp.bi, sp.C, _flip(sp.B),
-                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
+                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha, oa)
             da = Gemm.call(dc, b, None, s)
         else:                # storage holds A^T (KxM): dA^T = alpha * B (KxN) * dC^T (NxM)
             s = GemmSpec(sp.K, sp.M, sp.N, sp.bo, sp.bi, sp.B, _flip(sp.C),
-                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha)
+                         View(sp.A.offset, sp.A.ld, False, sp.A.so, sp.A.si), a_shape, sp.alpha, oa)
             da = Gemm.call(b, dc, None, s)
     if need_b:
         dc = dcs.pop() if dcs else dc
         if not sp.B.trans:   # dB (KxN) = alpha * A^T (KxM) * dC (MxN)
             s = GemmSpec(sp.K, sp.N, sp.M, sp.bo, sp.bi, _flip(sp.A), sp.C,
-                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha)
+                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha, ob)
             db = Gemm.call(a, dc, None, s)
         else:                # storage holds B^T (NxK): dB^T = alpha * dC^T (NxM) * A (MxK)
             s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
-                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha)
+                         View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), b_shape, sp.alpha, ob)
             db = Gemm.call(dc, a, None, s)
     return da, db
 
@@ -870,31 +926,64 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None, dot=Non
 
 def contraction_form():
     """1 = fp16x3 form of the 12-wave contraction kernel, 0 = bf16x6 (ix_gemm_set_x3 / IX_GEMM_KERNEL); + 2 in the
-    single-pass 16-bit mode (a captured graph must not replay another form: episode._graph_stamp)"""
+    single-pass 16-bit mode, + 4 in the 16-bit activation mode (a captured graph must not replay another form: episode._graph_stamp)"""
     lib = _L()
     cur = lib.ix_gemm_set_x3(1)
     lib.ix_gemm_set_x3(cur)
-    return cur + (2 if COMPUTE_DTYPE != "f32" else 0)
+    return cur + {"f32": 0, "single_pass": 2, "bf16": 4}[COMPUTE_DTYPE]
 
 
-# MODEL.COMPUTE_DTYPE (BASELINE.json configs[1]: "multi_frame_baseline ... bf16").  "f32" (default): every contraction is
-# fp32-grade (three fp16 / six bf16 matrix instructions per product) -- the parity path and every headline number.
-# "bf16" / "fp16": the 16-bit SINGLE-PASS mode -- contractions round each operand once to 16 bits (an fp16 value of
-# x * 2^-E with one exponent per 32 x 32 sub-block: 11 significant bits, i.e. bf16's accuracy or better, and fp32's
-# range) and issue ONE matrix instruction per k-slice with fp32 accumulation; activations stay fp32 in HBM, LayerNorm /
-# softmax statistics and the attention core stay fp32-grade.  Process-global (like the kernel-form switches).
+# MODEL.COMPUTE_DTYPE -- a property of a MODEL (episode._EpisodeModel.compute_dtype), put in force for the duration of each of its
+# entry points by `compute_mode` (round 5 set it process-wide at build time: a second model built without the key silently
+# switched the first one).
+#   "f32" (default): every contraction is fp32-grade (three fp16 / six bf16 matrix instructions per product) -- the parity path
+#       and every headline number.
+#   "bf16": the 16-bit ACTIVATION mode (BASELINE.json configs[1] "multi_frame_baseline ... bf16"; b16.py): activations live in HBM
+#       as bf16, contractions run on csrc/gemm16.hip (operands by LDS-DMA, one bf16 matrix instruction per k-slice, fp32
+#       accumulation), parameters / statistics / accumulations stay fp32.  Checked at SURVEY 8d's bf16 tolerances.
+#   "single_pass" (round 4's "bf16", also "fp16"): fp32 STORAGE, contractions round each operand once to 16 bits (an fp16 value
+#       of x * 2^-E with one exponent per 32 x 32 sub-block) and issue ONE matrix instruction per k-slice.
 COMPUTE_DTYPE = "f32"
+_DTYPE_NAMES = {"float32": "f32", "fp32": "f32", "f32": "f32", "bf16": "bf16", "bfloat16": "bf16", "fp16": "single_pass",
+                "half": "single_pass", "f16": "single_pass", "single_pass": "single_pass"}
+
+
+def normalize_compute_dtype(name):
+    out = _DTYPE_NAMES.get(str(name).lower())
+    if out is None:
+        raise ValueError("MODEL.COMPUTE_DTYPE must be f32, bf16 (16-bit activations) or single_pass / fp16 (fp32 storage, 16-bit single-pass contractions)")
+    return out
 
 
 def set_compute_dtype(name):
+    """-> the previous mode.  Prefer `compute_mode` (scoped); models apply their own mode at every entry point."""
     global COMPUTE_DTYPE
-    name = {"float32": "f32", "fp32": "f32", "f32": "f32", "bf16": "bf16", "bfloat16": "bf16", "fp16": "bf16", "half": "bf16",
-            "f16": "bf16"}.get(str(name).lower())
-    if name is None:
-        raise ValueError("MODEL.COMPUTE_DTYPE must be f32, bf16 or fp16")
-    _chk(0 if _L().ix_gemm_set_single_pass(1 if name == "bf16" else 0) in (0, 1) else 1, "ix_gemm_set_single_pass")
+    name = normalize_compute_dtype(name)
+    _chk(0 if _L().ix_gemm_set_single_pass(1 if name == "single_pass" else 0) in (0, 1) else 1, "ix_gemm_set_single_pass")
     old, COMPUTE_DTYPE = COMPUTE_DTYPE, name
     return old
+
+
+class compute_mode:
+    """with compute_mode("bf16"): ...   -- the arithmetic mode of the launches issued inside (re-entrant, restores on exit)"""
+
+    def __init__(self, name):
+        self.name = normalize_compute_dtype(name)
+
+    def __enter__(self):
+        self.prev = COMPUTE_DTYPE
+        if self.prev != self.name:
+            set_compute_dtype(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if COMPUTE_DTYPE != self.prev:
+            set_compute_dtype(self.prev)
+        return False
+
+
+def b16_active():
+    return COMPUTE_DTYPE == "bf16"
 
 
 def attn_split_multi(ops, n, H, hd, tr_form=None):

@@ -175,12 +175,13 @@ def test_stress_config_training_step_with_fp8_attention_against_the_oracle():
     import __graft_entry__ as entry
     from interactron_amd import hipops
     extra = dict(NUM_QUERIES=200, BLOCK_SIZE=5 * (16 * 16 + 200) + 5)
-    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=5e-3)
+    # (200 near-identical queries on RNG-free weights: the Hungarian optimum is full of ties -- both runs take the oracle's assignments)
+    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=5e-3, pin_matching="ties")
     assert hipops.ATTENTION_DTYPE == "fp32"
     hipops.ATTENTION_DTYPE = "fp8"
     try:
         got = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=FP8_TRAIN_NORM, loss_tol=FP8_TRAIN_LOSS,
-                                cos_min=FP8_TRAIN_COS)
+                                cos_min=FP8_TRAIN_COS, pin_matching="always")
     finally:
         hipops.ATTENTION_DTYPE = "fp32"
     assert got["checked"] >= 300

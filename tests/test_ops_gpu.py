@@ -1561,8 +1561,8 @@ def test_flash_fp8_forward_with_the_derivative_passes_of_either_family(ops, hd):
     (``flash_form``) -- recompute the probabilities from the fp16 planes with normalisers of THEIR scores (an lse-only pass of the
     32 x 32 forward kernel; the same fp16x3 products in another accumulation order than flash16's, so consistent to fp32
     rounding, not bit for bit).  What the fp8 forward leaves in the gradients is its output through delta = dO . O.  Against
-    float64 autograd: everything finite, forward within the fp8 forward's 7 % relative L2, gradients within 15 %, second-order
-    cotangents within 20 % (measured values are printed)."""
+    float64 autograd: everything finite, forward within the fp8 forward's 7 % relative L2, gradients within 3 %, second-order
+    cotangents within 2 % (measured r6a: forward 5.5 %, gradients <= 1.1 %, second order <= 0.6 %; printed)."""
     n, H, L, S = 1, 4, 300, 517
     E = H * hd
     q, k, v = rnd(n, L, E, seed=21), rnd(n, S, E, seed=22), rnd(n, S, E, seed=23)
@@ -1586,8 +1586,8 @@ def test_flash_fp8_forward_with_the_derivative_passes_of_either_family(ops, hd):
         ops.ATTENTION_DTYPE = old
     orf, g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, None, None))
     rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
-    errs = [("forward", rel(oh, orf), 0.07)] + [("grad " + nm, rel(a, b), 0.15) for nm, a, b in zip("qkv", g1h, g1r)] + \
-        [("second-order " + nm, rel(a, b), 0.20) for nm, a, b in zip(["q", "k", "v", "dO"], g2h, g2r)]
+    errs = [("forward", rel(oh, orf), 0.07)] + [("grad " + nm, rel(a, b), 0.03) for nm, a, b in zip("qkv", g1h, g1r)] + \
+        [("second-order " + nm, rel(a, b), 0.02) for nm, a, b in zip(["q", "k", "v", "dO"], g2h, g2r)]
     print("fp8 forward + fp16 derivative passes, head dim %d: " % hd + ", ".join("%s %.3f" % (nm, e) for nm, e, _ in errs))
     for t in [oh] + list(g1h) + list(g2h):
         assert bool(torch.isfinite(t).all())

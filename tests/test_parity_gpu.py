@@ -417,8 +417,15 @@ F64_KINK_TENSORS = 2
 # 5e-3.  The tensors below need more than that in at least one contraction form (measured with IX_TEST_RECORD_ALL=1, the
 # worst ratio over the three forms rounded up; BASELINE.md section 4 lists them with the measurements): elements of the
 # clipped inner step and ReLUs upstream of them sit on kinks and flip under any other float32 summation order.
-SECOND_ORDER_REL = {
+SECOND_ORDER_REL = {   # measured r6a (gpurun_out/r6a_survey.txt): worst ratio to the 1e-3 bound over the three forms, rounded up
+    "g13/detector.backbone.0.body.layer3.3.conv1.weight": 2.5e-3,    # norm 1.83 x
+    "g13/detector.backbone.0.body.layer3.5.conv2.weight": 1.5e-3,    # norm 1.04 x
+    "g13/detector.backbone.0.body.layer2.1.conv3.weight": 2.5e-3,    # 10-12 of 256 strided samples beyond 20 x 1e-3 x RMS (5 allowed), worst 1.7 x
+    "rand/detector.backbone.0.body.layer2.0.conv1.weight": 1.5e-3,   # strided sample L2 1.26 x
 }
+# ... and the whole-tensor direction (G13b): 0.9999 everywhere but on the first trainable convolution, the tensor furthest upstream
+# of every kink (measured 0.99990 in the bf16x6 form, 0.99991 / 0.99992 in the others)
+FULL_COS_MIN = {"detector.backbone.0.body.layer2.0.conv1.weight": 0.9998}
 
 
 def second_order_rel(what):
@@ -443,7 +450,7 @@ def check_full_gradients(F, model, cos_min=0.9999, norm_rel=2e-3):
             ref = _decompress(rec).double()
             cos = float((g.double() * ref).sum() / (g.double().norm() * ref.norm()))
             worst = min(worst, (cos, grp + "." + k))
-            assert cos >= cos_min, (grp, k, "direction over the whole tensor", cos)
+            assert cos >= FULL_COS_MIN.get(grp + "." + k, cos_min), (grp, k, "direction over the whole tensor", cos)
             n = float(g.double().norm())
             assert abs(n - rec["norm"]) <= max(norm_rel, 2 * second_order_rel("g13/%s.%s" % (grp, k))) * rec["norm"] + 1e-9, (grp, k, n, rec["norm"])
     print("G13b: %d whole gradient tensors, smallest cosine %.7f on %s" % (len(F["detector"]) + len(F["fusion"]), worst[0], worst[1]))
@@ -912,9 +919,9 @@ def test_inner_steps_2_against_the_oracle():
     """MODEL.INNER_STEPS = 2 (BASELINE.json's multi-step adapt loop): two learned-loss SGD steps with the
     second-order graph through both (reference step: models/interactron.py:94-102, utils/meta_utils.py:135-142), one episode
     at 128 x 128.  The episode-batched schedule against the CPU oracle: every loss (2e-3) and every gradient tensor of both
-    networks -- None-pattern, direction (cosine >= 0.999), norm within 5e-3 + 3 x the float32 oracle's own distance from its
+    networks -- None-pattern, direction (cosine >= 0.999), norm within 1e-3 + 3 x the float32 oracle's own distance from its
     float64 run on that tensor (two clipped steps double the elements that sit on kinks: the float32 oracle itself is up to
-    7.5e-3 off its float64 run at two steps, 2e-3 at one).  The reference's sequential schedule (EPISODE_CHUNK 0) against the
+    7.5e-3 off its float64 run at two steps, 2e-3 at one; one tensor needs 2e-3: __graft_entry__.SMOKE_REL).  The reference's sequential schedule (EPISODE_CHUNK 0) against the
     batched one.  And the second step must matter: the supervisor losses differ from the single-step run's."""
     import __graft_entry__ as entry
     two = entry.smoke_check(128, inner_steps=2, episodes=1, chunk=16, f64_slack=True)
