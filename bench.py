@@ -403,10 +403,33 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
         lib.ix_prof_contraction_bytes(cby)
         fms, ffl, fmf, fn = (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_double * 7)(), (ctypes.c_int64 * 7)()
         lib.ix_prof_flash(fms, ffl, fmf, fn)
+        bms, bfl, bby, bn = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.ix_prof_b16(ctypes.byref(bms), ctypes.byref(bfl), ctypes.byref(bby), ctypes.byref(bn))
         ms, pairs = ctypes.c_double(), ctypes.c_int64()
         lib.ix_gemm_prof_read(ctypes.byref(ms), ctypes.byref(pairs))
         lib.ix_gemm_prof_enable(0)
         res["roofline"] = build_roofline(list(cms), list(cfl), list(cmf), list(cn), list(fms), list(ffl), list(fmf), list(fn), size)
+        if bn.value:
+            # the 16-bit activation mode: the bf16 GEMM (csrc/gemm16.hip) is the dominant kernel -- ONE matrix instruction per multiply-add,
+            # so executed = algorithmic FLOPs; priced against the same dense 16-bit MFMA peak
+            r = res["roofline"]
+            b16 = {"kernel": "gemm16_kernel (bf16 operands by LDS-DMA, v_mfma_f32_16x16x32_bf16, fp32 accumulation)", "bound": "mfma",
+                   "achieved": bfl.value / (bms.value * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": bfl.value / (bms.value * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "launches_per_step": int(bn.value),
+                   "kernel_ms_per_step": bms.value, "gflop_per_step": bfl.value / 1e9, "avg_launch_us": bms.value * 1e3 / bn.value,
+                   "algorithmic_bytes_per_launch": bby.value / bn.value, "algorithmic_GBps": bby.value / (bms.value * 1e-3) / 1e9,
+                   "traffic": None}
+            r["bf16_gemm"] = b16
+            if bms.value > r["kernel_ms_per_step"]:   # it IS the dominant kernel of this run: the top-level fields describe it
+                r["fp32_on_16bit_kernels"] = {k: r[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "gflop_per_step",
+                                                                "kernel_ms_per_step", "algorithmic_tflops", "avg_launch_us")}
+                for k in ("kernel", "achieved", "frac", "launches_per_step", "gflop_per_step", "kernel_ms_per_step", "avg_launch_us", "traffic"):
+                    r[k] = b16[k]
+                r["algorithmic_tflops"] = b16["achieved"]
+                r["executed_gflop_per_step"] = b16["gflop_per_step"]
+                r["note"] = ("achieved = 2MNK FLOP/s of the bf16 GEMM over its launches (one matrix instruction per multiply-add: executed = "
+                             "algorithmic) against the dense 16-bit MFMA peak; the fp32-on-16-bit kernels that still run (adapted ops, "
+                             "convolution gathers) are listed under fp32_on_16bit_kernels")
         en = cn[1] + cn[2]
         res["roofline"]["algorithmic_bytes_per_launch"] = (cby[1] + cby[2]) / max(1, en)
         t = res["roofline"]["traffic"]
@@ -563,10 +586,11 @@ def main():
                          "batch on 8 GPUs; replayed from HIP graphs); 0 = skip it")
     ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
                     help="MODEL.STEP_GRAPH: replay the chunk's launch sequence from captured HIP graphs (auto: whenever the capture fits in free device memory)")
-    ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16"],
-                    help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the single-pass "
-                         "16-bit mode (BASELINE.json configs[1]: --config multi_frame_baseline --compute-dtype bf16) -- its own line, "
-                         "`dtype` says so, never the headline")
+    ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16", "single_pass"],
+                    help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the 16-bit ACTIVATION "
+                         "mode (activations stored as bf16, bf16 GEMM with LDS-DMA operands; BASELINE.json configs[1]: --config "
+                         "multi_frame_baseline --compute-dtype bf16); single_pass = fp32 storage, single-pass 16-bit contractions (round 4) "
+                         "-- their own lines, `dtype` says so, never the headline")
     ap.add_argument("--inner-steps", type=int, default=1,
                     help="MODEL.INNER_STEPS: learned-loss SGD steps per episode (reference: 1; BASELINE.json's '5-step adapt loop' = 5, "
                          "a stress setting -- the default run reports it as the `inner5` sub-line)")
@@ -664,8 +688,9 @@ def main():
             "metric": "frames/sec (5-frame episodes of 3x%dx%d frames)" % (args.size, args.size), "value": head["frames_per_s"], "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32" if args.compute_dtype == "f32" else "bf16-class (single-pass 16-bit contractions: fp16 x 2^E per 32x32 block, "
-                                                                "fp32 accumulation; fp32 storage, fp32-grade attention / norms)",
+            "dtype": {"f32": "f32", "bf16": "bf16 (activations stored as bf16, bf16 matrix instructions, fp32 accumulation / statistics / parameters)",
+                      "single_pass": "bf16-class (single-pass 16-bit contractions: fp16 x 2^E per 32x32 block, fp32 accumulation; fp32 storage, "
+                                     "fp32-grade attention / norms)"}[args.compute_dtype],
             "data": "synthetic",
             "config": {"workload": ("%s training step (%s.forward + all-reduce + clip + Adam), "
                                     "%d episodes/GPU x 5 frames x 3x%dx%d, Q=%d, fusion T=%d, procedural weights, train mode "

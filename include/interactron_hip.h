@@ -455,6 +455,26 @@ int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M,
 int ix_gemm_b16_supported(const void* A, const void* B, const void* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
                           int64_t ldb, int64_t ldc, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi);
 int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out_host);
+/*   ix_map_b16    : out[k] = f_op(a[k], b[k], c[k]) on bf16 tensors (csrc/ew16.hip), the arithmetic of the fp32 kernels of the same name,
+ *                   rounded once: op 0 a + b | 1 p0 a + p1 b | 2 p0 a | 3 relu(a) | 4 a [b > 0] p0 | 5 (a + b) [c > 0] | 6 gelu(a) |
+ *                   7 a gelu'(b) | 8 dropout(a; p0, seed) | 9 dropout(relu(a)) | 10 a + dropout(b) (the dropout hash of ix_dropout_f32:
+ *                   a pure function of (seed ^ salt, element index)); unused operands null
+ *   ix_sum_n_b16  : ((a0 + a1) + ...) over 2..8 bf16 tensors, left to right in fp32, one rounding
+ *   ix_channel_b16: [rows, C] bf16 with per-channel fp32 vectors: op 0 [relu](x scale[c] + shift[c] (+ y)) | 1 x [y > 0] scale[c] |
+ *                   2 x scale[c] | 3 x + scale[g][c] (a row vector per slab of rows / groups rows); C % 8 == 0
+ *   ix_layernorm_*_b16 : nn.LayerNorm forward / first derivative on bf16 rows (D % 4 == 0, D <= 1024), fp32 statistics, gamma / beta and
+ *                   parameter gradients; the backward's workspace (ix_workspace_bytes_layernorm_bwd_b16, ticket layout) holds the
+ *                   per-workgroup partial parameter gradients, added in order */
+int ix_map_b16(int op, const void* a, const void* b, const void* c, void* out, int64_t n, float p0, float p1, uint64_t seed,
+               ix_stream_t stream);
+int ix_sum_n_b16(const void* const* srcs_host_array, int n, void* out, int64_t count, ix_stream_t stream);
+int ix_channel_b16(int op, const void* x, const void* y, const float* scale, const float* shift, void* out, int64_t rows, int C, int relu,
+                   int groups, ix_stream_t stream);
+int ix_layernorm_fwd_b16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows, int D,
+                         float eps, ix_stream_t stream);
+int ix_workspace_bytes_layernorm_bwd_b16(int64_t rows, int D, size_t* out_host);
+int ix_layernorm_bwd_b16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                         float* dbeta, int64_t rows, int D, void* workspace, size_t workspace_bytes, ix_stream_t stream);
 int ix_cast_f32_b16(const float* x, void* y, int64_t n, ix_stream_t stream);
 int ix_cast_b16_f32(const void* x, float* y, int64_t n, ix_stream_t stream);
 int ix_prof_b16(double* ms, double* flops, double* bytes, int64_t* launches);

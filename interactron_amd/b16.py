@@ -95,8 +95,15 @@ def to_f32(x):
 def adapt(cls, args, run):
     """An op without 16-bit kernels on bf16 inputs: fp32 kernels between conversion passes (see the module docstring).
     `run(args)` applies the op (recorded or not, the caller decides)."""
-    up = tuple(ToF32.call(a) if is_b16(a) else a for a in args)
-    out = run(up)
+    done = {}   # (one conversion per distinct tensor: the packed [k | q | v] buffer is passed three times)
+    up = []
+    for a in args:
+        if is_b16(a):
+            if id(a) not in done:
+                done[id(a)] = ToF32.call(a)
+            a = done[id(a)]
+        up.append(a)
+    out = run(tuple(up))
     keep = cls.b16_out
     if keep is False:
         return out
@@ -161,8 +168,10 @@ def run_gemm(a, b, bias, sp, fill=True, scale=None, shift=None, residual=None, a
         ok = False
     if not ok:
         _stats["fallback_gemms"] += 1
-        assert scale is None and residual is None and act == 0
         o = ops._run_gemm(cast_f32(a), cast_f32(b), bias, sp._replace(odt=None), fill)
+        if scale is not None or residual is not None or act:
+            assert scale is not None and act in (0, 1), "only the frozen-BN affine (+ residual) (+ ReLU) has an fp32 twin here"
+            o = ops._channel_affine(o, scale, shift, cast_f32(residual) if residual is not None else None, act == 1)
         return o if out_f32 else cast_b16(o)
     a16, b16_ = _as_b16(a), _as_b16(b)
     out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=a.device, dtype=torch.float32 if out_f32 else B16)

@@ -100,7 +100,11 @@ class ResNet50Body(nn.Module):
             x = ops.linear(cols, w).reshape(n, g.OH, g.OW, 64)
             x = self.bn1(x, relu=True)
             x = ops.maxpool_nhwc(x, 3, 2, 1)
-            return self.layer1(x)
+            x = self.layer1(x)
+            if ops.b16_active():   # MODEL.COMPUTE_DTYPE bf16: from here on activations live in HBM as bf16 (b16.py)
+                from . import b16
+                x = b16.cast_b16(x)
+            return x
 
     def forward(self, frames_nchw, stem=None):
         x = stem if stem is not None else self.frozen_stem(frames_nchw)
@@ -262,7 +266,7 @@ class Transformer(nn.Module):
         n, hw, E = src.shape
         Q = query_embed.shape[-2]
         memory, m_dec = ops.fanout(self.encoder(src, mask, pos), 2)   # (the caller's copy and the decoder's)
-        tgt = torch.zeros(n, Q, E, device=src.device, dtype=torch.float32)
+        tgt = torch.zeros(n, Q, E, device=src.device, dtype=src.dtype)
         qe = query_embed.reshape(Q * E) if query_embed.dim() == 2 else query_embed.reshape(-1, Q * E)
         hs = self.decoder(tgt, m_dec, mask, pos, qe)
         return hs, memory
@@ -279,7 +283,8 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
+            # (16-bit mode: a head's last layer hands fp32 to the criterion / the decoders' consumers)
+            x = layer(x) if i < self.num_layers - 1 else layer(x, out_dtype=torch.float32)
             if i < self.num_layers - 1:
                 x = ops.Relu.apply(x)
         return x
@@ -310,7 +315,7 @@ class DETR(nn.Module):
         hs, memory = self.transformer(src, mask.reshape(n, h * w), self.query_embed.weight, pos)
         h_cls, h_box, hs = ops.fanout(hs, 3)
         return {
-            "pred_logits": self.class_embed(h_cls),
+            "pred_logits": self.class_embed(h_cls, out_dtype=torch.float32),
             "pred_boxes": ops.Sigmoid.apply(self.bbox_embed(h_box)),
             "image_features": feat.permute(0, 3, 1, 2),
             "embedded_memory_features": memory.reshape(n, h, w, -1).permute(0, 3, 1, 2),

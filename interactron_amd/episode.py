@@ -105,7 +105,31 @@ def _mean_losses(per_task, tag):
     return {k.replace("loss", tag): torch.mean(torch.stack([x[k] for x in per_task])) for k in per_task[0]}
 
 
+def _in_compute_mode(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def run(self, *args, **kwargs):
+        with ops.compute_mode(self.compute_dtype):
+            return fn(self, *args, **kwargs)
+    run._ix_mode_wrapped = True
+    return run
+
+
 class _EpisodeModel(nn.Module):
+    """``compute_dtype`` (MODEL.COMPUTE_DTYPE, set by config.build_model): the arithmetic mode of THIS model -- "f32" (fp32-grade, the
+    parity path), "bf16" (16-bit activations, b16.py) or "single_pass".  Every entry point of a subclass runs inside
+    ``hipops.compute_mode(self.compute_dtype)``: two live models with different modes do not disturb each other."""
+    compute_dtype = "f32"
+    _ENTRY_POINTS = ("forward", "predict", "get_next_action", "_policy_logits", "dp_idle_step")
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        for name in _EpisodeModel._ENTRY_POINTS:
+            fn = cls.__dict__.get(name)
+            if fn is not None and not getattr(fn, "_ix_mode_wrapped", False):
+                setattr(cls, name, _in_compute_mode(fn))
+
     def __init__(self):
         super().__init__()
         self.logger = None

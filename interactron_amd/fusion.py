@@ -102,9 +102,18 @@ class GPT(nn.Module):
         return self.head(self.ln_f(x))
 
 
+def _like(t, ref):
+    """t in ref's storage dtype (16-bit mode: the detector's fp32 head outputs and the fp32 token parameters join bf16 sequences)"""
+    if t.dtype == ref.dtype:
+        return t
+    from . import b16
+    return b16.to_b16(t) if ref.dtype == torch.bfloat16 else b16.to_f32(t)
+
+
 def _token_inputs(mod, x):
     img = mod.img_feature_embedding(x["embedded_memory_features"].permute(0, 1, 3, 4, 2))
-    preds = torch.cat((x["box_features"], x["pred_logits"], x["pred_boxes"]), dim=-1)
+    bf = x["box_features"]
+    preds = torch.cat((bf, _like(x["pred_logits"], bf), _like(x["pred_boxes"], bf)), dim=-1)
     return img, mod.prediction_embedding(preds)
 
 
@@ -112,7 +121,7 @@ def _decode(mod, y_preds, y_actions):
     y_seq, y_box, y_logit, y_loss = ops.fanout(y_preds, 4)
     return {"seq": y_seq.squeeze(),
             "pred_boxes": ops.Sigmoid.apply(mod.box_decoder(y_box)).squeeze(),
-            "pred_logits": mod.logit_decoder(y_logit).squeeze(),
+            "pred_logits": mod.logit_decoder(y_logit, out_dtype=torch.float32).squeeze(),
             "loss": mod.loss_decoder(y_loss),
             "actions": mod.action_decoder(y_actions).squeeze()}
 
@@ -136,7 +145,7 @@ class Transformer(nn.Module):
         img, pred = _token_inputs(self, x)
         b, s, p, n = pred.shape
         n_preds = s * p
-        seq = torch.cat((img.reshape(b, -1, n), pred.reshape(b, -1, n), self.action_tokens.repeat(b, 1, 1)), dim=1)
+        seq = torch.cat((img.reshape(b, -1, n), pred.reshape(b, -1, n), _like(self.action_tokens, pred).repeat(b, 1, 1)), dim=1)
         y = self.model(seq)
         y_preds = y[:, -(n_preds + 5):-5].reshape(b, s, p, -1)
         return _decode(self, y_preds, y[:, -5:-1].reshape(b, 4, -1))
@@ -193,12 +202,12 @@ class DecoderTransformer(nn.Module):
         mem_len, L = 5 * self.img_len, self.img_len
         parts = [img.reshape(b, -1, n)]
         if s * L < mem_len:
-            parts.append(torch.zeros(b, mem_len - s * L, n, device=dev))
+            parts.append(torch.zeros(b, mem_len - s * L, n, device=dev, dtype=img.dtype))
         memory = torch.cat(parts, dim=1)
         parts = [pred.reshape(b, -1, n)]
         if s * p < 250:
-            parts.append(torch.zeros(b, 250 - s * p, n, device=dev))
-        parts.append(self.action_tokens.repeat(b, 1, 1))
+            parts.append(torch.zeros(b, 250 - s * p, n, device=dev, dtype=pred.dtype))
+        parts.append(_like(self.action_tokens, pred).repeat(b, 1, 1))
         tgt = torch.cat(parts, dim=1)
         y = self.transformer(tgt, memory, None, self.pos_embed, self.query_embed.reshape(255 * n))
         y_preds = y[:, :-5].reshape(b, s, p, -1)

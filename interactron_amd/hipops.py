@@ -618,25 +618,28 @@ class GemmRowsum(Function):
         return da, db, None, None
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, out_dtype=None):
     """y[..., o] = sum_i x[..., i] * weight[o, i] + bias[o]   (nn.Linear semantics).
 
     Episode-batched form: weight [E, N, K] (+ bias [E, N]) holds one set of MAML fast weights per episode and the
-    leading dim of x is E * (rows per episode); episode e's rows meet episode e's weights in ONE batched launch."""
+    leading dim of x is E * (rows per episode); episode e's rows meet episode e's weights in ONE batched launch.
+    out_dtype (16-bit mode only): torch.float32 for a result that leaves the 16-bit part of the graph (heads)."""
     mark_weight(weight)
+    if x.dtype != torch.bfloat16:
+        out_dtype = None
     if weight.dim() == 3:
         E, N, K = weight.shape
         assert x.shape[-1] == K and x.numel() % (E * K) == 0, (tuple(x.shape), tuple(weight.shape))
         R = x.numel() // (E * K)
         sp = GemmSpec(R, N, K, E, 1, View(0, K, False, R * K, 0), View(0, K, True, N * K, 0), View(0, N, False, R * N, 0),
-                      tuple(x.shape[:-1]) + (N,), 1.0)
+                      tuple(x.shape[:-1]) + (N,), 1.0, out_dtype)
         return Gemm.call(x, weight, bias, sp)
     K = x.shape[-1]
     N = weight.shape[0]
     R = x.numel() // K
     out_shape = tuple(x.shape[:-1]) + (N,)
     sp = GemmSpec(R, N, K, 1, 1, View(0, K, False, 0, 0), View(0, K, True, 0, 0), View(0, N, False, 0, 0),
-                  out_shape, 1.0)
+                  out_shape, 1.0, out_dtype)
     return Gemm.call(x, weight, bias, sp)
 
 
@@ -1255,6 +1258,7 @@ def attention(q, k, v, nbatch, heads, L, S, hd, q_ld, k_ld, q_off, k_off, v_ld, 
 # ---------------------------------------------------------------------------------------------------------
 class ColSum(Function):
     """[rows, C] -> [C], or grouped [G, rows, C] -> [G, C]."""
+    b16_out = False   # (a bias gradient: fp32)
 
     @staticmethod
     def forward(ctx, x):
@@ -1355,6 +1359,7 @@ class SumN(Function):
 
 
 class Fanout(Function):
+    b16 = "native"   # (aliases: no arithmetic)
     @staticmethod
     def forward(ctx, x, n):
         ctx.set_materialize_grads(False)
@@ -1440,6 +1445,7 @@ def gs_zero(ctx, n, gs):
 
 class Dot(Function):
     """sum(a*b) -> 0-d tensor."""
+    b16_out = False   # (a scalar)
 
     @staticmethod
     def forward(ctx, a, b):
@@ -1482,6 +1488,7 @@ class RowNormSum(Function):
     """sum_e ||x_e||_2 over the rows of x [E, n] -> 0-d tensor, ONE launch (the learned loss of a chunk of episodes: reference
     models/interactron.py:96 per task).  Closed under the differentiation MAML needs: its backward is RowNormSumBwd, whose
     own backward is one more kernel."""
+    b16_out = False   # (a scalar)
 
     @staticmethod
     def forward(ctx, x):
@@ -1922,15 +1929,31 @@ class GemmBnAct(Function):
     """y = [relu]((A B) * scale[n] + shift[n] (+ residual)) for the plain row-major product of Gemm (1 x 1 convolutions);
     backward = BnAct's backward followed by Gemm's (all differentiable nodes: closed under the MAML double backward)."""
 
+    b16 = "native"
+
     @staticmethod
     def forward(ctx, a, b, scale, shift, residual, relu, sp, fan=1):
         ctx.set_materialize_grads(False)
         ctx.a_key, ctx.b_key = _param_key(a), _param_key(b)
+        assert sp.bi == 1 and sp.alpha == 1.0 and sp.C.offset == 0 and sp.C.ld == sp.N and not sp.C.trans
+        assert sp.A.offset == 0 and sp.B.offset == 0 and (sp.bo == 1 or sp.C.so == sp.M * sp.N)
+        if a.dtype == torch.bfloat16:   # 16-bit mode: the affine (+ residual) (+ ReLU) in the bf16 GEMM's own store (csrc/gemm16.hip)
+            from . import b16
+            wb = getattr(b, "_ix_weight", False)
+            a, b, scale, shift = b16._reqd(a, "gemm A"), b16._reqd(b, "gemm B"), _req(scale), _req(shift)
+            if wb:
+                mark_weight(b)
+            if residual is not None:
+                residual = b16._reqd(residual)
+                assert residual.dtype == torch.bfloat16
+            out = b16.run_gemm(a, b, None, sp, scale=scale, shift=shift, residual=residual, act=1 if relu else 0)
+            ctx.sp, ctx.relu, ctx.has_res = sp, relu, residual is not None
+            ctx.a_shape, ctx.b_shape = tuple(a.shape), tuple(b.shape)
+            ctx.save_for_backward(a, b, scale, out if relu else None)
+            return out if fan == 1 else (out, out.view_as(out))
         a, b, scale, shift = _req(a, "gemm A"), _req(b, "gemm B"), _req(scale), _req(shift)
         if residual is not None:
             residual = _req(residual)
-        assert sp.bi == 1 and sp.alpha == 1.0 and sp.C.offset == 0 and sp.C.ld == sp.N and not sp.C.trans
-        assert sp.A.offset == 0 and sp.B.offset == 0 and (sp.bo == 1 or sp.C.so == sp.M * sp.N)
         out = torch.empty(sp.out_shape, device=a.device, dtype=torch.float32)
         nws, _ = _gemm_workspace_bytes(a.data_ptr(), b.data_ptr(), sp, presplit=False)
         ws = _workspace(nws, a.device) if nws else None
@@ -2316,6 +2339,7 @@ class LayerNorm(Function):
 
 class LayerNormBwd(Function):
     """(dy, x, gamma) -> (dx, dgamma, dbeta); mean/rstd are recomputable statistics of x (handled analytically)."""
+    b16_out = (True, False, False)   # (dx is an activation; the parameter gradients stay fp32)
 
     @staticmethod
     def forward(ctx, dy, x, gamma, mean, rstd):

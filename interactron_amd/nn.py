@@ -24,8 +24,8 @@ class Linear(nn.Module):
         self.weight = _uniform((out_features, in_features), b)
         self.bias = _uniform((out_features,), b) if bias else None
 
-    def forward(self, x):
-        return ops.linear(x, self.weight, self.bias)
+    def forward(self, x, out_dtype=None):
+        return ops.linear(x, self.weight, self.bias, out_dtype)
 
 
 class LayerNorm(nn.Module):
