@@ -455,6 +455,20 @@ int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M,
 int ix_gemm_b16_supported(const void* A, const void* B, const void* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
                           int64_t ldb, int64_t ldc, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi);
 int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out_host);
+int ix_gemm_b16_set_stages(int stages); /* 1: one LDS stage, four workgroups per CU | 2: two stages, the next K step's DMA under this one's
+                                           matrix instructions; returns the previous setting (IX_GEMM16_STAGES) */
+/*   ix_conv_gemm_b16 : the three implicit-GEMM convolution kinds of ix_conv_gemm_f32 (forward, data gradient, weight gradient of a
+ *                   bias-free NHWC convolution with [out][kh][kw][in] weights: backbone.py:88-90) on bf16 tensors -- no patch matrix in
+ *                   HBM, the gather is the per-lane SOURCE address of the LDS-DMA.  kind 0 takes the frozen-BN affine (+ residual)
+ *                   (+ ReLU) epilogue; c_f32: fp32 result (the weight gradient).  Geometry limits: ix_conv_gemm_b16_supported
+ *                   (channels % 64 / % 128 so that a K step / an N tile lies inside one tap; stride 1, 2 or 4). */
+int ix_conv_gemm_b16(int kind, const void* src, const void* other, void* out, int groups, int imgs, int H, int W, int Cin, int OH, int OW,
+                     int Cout, int KH, int KW, int stride, int pad, int dil, int c_f32, const float* scale, const float* shift,
+                     const void* residual, int relu, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_conv_gemm_b16_supported(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                               int pad, int dil);
+int ix_workspace_bytes_conv_gemm_b16(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                                     size_t* out_host);
 /*   ix_map_b16    : out[k] = f_op(a[k], b[k], c[k]) on bf16 tensors (csrc/ew16.hip), the arithmetic of the fp32 kernels of the same name,
  *                   rounded once: op 0 a + b | 1 p0 a + p1 b | 2 p0 a | 3 relu(a) | 4 a [b > 0] p0 | 5 (a + b) [c > 0] | 6 gelu(a) |
  *                   7 a gelu'(b) | 8 dropout(a; p0, seed) | 9 dropout(relu(a)) | 10 a + dropout(b) (the dropout hash of ix_dropout_f32:
@@ -475,6 +489,9 @@ int ix_layernorm_fwd_b16(const void* x, const float* gamma, const float* beta, v
 int ix_workspace_bytes_layernorm_bwd_b16(int64_t rows, int D, size_t* out_host);
 int ix_layernorm_bwd_b16(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
                          float* dbeta, int64_t rows, int D, void* workspace, size_t workspace_bytes, ix_stream_t stream);
+int ix_workspace_bytes_colsum_b16(int64_t rows, int C, int groups, size_t* out_host);
+int ix_colsum_b16(const void* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                  ix_stream_t stream); /* [G][rows][C] bf16 -> [G][C] fp32 (bias gradients), ordered partial sums; C % 8 == 0 */
 int ix_cast_f32_b16(const float* x, void* y, int64_t n, ix_stream_t stream);
 int ix_cast_b16_f32(const void* x, float* y, int64_t n, ix_stream_t stream);
 int ix_prof_b16(double* ms, double* flops, double* bytes, int64_t* launches);

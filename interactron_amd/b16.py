@@ -22,7 +22,8 @@ from . import hipops as ops
 from ._lib import HipLibraryError
 
 B16 = torch.bfloat16
-_seen = ops._b16_seen   # [False] until the first bf16 activation exists in this process (keeps the fp32 path's per-call cost at one list read)
+_seen = ops._b16_seen   # [False] until this module is imported -- by the first model that runs in the mode, or by a test: the fp32 path's
+_seen[0] = True         # per-call cost stays at one list read in processes that never use 16-bit activations
 
 
 def is_b16(t):
@@ -194,3 +195,396 @@ def run_gemm(a, b, bias, sp, fill=True, scale=None, shift=None, residual=None, a
     _stats["native_gemms"] += 1
     _seen[0] = True
     return out
+
+
+# ---- native 16-bit forwards ("twins") --------------------------------------------------------------------------------------------
+# A twin subclasses the fp32 Function, inherits its backward (which is written with Functions that dispatch on dtype again) and
+# replaces the forward by the bf16 kernel of csrc/ew16.hip.  hipops.Function.apply / call send calls with bf16 tensors here.
+def _c16(t):
+    """an operand of a 16-bit elementwise op: bf16 as it is, an fp32 tensor (a position table, a cotangent from an fp32 island) cast"""
+    return _reqd(t) if t.dtype == B16 else cast_b16(t)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _map(op, a, b=None, c=None, p0=0.0, p1=0.0, seed=0):
+    out = torch.empty(a.shape, dtype=B16, device=a.device)
+    ops._chk(ops._L().ix_map_b16(op, a.data_ptr(), _ptr(b), _ptr(c), out.data_ptr(), a.numel(), p0, p1, seed, ops._stream()), "ix_map_b16")
+    return out
+
+
+def _channel(op, x, y, scale, shift, relu=False, groups=1):
+    C = scale.numel() // groups
+    out = torch.empty(x.shape, dtype=B16, device=x.device)
+    ops._chk(ops._L().ix_channel_b16(op, x.data_ptr(), _ptr(y), scale.data_ptr(), _ptr(shift), out.data_ptr(), x.numel() // C, C,
+                                     1 if relu else 0, groups, ops._stream()), "ix_channel_b16")
+    return out
+
+
+def _twin(base):
+    def deco(cls):
+        cls.b16 = "native"
+        base.b16_twin = cls
+        return cls
+    return deco
+
+
+@_twin(ops.Axpby)
+class Axpby16(ops.Axpby):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = _c16(a), _c16(b)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        ctx.alpha, ctx.beta = alpha, beta
+        return _map(0, a, b) if alpha == 1.0 and beta == 1.0 else _map(1, a, b, None, alpha, beta)
+
+
+@_twin(ops.Scale)
+class Scale16(ops.Scale):
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return _map(2, _c16(x), None, None, alpha)
+
+
+@_twin(ops.Relu)
+class Relu16(ops.Relu):
+    @staticmethod
+    def forward(ctx, x):
+        out = _map(3, _c16(x))
+        ctx.save_for_backward(out)
+        return out
+
+
+@_twin(ops.ReluBwd)
+class ReluBwd16(ops.ReluBwd):
+    @staticmethod
+    def forward(ctx, dy, y):
+        dy, y = _c16(dy), _c16(y)
+        ctx.save_for_backward(y)
+        return _map(4, dy, y, None, 1.0)
+
+
+@_twin(ops.ReluBwdSum)
+class ReluBwdSum16(ops.ReluBwdSum):
+    @staticmethod
+    def forward(ctx, ga, gb, y):
+        ga, gb, y = _c16(ga), _c16(gb), _c16(y)
+        ctx.save_for_backward(y)
+        return _map(5, ga, gb, y)
+
+
+@_twin(ops.ReluBwdScaled)
+class ReluBwdScaled16(ops.ReluBwdScaled):
+    @staticmethod
+    def forward(ctx, dy, y, scale):
+        dy, y = _c16(dy), _c16(y)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return _map(4, dy, y, None, scale)
+
+
+@_twin(ops.ReluDropout)
+class ReluDropout16(ops.ReluDropout):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        out = _map(9, _c16(x), None, None, p, 0.0, seed)
+        ctx.save_for_backward(out)
+        ctx.scale = 1.0 / (1.0 - p)
+        return out
+
+
+@_twin(ops.AddDropout)
+class AddDropout16(ops.AddDropout):
+    @staticmethod
+    def forward(ctx, x, a, p, seed):
+        x, a = _c16(x), _c16(a)
+        assert x.shape == a.shape, (x.shape, a.shape)
+        ctx.p, ctx.seed = p, seed
+        return _map(10, x, a, None, p, 0.0, seed)
+
+
+@_twin(ops._Dropout)
+class Dropout16(ops._Dropout):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return _map(8, _c16(x), None, None, p, 0.0, seed)
+
+
+@_twin(ops._AddDropoutBwd)
+class AddDropoutBwd16(ops._AddDropoutBwd):
+    @staticmethod
+    def forward(ctx, g, p, seed):
+        ctx.set_materialize_grads(False)
+        ctx.p, ctx.seed = p, seed
+        g = _c16(g)
+        return g.view_as(g), _map(8, g, None, None, p, 0.0, seed)
+
+
+@_twin(ops.Gelu)
+class Gelu16(ops.Gelu):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c16(x)
+        ctx.save_for_backward(x)
+        return _map(6, x)
+
+
+@_twin(ops.GeluBwd)
+class GeluBwd16(ops.GeluBwd):
+    @staticmethod
+    def forward(ctx, dy, x):
+        dy, x = _c16(dy), _c16(x)
+        ctx.save_for_backward(dy, x)
+        return _map(7, dy, x)
+
+    @staticmethod
+    def backward(ctx, G):   # second order: the fp32 kernel between conversion passes
+        dy, x = ctx.saved_tensors
+        gdy, gx = ops.GeluBwd.backward(_Saved(cast_f32(dy), cast_f32(x)), cast_f32(G))
+        return cast_b16(gdy), cast_b16(gx)
+
+
+class _Saved:
+    """stand-in context carrying `saved_tensors` for a parent-class backward run on converted tensors"""
+
+    def __init__(self, *tensors, **attrs):
+        self.saved_tensors = tensors
+        self.__dict__.update(attrs)
+
+
+@_twin(ops.SumN)
+class SumN16(ops.SumN):
+    @staticmethod
+    def forward(ctx, *xs):
+        assert all(x.shape == xs[0].shape for x in xs), [tuple(x.shape) for x in xs]
+        ts = [_c16(x) for x in xs]
+        L = ops._L()
+        while len(ts) > 1:
+            head, ts = ts[:8], ts[8:]
+            if len(head) == 1:
+                ts.insert(0, head[0])
+                break
+            out = torch.empty(head[0].shape, dtype=B16, device=head[0].device)
+            arr = (ctypes.c_void_p * len(head))(*[t.data_ptr() for t in head])
+            ops._chk(L.ix_sum_n_b16(arr, len(head), out.data_ptr(), out.numel(), ops._stream()), "ix_sum_n_b16")
+            ts.insert(0, out)
+        return ts[0]
+
+
+@_twin(ops.ChannelScale)
+class ChannelScale16(ops.ChannelScale):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = _c16(x)
+        if scale.numel() % 8:
+            return cast_b16(ops.ChannelScale.forward(ctx, cast_f32(x), scale))
+        ctx.save_for_backward(scale)
+        return _channel(2, x, None, scale, None)
+
+
+@_twin(ops.ReluBwdChannelScale)
+class ReluBwdChannelScale16(ops.ReluBwdChannelScale):
+    @staticmethod
+    def forward(ctx, g, y, scale):
+        g, y = _c16(g), _c16(y)
+        ctx.save_for_backward(y, scale)
+        return _channel(1, g, y, scale, None)
+
+
+@_twin(ops.BnAct)
+class BnAct16(ops.BnAct):
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        x = _c16(x)
+        residual = _c16(residual) if residual is not None else None
+        y = _channel(0, x, residual, scale, shift, relu)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(scale, y if relu else None)
+        return y
+
+
+@_twin(ops.AddRowVec)
+class AddRowVec16(ops.AddRowVec):
+    @staticmethod
+    def forward(ctx, a, v, groups=1):
+        a, v = _c16(a), ops._req(cast_f32(v))
+        C = v.numel() // groups
+        assert a.numel() % (C * groups) == 0 and C % 8 == 0
+        ctx.vshape, ctx.groups = tuple(v.shape), groups
+        return _channel(3, a, None, v, None, False, groups)
+
+
+@_twin(ops.ColSum)
+class ColSum16(ops.ColSum):
+    b16_out = False
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c16(x)
+        if x.dim() == 3:
+            G, rows, C = x.shape
+            out = torch.empty(G, C, device=x.device, dtype=torch.float32)
+        else:
+            (rows, C), G = x.shape, 1
+            out = torch.empty(C, device=x.device, dtype=torch.float32)
+        ctx.rows = rows
+        if C % 8:
+            return ops.ColSum.forward(ctx, cast_f32(x))
+        n = ctypes.c_size_t()
+        ops._chk(ops._L().ix_workspace_bytes_colsum_b16(rows, C, G, ctypes.byref(n)), "ix_workspace_bytes_colsum_b16")
+        ws = ops._workspace(n.value, x.device)
+        ops._chk(ops._L().ix_colsum_b16(x.data_ptr(), out.data_ptr(), rows, C, G, ws.data_ptr(), n.value, ops._stream()), "ix_colsum_b16")
+        return out
+
+
+@_twin(ops.LayerNorm)
+class LayerNorm16(ops.LayerNorm):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _c16(x), ops._req(gamma), ops._req(beta)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        if gamma.dim() == 2 or D % 4 or D > 1024:   # per-episode affine / odd widths: the fp32 kernel between conversion passes
+            G = gamma.shape[0] if gamma.dim() == 2 else 1
+            x32 = cast_f32(x)
+            y32 = torch.empty_like(x32)
+            mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            ops._chk(ops._L().ix_layernorm_fwd_f32(x32.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y32.data_ptr(), mean.data_ptr(),
+                                                   rstd.data_ptr(), rows // G, D, eps, G, ops._stream()), "ix_layernorm_fwd_f32")
+            ctx.save_for_backward(x, gamma, mean, rstd)
+            return cast_b16(y32)
+        y = torch.empty(x.shape, dtype=B16, device=x.device)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        ops._chk(ops._L().ix_layernorm_fwd_b16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                               rstd.data_ptr(), rows, D, eps, ops._stream()), "ix_layernorm_fwd_b16")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+
+@_twin(ops.LayerNormBwd)
+class LayerNormBwd16(ops.LayerNormBwd):
+    @staticmethod
+    def forward(ctx, dy, x, gamma, mean, rstd):
+        dy, x = _c16(dy), _c16(x)
+        D = x.shape[-1]
+        if gamma.dim() == 2 or D % 4 or D > 1024:
+            dx, dg, db = ops.LayerNormBwd.forward(ops._NullCtx(), cast_f32(dy), cast_f32(x), gamma, mean, rstd)
+            ctx.save_for_backward(dy, x, gamma, mean, rstd)
+            return cast_b16(dx), dg, db
+        rows = x.numel() // D
+        dx = torch.empty(x.shape, dtype=B16, device=x.device)
+        both = torch.empty((2,) + tuple(gamma.shape), device=gamma.device, dtype=torch.float32)
+        n = ctypes.c_size_t()
+        ops._chk(ops._L().ix_workspace_bytes_layernorm_bwd_b16(rows, D, ctypes.byref(n)), "ix_workspace_bytes_layernorm_bwd_b16")
+        ws = ops._workspace(n.value, x.device)
+        ops._chk(ops._L().ix_layernorm_bwd_b16(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                               both[0].data_ptr(), both[1].data_ptr(), rows, D, ws.data_ptr(), n.value, ops._stream()),
+                 "ix_layernorm_bwd_b16")
+        ctx.save_for_backward(dy, x, gamma, mean, rstd)
+        return dx, both[0], both[1]
+
+    @staticmethod
+    def backward(ctx, Gx, Gg, Gb):   # second order: the fp32 kernel between conversion passes
+        dy, x, gamma, mean, rstd = ctx.saved_tensors
+        up = lambda t: cast_f32(t) if t is not None else None
+        gdy, gx, gg, _, _ = ops.LayerNormBwd.backward(_Saved(cast_f32(dy), cast_f32(x), gamma, mean, rstd), up(Gx), Gg, Gb)
+        return cast_b16(gdy), cast_b16(gx), gg, None, None
+
+
+# ---- implicit-GEMM convolutions on bf16 NHWC activations (csrc/gemm16.hip, ix_conv_gemm_b16) -------------------------------------------
+_conv16_ok, _conv16_ws = {}, {}
+
+
+def conv16_supported(kind, cg):
+    ok = _conv16_ok.get((kind, cg))
+    if ok is None:
+        ok = _conv16_ok[(kind, cg)] = bool(ops._L().ix_conv_gemm_b16_supported(
+            kind, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil))
+    return ok
+
+
+def _conv16(kind, src, other, out_shape, cg, out_f32=False, scale=None, shift=None, residual=None, relu=False):
+    out = torch.empty(out_shape, device=src.device, dtype=torch.float32 if out_f32 else B16)
+    nws = _conv16_ws.get((kind, cg))
+    if nws is None:
+        n = ctypes.c_size_t(0)
+        ops._chk(ops._L().ix_workspace_bytes_conv_gemm_b16(kind, cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH, cg.OW, cg.Cout, cg.KH, cg.KW,
+                                                           ctypes.byref(n)), "ix_workspace_bytes_conv_gemm_b16")
+        nws = _conv16_ws[(kind, cg)] = n.value
+    ws = ops._workspace(nws, src.device) if nws else None
+    ops._chk(ops._L().ix_conv_gemm_b16(kind, src.data_ptr(), other.data_ptr(), out.data_ptr(), cg.E, cg.imgs, cg.H, cg.W, cg.Cin, cg.OH,
+                                       cg.OW, cg.Cout, cg.KH, cg.KW, cg.stride, cg.pad, cg.dil, 1 if out_f32 else 0, _ptr(scale),
+                                       _ptr(shift), _ptr(residual), 1 if relu else 0, ws.data_ptr() if nws else None, nws,
+                                       ops._stream()), "ix_conv_gemm_b16")
+    _stats["native_gemms"] += 1
+    return out
+
+
+@_twin(ops.ConvFwd)
+class ConvFwd16(ops.ConvFwd):
+    @staticmethod
+    def forward(ctx, x, w, cg):
+        ctx.w_key = ops._param_key(w)
+        ctx.cg = cg
+        x = _c16(x)
+        w = _reqd(w, "conv weight")
+        ctx.save_for_backward(x, w)
+        if not conv16_supported(0, cg):
+            return cast_b16(ops._conv_gemm(0, cast_f32(x), cast_f32(w), (cg.E * cg.imgs, cg.OH, cg.OW, cg.Cout), cg))
+        return _conv16(0, x, _as_b16(w), (cg.E * cg.imgs, cg.OH, cg.OW, cg.Cout), cg)
+
+
+@_twin(ops.ConvBwdData)
+class ConvBwdData16(ops.ConvBwdData):
+    @staticmethod
+    def forward(ctx, dy, w, cg):
+        ctx.w_key = ops._param_key(w)
+        ctx.cg = cg
+        dy = _c16(dy)
+        w = _reqd(w, "conv weight")
+        ctx.save_for_backward(dy, w)
+        if not conv16_supported(1, cg):
+            return cast_b16(ops._conv_gemm(1, cast_f32(dy), cast_f32(w), (cg.E * cg.imgs, cg.H, cg.W, cg.Cin), cg))
+        return _conv16(1, dy, _as_b16(w), (cg.E * cg.imgs, cg.H, cg.W, cg.Cin), cg)
+
+
+@_twin(ops.ConvBwdWeight)
+class ConvBwdWeight16(ops.ConvBwdWeight):
+    b16_out = False
+
+    @staticmethod
+    def forward(ctx, dy, x, cg, w_shape):
+        """the weight gradient of a bf16 convolution: fp32 (the parameter's dtype)"""
+        ctx.cg = cg
+        dy, x = _c16(dy), _c16(x)
+        ctx.save_for_backward(dy, x)
+        if not conv16_supported(2, cg):
+            return ops._conv_gemm(2, cast_f32(dy), cast_f32(x), w_shape, cg)
+        return _conv16(2, dy, x, w_shape, cg, out_f32=True)
+
+
+@_twin(ops.ConvFwdBnAct)
+class ConvFwdBnAct16(ops.ConvFwdBnAct):
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, residual, relu, cg, fan=1):
+        ctx.set_materialize_grads(False)
+        ctx.w_key = ops._param_key(w)
+        x = _c16(x)
+        w, scale, shift = _reqd(w, "conv weight"), ops._req(scale), ops._req(shift)
+        residual = _c16(residual) if residual is not None else None
+        shape = (cg.E * cg.imgs, cg.OH, cg.OW, cg.Cout)
+        if conv16_supported(0, cg):
+            out = _conv16(0, x, _as_b16(w), shape, cg, False, scale, shift, residual, relu)
+        else:
+            y = ops._conv_gemm(0, cast_f32(x), cast_f32(w), shape, cg)
+            out = cast_b16(ops._channel_affine(y, scale, shift, cast_f32(residual) if residual is not None else None, relu))
+        ctx.cg, ctx.relu, ctx.has_res = cg, relu, residual is not None
+        ctx.save_for_backward(x, w, scale, out if relu else None)
+        return out if fan == 1 else (out, out.view_as(out))

@@ -413,3 +413,69 @@ extern "C" int ix_layernorm_bwd_b16(const void* dy, const void* x, const float* 
     IX_CHECK_LAUNCH("ix_layernorm_bwd_b16");
     return IX_OK;
 }
+
+// ---- column sums of a bf16 [G][rows][C] tensor -> fp32 [G][C] (bias gradients): each workgroup sums CS16_ROWS rows of a 512-column
+// slab into one fp32 partial row, colsum_b16_reduce_kernel adds the partial rows in order (deterministic; C % 8 == 0) -----------------
+#define CS16_ROWS 128
+__global__ __launch_bounds__(256) void colsum_b16_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, int64_t rows, int C, int nblk) {
+    // thread t: column group (t % 64) of this slab (8 columns), row phase t / 64 (4 phases)
+    __shared__ float red[4][512];
+    const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c0 = blockIdx.y * 512 + cg * 8;
+    const int g = blockIdx.z;
+    const bf16_t* xg = x + (int64_t)g * rows * C;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        const int64_t r0 = (int64_t)blockIdx.x * CS16_ROWS, r1 = min(rows, r0 + CS16_ROWS);
+        for (int64_t r = r0 + ph; r < r1; r += 4) {
+            const F8 v = e16_ld8(xg + r * C + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v.v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ph][cg * 8 + e] = s[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int col = blockIdx.y * 512 + c;
+        if (col < C) part[((int64_t)g * nblk + blockIdx.x) * C + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
+}
+// 64 columns per workgroup, four row phases: thread (c, ph) adds partial rows ph, ph + 4, ... in order, the four phase sums are added
+// in phase order (a fixed order: the same bits every time)
+__global__ __launch_bounds__(256) void colsum_b16_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int C, int G) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + cl;     // flat (group, column)
+    float s = 0.f;
+    if (i < (int64_t)G * C) {
+        const int g = (int)(i / C), c = (int)(i - (int64_t)g * C);
+        const float* p = part + (int64_t)g * nblk * C + c;
+        for (int b = ph; b < nblk; b += 4) s += p[(int64_t)b * C];
+    }
+    red[ph][cl] = s;
+    __syncthreads();
+    if (ph == 0 && i < (int64_t)G * C) out[i] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+extern "C" int ix_workspace_bytes_colsum_b16(int64_t rows, int C, int groups, size_t* out) {
+    IX_CHECK_ARG(out && rows >= 0 && C > 0 && groups > 0, "ix_workspace_bytes_colsum_b16: bad args");
+    const int64_t nblk = (rows + CS16_ROWS - 1) / CS16_ROWS;
+    *out = IX_TICKET_BYTES + (size_t)groups * nblk * C * sizeof(float);
+    return IX_OK;
+}
+extern "C" int ix_colsum_b16(const void* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
+                             hipStream_t stream) {
+    if (rows <= 0 || C <= 0 || groups <= 0) return IX_OK;
+    IX_CHECK_ARG(x && out && ix_al16(x) && C % 8 == 0 && groups <= 65535, "ix_colsum_b16: null / unaligned pointer or C %% 8 != 0");
+    const int64_t nblk = (rows + CS16_ROWS - 1) / CS16_ROWS;
+    const size_t need = IX_TICKET_BYTES + (size_t)groups * nblk * C * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        ix_set_error("ix_colsum_b16: workspace of %zu bytes needed (ix_workspace_bytes_colsum_b16)", need);
+        return IX_ERR_WORKSPACE;
+    }
+    float* part = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+    hipLaunchKernelGGL(colsum_b16_kernel, dim3((unsigned)nblk, (C + 511) / 512, groups), dim3(256), 0, stream, (const bf16_t*)x, part, rows, C, (int)nblk);
+    hipLaunchKernelGGL(colsum_b16_reduce_kernel, dim3((unsigned)(((int64_t)groups * C + 63) / 64)), dim3(256), 0, stream, part, out, (int)nblk, C, groups);
+    IX_CHECK_LAUNCH("ix_colsum_b16");
+    return IX_OK;
+}

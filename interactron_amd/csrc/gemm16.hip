@@ -38,7 +38,32 @@ constexpr int G16_IMG = 128 * 64 * 2;   // one operand tile in LDS: 16 KB in eit
 
 void ix_prof_begin_b16(hipStream_t stream, int M, int N, int K, int nbatch, double bytes);
 
+// Division by an invariant positive integer d:  n / d = (mulhi(n, m) + n) >> s  for 0 <= n < 2^31 (the FastDiv of gemm.hip)
+struct G16Div { unsigned m; int s; };
+__device__ __forceinline__ int g16_div(int n, G16Div f) { return (int)((__umulhi((unsigned)n, f.m) + (unsigned)n) >> f.s); }
+static inline G16Div g16_make_div(unsigned d) {
+    G16Div f;
+    f.s = 0;
+    while ((1ull << f.s) < d) ++f.s;
+    f.m = (unsigned)((((1ull << 32) * ((1ull << f.s) - d)) / d) + 1);
+    return f;
+}
+// Implicit-GEMM convolution operands (no patch matrix in HBM; the scheme of ConvGather in gemm.hip, here as per-lane SOURCE
+// addresses of the LDS-DMA).  A "pixel row" index decomposes over a grid, row = (img * gH + gy) * gW + gx, and tap (ky, kx) of that
+// pixel reads the NHWC source [img][sH][sW][sC] at  sy = (gy * a + b + ky * d) >> qs,  sx likewise (valid iff divisible by 1 << qs
+// and inside; invalid taps are requested out of range: zeros).
+//   mode 1: A rows are pixels, k = (tap, c): a K step of 64 lies inside one tap (sC % 64 == 0)            forward, data gradient
+//           + btap: B(k, n) with k = (tap, co) is W[co][tap][n]: rows co of a matrix with ld = ldb at column offset tap * bcol   (data gradient)
+//   mode 2: B rows k are pixels, n = (tap, c): an N tile of 128 lies inside one tap (sC % 128 == 0)       weight gradient
+struct G16Conv {
+    int mode, btap, bcol;
+    int gH, gW, sH, sW, sC;
+    int a, b, d, qs, KW;
+    G16Div dW, dHW, dC;   // divisions by gW, gH * gW, sC (mode 1: k -> tap; with btap: by the channels per tap of B's k index)
+};
+
 struct G16Args {
+    G16Conv cg;
     const unsigned short* A;
     const unsigned short* B;
     void* C;
@@ -81,9 +106,12 @@ __device__ __forceinline__ float g16_act(float v, int act) {
 #define G16_OOB 0x7ffffff0
 
 // A_KC / B_KC: the operand's contracted index is contiguous in HBM.  F32OUT: C (and the residual) are fp32.
-template <bool A_KC, bool B_KC, bool F32OUT>
-__global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G16_IMG];
+// CONV: 0 plain operands; 1 / 2: the gathering operand of an implicit-GEMM convolution (G16Conv.mode)
+// STAGES: 1 = one 32 KB LDS stage, four workgroups per CU cover each other's DMA latency; 2 = two stages, the next K step's DMA in
+// flight under this one's matrix instructions (counted vmcnt, raw barriers), two workgroups per CU
+template <bool A_KC, bool B_KC, bool F32OUT, int CONV = 0, int STAGES = 1>
+__global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm16_kernel(G16Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * 2 * G16_IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, g = lane >> 4;
     const int nwg = p.tiles_m * p.tiles_n;
@@ -106,13 +134,24 @@ __global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
     // ---- DMA: pieces q = 4 wave .. 4 wave + 3 of each image; lane l of piece q fills the 16-byte slot q * 64 + l ----------------
     // per-lane byte offset of the slot's source at k step 0, the k index (0..63) it holds, and the per-k-step advance (scalar)
     int va[4], vb[4], ka[4], kb[4];
+    int gpy[4], gpx[4], gbase[4];   // CONV: per slot, the pixel row's source coordinates at tap (0, 0) and its image's first pixel
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int slot = (wave * 4 + q) * 64 + lane;
+        gpy[q] = gpx[q] = gbase[q] = 0;
         if (A_KC) {
             const int row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
             va[q] = (min(m0 + row, p.M - 1) * (int)p.lda + c * 8) * 2;
             ka[q] = c * 8;
+            if (CONV == 1) {
+                const int r = min(m0 + row, p.M - 1);
+                const int img = g16_div(r, p.cg.dHW), rem = r - img * (p.cg.gH * p.cg.gW);
+                const int gy = g16_div(rem, p.cg.dW), gx = rem - gy * p.cg.gW;
+                gpy[q] = gy * p.cg.a + p.cg.b;
+                gpx[q] = gx * p.cg.a + p.cg.b;
+                gbase[q] = img * (p.cg.sH * p.cg.sW);
+                va[q] = c * 16;
+            }
         } else {
             const int kr = slot >> 4, u = (slot & 15) ^ (2 * ((kr & 3) + 4 * ((kr >> 3) & 1)));
             va[q] = (kr * (int)p.lda + m0 + u * 8) * 2;
@@ -126,10 +165,17 @@ __global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
             const int kr = slot >> 4, u = (slot & 15) ^ (2 * ((kr & 3) + 4 * ((kr >> 3) & 1)));
             vb[q] = (kr * (int)p.ldb + n0 + u * 8) * 2;
             kb[q] = kr;
+            if (CONV == 2) vb[q] = u * 16;   // (the column inside the tap's channels; the pixel part is computed per k step)
         }
     }
     const int stepA = A_KC ? G16_BK * 2 : G16_BK * (int)p.lda * 2;
     const int stepB = B_KC ? G16_BK * 2 : G16_BK * (int)p.ldb * 2;
+    // CONV == 2: this N tile's tap and first channel (the tile lies inside one tap)
+    int wt_ky = 0, wt_kx = 0, wt_c0 = 0;
+    if (CONV == 2) {
+        const int t = g16_div(n0, p.cg.dC);
+        wt_ky = t / p.cg.KW; wt_kx = t - wt_ky * p.cg.KW; wt_c0 = n0 - t * p.cg.sC;
+    }
 
     // ---- fragment addresses (bytes inside an image) -------------------------------------------------------------------------------
     // k-contiguous image: row (w + 16 rb + idx) * 128 + ((4 s + g) ^ swz) * 16, swz = (idx >> 1) & 7 (w and 16 rb are multiples of 16)
@@ -147,21 +193,70 @@ __global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    unsigned char* const imgA = lds;
-    unsigned char* const imgB = lds + G16_IMG;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        {
-            unsigned char* dA = imgA + wave * 4096;
-            unsigned char* dB = imgB + wave * 4096;
-            const int klim = p.K - kt * G16_BK;   // k indices >= klim of this stage do not exist: out-of-range request -> zeros
-            const int sa = kt * stepA, sb = kt * stepB;
+    // the DMA requests of K step kt into the images at imgA / imgB
+    auto issue = [&](int kt, unsigned char* imgA, unsigned char* imgB) {
+        unsigned char* dA = imgA + wave * 4096;
+        unsigned char* dB = imgB + wave * 4096;
+        const int klim = p.K - kt * G16_BK;   // k indices >= klim of this stage do not exist: out-of-range request -> zeros
+        int sa = kt * stepA, sb = kt * stepB;
+        if (CONV == 1) {
+            // this K step's tap (scalar) and, per slot, the source pixel of the slot's row under that tap
+            const int k0 = kt * G16_BK, t = g16_div(k0, p.cg.dC);
+            const int ky = t / p.cg.KW, kx = t - ky * p.cg.KW;
+            sa = (k0 - t * p.cg.sC) * 2;
+            const int qm = (1 << p.cg.qs) - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int y = gpy[q] + ky * p.cg.d, x = gpx[q] + kx * p.cg.d;
+                bool ok = ((y | x) & qm) == 0;
+                y >>= p.cg.qs; x >>= p.cg.qs;
+                ok = ok && (unsigned)y < (unsigned)p.cg.sH && (unsigned)x < (unsigned)p.cg.sW;
+                const int off = ((gbase[q] + y * p.cg.sW + x) * p.cg.sC) * 2 + va[q];
+                g16_dma16(rA, ok ? off : G16_OOB, sa, dA + q * 1024);
+            }
+            if (p.cg.btap) {   // B rows k = (tap, co) live at W[co][tap][n]: row co of a [.., ldb] matrix at column offset tap * bcol
+                const int tb = k0 / p.cg.btap;
+                sb = ((k0 - tb * p.cg.btap) * (int)p.ldb + tb * p.cg.bcol) * 2;
+            }
+        } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g16_dma16(rA, ka[q] < klim ? va[q] : G16_OOB, sa, dA + q * 1024);
+        }
+        if (CONV == 2) {
+            // B rows are pixels: row kr of this stage is pixel kt * 64 + kr of the output grid, read at this tile's tap
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pix = kt * G16_BK + kb[q];
+                const int img = g16_div(pix, p.cg.dHW), rem = pix - img * (p.cg.gH * p.cg.gW);
+                const int gy = g16_div(rem, p.cg.dW), gx = rem - gy * p.cg.gW;
+                const int y = gy * p.cg.a + p.cg.b + wt_ky * p.cg.d, x = gx * p.cg.a + p.cg.b + wt_kx * p.cg.d;
+                const bool ok = pix < p.K && (unsigned)y < (unsigned)p.cg.sH && (unsigned)x < (unsigned)p.cg.sW;
+                const int off = (((img * p.cg.sH + y) * p.cg.sW + x) * p.cg.sC + wt_c0) * 2 + vb[q];
+                g16_dma16(rB, ok ? off : G16_OOB, 0, dB + q * 1024);
+            }
+        } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) g16_dma16(rB, kb[q] < klim ? vb[q] : G16_OOB, sb, dB + q * 1024);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
-        __syncthreads();                                    // everybody's have
+    };
+    if (STAGES == 2) issue(kt0, lds, lds + G16_IMG);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        unsigned char* const imgA = lds + (STAGES == 2 ? ((kt - kt0) & 1) * 2 * G16_IMG : 0);
+        unsigned char* const imgB = imgA + G16_IMG;
+        if (STAGES == 2) {
+            if (kt + 1 < kt1) {
+                unsigned char* const nA = lds + (((kt - kt0) & 1) ^ 1) * 2 * G16_IMG;
+                issue(kt + 1, nA, nA + G16_IMG);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's eight pieces of THIS stage have landed; the next stage's fly
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        } else {
+            issue(kt, imgA, imgB);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
+            __syncthreads();                                    // everybody's have
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             u32x4 fm[4], fn[4];
@@ -189,7 +284,12 @@ __global__ __launch_bounds__(256, 4) void gemm16_kernel(G16Args p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fn[j]), __builtin_bit_cast(bf16x8, fm[i]),
                                                                         acc[i][j], 0, 0, 0);
         }
-        __syncthreads();   // the stage may be overwritten
+        if (STAGES == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // everybody has read this stage: the DMA of K step kt + 2 may overwrite it
+        } else {
+            __syncthreads();   // the stage may be overwritten
+        }
     }
 
     // ---- epilogue: lane (idx, g) of block (i, j) holds row m = wm + 16 i + idx, columns n = wn + 16 j + 4 g .. + 3 -----------------
@@ -311,6 +411,64 @@ extern "C" int ix_gemm_b16_supported(const void* A, const void* B, const void* C
     return 1;
 }
 
+// 1 (default until measured otherwise) | 2 LDS stages per workgroup: ix_gemm_b16_set_stages / IX_GEMM16_STAGES (A/B runs, tests)
+static int g_g16_stages = -1;
+static int g16_stages() {
+    if (g_g16_stages < 0) {
+        const char* e = getenv("IX_GEMM16_STAGES");
+        g_g16_stages = (e && e[0] == '2') ? 2 : 1;
+    }
+    return g_g16_stages;
+}
+extern "C" int ix_gemm_b16_set_stages(int stages) {
+    const int old = g16_stages();
+    g_g16_stages = stages == 2 ? 2 : 1;
+    return old;
+}
+
+// plan + launch (+ the split-K tail) of a prepared argument block: the plain contraction and the three convolution kinds share it
+static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                   const char* name) {
+    const int M = a.M, N = a.N, K = a.K;
+    a.nk = ix_div_up(K, G16_BK);
+    g16_plan(M, N, K, nbatch, &a.split, &a.kps);
+    a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN);
+    a.planes = nullptr;
+    if (a.split > 1) {
+        const size_t need = (size_t)a.split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float);
+        if (!workspace || workspace_bytes < need + IX_TICKET_BYTES) { a.split = 1; a.kps = a.nk; }   // no scratch: one pass over K
+        else a.planes = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+    }
+    IX_CHECK_ARG(nbatch <= 65535 && a.split <= 65535, "%s: too many batch slices", name);
+    const dim3 grid(a.tiles_m * a.tiles_n, nbatch, a.split);
+    const double bytes = 2.0 * ((double)M * K + (double)K * N) * nbatch + (f32 ? 4.0 : 2.0) * (double)M * N * nbatch;
+    ix_prof_begin_b16(stream, M, N, K, nbatch, bytes);
+#define G16_LAUNCH(AK, BK_, F, CV)                                                                                       \
+    do {                                                                                                                 \
+        if (g16_stages() == 2) hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 2>), grid, dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 1>), grid, dim3(256), 0, stream, a);                      \
+    } while (0)
+    if (a.cg.mode == 1) {
+        if (b_kc) { if (f32) G16_LAUNCH(true, true, true, 1); else G16_LAUNCH(true, true, false, 1); }
+        else { if (f32) G16_LAUNCH(true, false, true, 1); else G16_LAUNCH(true, false, false, 1); }
+    } else if (a.cg.mode == 2) {
+        if (f32) G16_LAUNCH(false, false, true, 2); else G16_LAUNCH(false, false, false, 2);
+    } else if (a_kc && b_kc) { if (f32) G16_LAUNCH(true, true, true, 0); else G16_LAUNCH(true, true, false, 0); }
+    else if (a_kc && !b_kc) { if (f32) G16_LAUNCH(true, false, true, 0); else G16_LAUNCH(true, false, false, 0); }
+    else if (!a_kc && b_kc) { if (f32) G16_LAUNCH(false, true, true, 0); else G16_LAUNCH(false, true, false, 0); }
+    else { if (f32) G16_LAUNCH(false, false, true, 0); else G16_LAUNCH(false, false, false, 0); }
+#undef G16_LAUNCH
+    if (a.planes) {
+        const int64_t work = (int64_t)nbatch * M * (N / 4);
+        const int g = ix_grid_1d(work, 256);
+        if (f32) hipLaunchKernelGGL(gemm16_reduce_kernel<true>, dim3(g), dim3(256), 0, stream, a, nbatch);
+        else hipLaunchKernelGGL(gemm16_reduce_kernel<false>, dim3(g), dim3(256), 0, stream, a, nbatch);
+    }
+    ix_prof_end(stream);
+    IX_CHECK_LAUNCH(name);
+    return IX_OK;
+}
+
 extern "C" int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int a_kcontig, int b_kcontig,
                            int64_t lda, int64_t ldb, int64_t ldc, int batch_outer, int batch_inner, int64_t sAo, int64_t sAi,
                            int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi, int64_t bias_stride, float alpha, int c_f32,
@@ -331,36 +489,92 @@ extern "C" int ix_gemm_b16(const void* A, const void* B, void* C, const float* b
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sAo = sAo; a.sAi = sAi; a.sBo = sBo; a.sBi = sBi; a.sCo = sCo; a.sCi = sCi; a.sBias = bias_stride;
     a.extA = (unsigned)(2 * (a_kcontig ? ((int64_t)(M - 1) * lda + K) : ((int64_t)(K - 1) * lda + M)));
     a.extB = (unsigned)(2 * (b_kcontig ? ((int64_t)(N - 1) * ldb + K) : ((int64_t)(K - 1) * ldb + N)));
-    a.M = M; a.N = N; a.K = K; a.nk = ix_div_up(K, G16_BK);
-    g16_plan(M, N, K, nbatch, &a.split, &a.kps);
-    a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN); a.batch_inner = batch_inner;
-    a.alpha = alpha; a.act = act; a.planes = nullptr;
-    if (a.split > 1) {
-        const size_t need = (size_t)a.split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float);
-        if (!workspace || workspace_bytes < need + IX_TICKET_BYTES) { a.split = 1; a.kps = a.nk; }   // no scratch: one pass over K
-        else a.planes = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+    a.M = M; a.N = N; a.K = K; a.batch_inner = batch_inner;
+    a.alpha = alpha; a.act = act;
+    a.cg.mode = 0; a.cg.btap = 0;
+    return g16_run(a, a_kcontig != 0, b_kcontig != 0, c_f32 != 0, nbatch, workspace, workspace_bytes, stream, "ix_gemm_b16");
+}
+
+// ---- implicit-GEMM convolution on bf16 NHWC activations (the three kinds of ix_conv_gemm_f32; csrc/gemm.hip has the fp32 twin) ------
+//   kind 0  y[g][img][oy][ox][co]  = sum_{ky,kx,c} x[g][img][oy*s-p+ky*d][ox*s-p+kx*d][c] * w[g][co][ky][kx][c]     (+ epilogue)
+//   kind 1  dx[g][img][y][x][c]    = sum_{ky,kx,co} dy[g][img][(y+p-ky*d)/s][(x+p-kx*d)/s][co] * w[g][co][ky][kx][c]
+//   kind 2  dw[g][co][ky][kx][c]   = sum_{img,oy,ox} dy[g][img][oy][ox][co] * x[g][img][oy*s-p+ky*d][ox*s-p+kx*d][c]
+// `groups` = episodes with their own (fast) weights; shared weights: groups = 1 and imgs = all images.
+static bool g16_conv_ok(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride,
+                        int pad, int dil) {
+    if (groups <= 0 || imgs <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || dil <= 0 || pad < 0) return false;
+    if (stride != 1 && stride != 2 && stride != 4) return false;
+    if (Cin % 8 || Cout % 8) return false;
+    if (kind == 0 && Cin % 64) return false;          // a K step inside one tap
+    if (kind == 1 && Cout % 64) return false;
+    if (kind == 2 && Cin % 128) return false;         // an N tile inside one tap
+    const int64_t px_in = (int64_t)imgs * H * W, px_out = (int64_t)imgs * OH * OW;
+    if (px_in * Cin * 2 >= 0x7fffff00ll || px_out * Cout * 2 >= 0x7fffff00ll || (int64_t)Cout * KH * KW * Cin * 2 >= 0x7fffff00ll) return false;
+    if (px_in >= (1ll << 30) || px_out >= (1ll << 30)) return false;
+    return true;
+}
+extern "C" int ix_conv_gemm_b16_supported(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                                          int stride, int pad, int dil) {
+    return (kind >= 0 && kind <= 2 && g16_conv_ok(kind, groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil)) ? 1 : 0;
+}
+static void g16_conv_dims(int kind, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int T, int* M, int* N, int* K) {
+    if (kind == 0) { *M = imgs * OH * OW; *N = Cout; *K = T * Cin; }
+    else if (kind == 1) { *M = imgs * H * W; *N = Cin; *K = T * Cout; }
+    else { *M = Cout; *N = T * Cin; *K = imgs * OH * OW; }
+}
+extern "C" int ix_workspace_bytes_conv_gemm_b16(int kind, int groups, int imgs, int H, int W, int Cin, int OH, int OW, int Cout, int KH,
+                                                int KW, size_t* out) {
+    IX_CHECK_ARG(out && kind >= 0 && kind <= 2, "ix_workspace_bytes_conv_gemm_b16: bad args");
+    int M, N, K;
+    g16_conv_dims(kind, imgs, H, W, Cin, OH, OW, Cout, KH * KW, &M, &N, &K);
+    return ix_workspace_bytes_gemm_b16(M, N, K, groups, out);
+}
+extern "C" int ix_conv_gemm_b16(int kind, const void* src, const void* other, void* out, int groups, int imgs, int H, int W, int Cin,
+                                int OH, int OW, int Cout, int KH, int KW, int stride, int pad, int dil, int c_f32, const float* scale,
+                                const float* shift, const void* residual, int relu, void* workspace, size_t workspace_bytes,
+                                hipStream_t stream) {
+    IX_CHECK_ARG(kind >= 0 && kind <= 2 && src && other && out, "ix_conv_gemm_b16: bad kind or null pointer");
+    IX_CHECK_ARG(g16_conv_ok(kind, groups, imgs, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, dil),
+                 "ix_conv_gemm_b16: geometry not supported (ix_conv_gemm_b16_supported)");
+    IX_CHECK_ARG(ix_al16(src) && ix_al16(other) && ix_al16(out), "ix_conv_gemm_b16: 16-byte aligned tensors needed");
+    IX_CHECK_ARG((scale == nullptr) == (shift == nullptr) && (kind == 0 || (!scale && !residual && !relu)),
+                 "ix_conv_gemm_b16: the affine / residual / ReLU epilogue belongs to the forward kind");
+    const int T = KH * KW;
+    G16Args a;
+    int M, N, K;
+    g16_conv_dims(kind, imgs, H, W, Cin, OH, OW, Cout, T, &M, &N, &K);
+    a.C = out; a.bias = nullptr; a.scale = scale; a.shift = shift; a.res = residual;
+    a.M = M; a.N = N; a.K = K; a.batch_inner = 1; a.alpha = 1.f; a.act = relu ? 1 : 0; a.sBias = 0;
+    a.sAi = a.sBi = a.sCi = 0;
+    a.ldc = N; a.sCo = (int64_t)M * N;
+    G16Conv& g = a.cg;
+    g.btap = 0; g.bcol = 0; g.KW = KW;
+    int qs = 0;
+    while ((1 << qs) < stride) ++qs;
+    const int64_t x_slice = (int64_t)imgs * H * W * Cin, y_slice = (int64_t)imgs * OH * OW * Cout, w_slice = (int64_t)Cout * T * Cin;
+    bool a_kc, b_kc;
+    if (kind == 0) {          // A = x gathered over output pixels, B = w [Cout][T * Cin]
+        a.A = (const unsigned short*)src; a.B = (const unsigned short*)other;
+        a.lda = Cin; a.ldb = (int64_t)T * Cin; a.sAo = x_slice; a.sBo = w_slice;
+        a.extA = (unsigned)(2 * x_slice); a.extB = (unsigned)(2 * w_slice);
+        g.mode = 1; g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        a_kc = true; b_kc = true;
+    } else if (kind == 1) {   // A = dy gathered over input pixels (flipped taps), B(k = (tap, co), n = c) = w[co][tap][c]
+        a.A = (const unsigned short*)src; a.B = (const unsigned short*)other;
+        a.lda = Cout; a.ldb = (int64_t)T * Cin; a.sAo = y_slice; a.sBo = w_slice;
+        a.extA = (unsigned)(2 * y_slice); a.extB = (unsigned)(2 * w_slice);
+        g.mode = 1; g.gH = H; g.gW = W; g.sH = OH; g.sW = OW; g.sC = Cout; g.a = 1; g.b = pad; g.d = -dil; g.qs = qs;
+        g.btap = Cout; g.bcol = Cin;
+        a_kc = true; b_kc = false;
+    } else {                  // A = dy^T (m = co contiguous), B = x gathered over output pixels, n = (tap, c)
+        a.A = (const unsigned short*)src; a.B = (const unsigned short*)other;
+        a.lda = Cout; a.ldb = Cin; a.sAo = y_slice; a.sBo = x_slice;
+        a.extA = (unsigned)(2 * y_slice); a.extB = (unsigned)(2 * x_slice);
+        g.mode = 2; g.gH = OH; g.gW = OW; g.sH = H; g.sW = W; g.sC = Cin; g.a = stride; g.b = -pad; g.d = dil; g.qs = 0;
+        a_kc = false; b_kc = false;
     }
-    IX_CHECK_ARG(nbatch <= 65535 && a.split <= 65535, "ix_gemm_b16: too many batch slices");
-    const dim3 grid(a.tiles_m * a.tiles_n, nbatch, a.split);
-    const double bytes = 2.0 * ((double)M * K + (double)K * N) * nbatch + (c_f32 ? 4.0 : 2.0) * (double)M * N * nbatch;
-    ix_prof_begin_b16(stream, M, N, K, nbatch, bytes);
-#define G16_LAUNCH(AK, BK_, F)                                                                           \
-    hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F>), grid, dim3(256), 0, stream, a)
-    const bool f = c_f32 != 0;
-    if (a_kcontig && b_kcontig) { if (f) G16_LAUNCH(true, true, true); else G16_LAUNCH(true, true, false); }
-    else if (a_kcontig && !b_kcontig) { if (f) G16_LAUNCH(true, false, true); else G16_LAUNCH(true, false, false); }
-    else if (!a_kcontig && b_kcontig) { if (f) G16_LAUNCH(false, true, true); else G16_LAUNCH(false, true, false); }
-    else { if (f) G16_LAUNCH(false, false, true); else G16_LAUNCH(false, false, false); }
-#undef G16_LAUNCH
-    if (a.planes) {
-        const int64_t work = (int64_t)nbatch * M * (N / 4);
-        const int g = ix_grid_1d(work, 256);
-        if (f) hipLaunchKernelGGL(gemm16_reduce_kernel<true>, dim3(g), dim3(256), 0, stream, a, nbatch);
-        else hipLaunchKernelGGL(gemm16_reduce_kernel<false>, dim3(g), dim3(256), 0, stream, a, nbatch);
-    }
-    ix_prof_end(stream);
-    IX_CHECK_LAUNCH("ix_gemm_b16");
-    return IX_OK;
+    g.dW = g16_make_div((unsigned)g.gW); g.dHW = g16_make_div((unsigned)(g.gH * g.gW)); g.dC = g16_make_div((unsigned)g.sC);
+    return g16_run(a, a_kc, b_kc, c_f32 != 0, groups, workspace, workspace_bytes, stream, "ix_conv_gemm_b16");
 }
 
 // ---- dtype conversion passes (HBM-bound: 6 bytes per element) -----------------------------------------------------------------

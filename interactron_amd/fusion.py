@@ -113,7 +113,13 @@ def _like(t, ref):
 def _token_inputs(mod, x):
     img = mod.img_feature_embedding(x["embedded_memory_features"].permute(0, 1, 3, 4, 2))
     bf = x["box_features"]
-    preds = torch.cat((bf, _like(x["pred_logits"], bf), _like(x["pred_boxes"], bf)), dim=-1)
+    if bf.dtype == torch.bfloat16:
+        # 16-bit mode: the prediction embedding reads the detector's fp32 logits (|logit| up to ~10: bf16 would round them by 0.02-0.04)
+        # and is tiny (50 rows per frame) -- it runs fp32-grade, its output joins the bf16 token sequence
+        from . import b16
+        preds = torch.cat((b16.to_f32(bf), x["pred_logits"], x["pred_boxes"]), dim=-1)
+        return img, b16.to_b16(mod.prediction_embedding(preds))
+    preds = torch.cat((bf, x["pred_logits"], x["pred_boxes"]), dim=-1)
     return img, mod.prediction_embedding(preds)
 
 

@@ -86,11 +86,14 @@ class Function(_TorchFunction):
     adapted call come back as bf16 (True: all; False: none -- reductions to scalars, parameter gradients; or one flag per output)."""
     b16 = "adapt"
     b16_out = True
+    b16_twin = None   # a subclass with the same backward whose forward launches the 16-bit kernels (b16.py): calls with bf16 tensors go there
 
     @classmethod
     def apply(cls, *args):
         if _b16_seen[0] and cls.b16 != "native" and _any_b16(args):
             from . import b16
+            if cls.b16_twin is not None:
+                return cls.b16_twin.apply(*args)
             return b16.adapt(cls, args, lambda up: super(Function, cls).apply(*up))
         return super().apply(*args)
 
@@ -100,6 +103,8 @@ class Function(_TorchFunction):
             return cls.apply(*args)
         if _b16_seen[0] and cls.b16 != "native" and _any_b16(args):
             from . import b16
+            if cls.b16_twin is not None:
+                return cls.b16_twin.forward(_NullCtx(), *args)
             return b16.adapt(cls, args, lambda up: cls.forward(_NullCtx(), *up))
         return cls.forward(_NullCtx(), *args)
 

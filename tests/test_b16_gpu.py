@@ -19,6 +19,15 @@ def lib():
     return _lib.load()
 
 
+@pytest.fixture(params=[1, 2])
+def stages(request, lib):
+    """every bf16 GEMM test runs on both forms of the kernel: one LDS stage / four workgroups per CU, and two stages with the next K
+    step's DMA in flight (ix_gemm_b16_set_stages)"""
+    old = lib.ix_gemm_b16_set_stages(request.param)
+    yield request.param
+    lib.ix_gemm_b16_set_stages(old)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
@@ -42,7 +51,7 @@ def gemm_b16(lib, A, B, M, N, K, a_kc, b_kc, lda, ldb, bo=1, bi=1, sA=(0, 0), sB
 
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 136), (1000, 260, 1496), (64, 2048, 256), (333 * 8, 132, 72)])
-def test_bf16_gemm_layouts_and_tails_against_float64(lib, a_kc, b_kc, M, N, K):
+def test_bf16_gemm_layouts_and_tails_against_float64(lib, stages, a_kc, b_kc, M, N, K):
     """All four operand layouts (what forward, input gradient and weight gradient of a Linear present), ragged M / N / K (K tails
     inside and across 16-byte chunks of the m-contiguous layouts, N = 4 (mod 8)), leading dimensions larger than the rows."""
     lda = (K if a_kc else M) + 8
@@ -64,7 +73,7 @@ def test_bf16_gemm_layouts_and_tails_against_float64(lib, a_kc, b_kc, M, N, K):
     assert float((errb / (ref.abs() * 2.0 ** -8 + bound * 4e-7)).max()) <= 1.0   # one bf16 rounding of the result
 
 
-def test_bf16_gemm_batches_bias_affine_residual_and_activations(lib):
+def test_bf16_gemm_batches_bias_affine_residual_and_activations(lib, stages):
     """Outer / inner batch strides (episode-batched weights: one B per outer slice), per-slice bias, the frozen-BN affine + residual +
     ReLU epilogue of the backbone, and GELU (models/gpt.py:70-75) -- against float64 of the same formula."""
     bo, bi, M, N, K = 3, 2, 150, 136, 200
@@ -89,7 +98,7 @@ def test_bf16_gemm_batches_bias_affine_residual_and_activations(lib):
                 assert bool(((C.double().cpu() - ref).abs() <= tol).all()), (act, use_res, c_f32, float((C.double().cpu() - ref).abs().max()))
 
 
-def test_bf16_gemm_split_k_is_ordered_and_equals_one_pass(lib):
+def test_bf16_gemm_split_k_is_ordered_and_equals_one_pass(lib, stages):
     """The weight-gradient shape: a small output with a long K (dW = dY^T X, both operands m / n-contiguous).  With a workspace the
     launch is cut along K into fp32 planes that are added in order (two runs: identical bits); without one it runs as a single pass --
     the same fp32 sums in another order."""
@@ -126,3 +135,131 @@ def test_casts_round_to_nearest_even(lib):
     z = torch.empty(100003, device="cuda")
     assert lib.ix_cast_b16_f32(y.data_ptr(), z.data_ptr(), y.numel(), st) == 0
     assert torch.equal(z, y.float())
+
+
+# ---- the elementwise / channel / LayerNorm twins (csrc/ew16.hip through b16.py) against the fp32 Functions on the same values --------
+def _close16(got, ref32, what, extra=0.0):
+    """a bf16 result against the fp32 kernel's result on the same (bf16-valued) inputs: one rounding apart"""
+    assert got.dtype == torch.bfloat16, what
+    err = (got.float() - ref32).abs()
+    tol = ref32.abs() * 2.0 ** -8 + 1e-30 + extra
+    assert bool((err <= tol).all()), (what, float((err - tol).max()))
+
+
+def test_elementwise_twins_equal_the_fp32_functions_rounded_once(lib):
+    from interactron_amd import b16, hipops as ops
+    n = 3 * 1000 * 256 + 5    # (a ragged tail behind the 16-byte bulk)
+    x, y, z = rnd(n, seed=1).cuda(), rnd(n, seed=2).cuda(), rnd(n, seed=3).cuda()
+    f = lambda t: t.float()
+    seed = 0x1234567
+    cases = [
+        ("add", ops.Axpby, (x, y, 1.0, 1.0)), ("axpby", ops.Axpby, (x, y, 0.5, -2.0)), ("scale", ops.Scale, (x, 0.37)),
+        ("relu", ops.Relu, (x,)), ("relu_bwd", ops.ReluBwd, (x, y)), ("relu_bwd_sum", ops.ReluBwdSum, (x, y, z)),
+        ("relu_bwd_scaled", ops.ReluBwdScaled, (x, y, 1.0 / 0.9)), ("gelu", ops.Gelu, (x,)), ("gelu_bwd", ops.GeluBwd, (x, y)),
+        ("dropout", ops._Dropout, (x, 0.1, seed)), ("relu_dropout", ops.ReluDropout, (x, 0.1, seed)),
+        ("add_dropout", ops.AddDropout, (x, y, 0.1, seed)), ("sum_n", ops.SumN, (x, y, z, x, y)),
+    ]
+    with torch.no_grad():
+        for name, fn, args in cases:
+            got = fn.call(*args)
+            ref = fn.call(*[f(a) if torch.is_tensor(a) else a for a in args])
+            # (FMA contraction may differ by an fp32 ulp before the rounding: 2e-7 of the value on top of the bf16 half-ulp)
+            _close16(got, ref, name, extra=4e-7 * float(ref.abs().max()))
+            if "dropout" in name:   # the SAME mask: zeros in the same places
+                assert torch.equal(got == 0, ref == 0), name
+    assert ops.Relu.b16_twin is b16.Relu16
+
+
+def test_channel_twins_and_bias_gradient_column_sums(lib):
+    from interactron_amd import hipops as ops
+    rows, C = 3000, 256
+    x, y = rnd(rows, C, seed=4).cuda(), rnd(rows, C, seed=5).cuda()
+    g = torch.Generator().manual_seed(6)
+    scale, shift = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    with torch.no_grad():
+        for relu in (False, True):
+            for res in (None, y):
+                got = ops.BnAct.call(x, scale, shift, res, relu)
+                ref = ops.BnAct.call(x.float(), scale, shift, None if res is None else res.float(), relu)
+                _close16(got, ref, "bn_act", extra=4e-7 * float(ref.abs().max()))
+        _close16(ops.ChannelScale.call(x, scale), ops.ChannelScale.call(x.float(), scale), "channel_scale")
+        _close16(ops.ReluBwdChannelScale.call(x, y, scale), ops.ReluBwdChannelScale.call(x.float(), y.float(), scale), "relu_bwd_channel_scale")
+        v = torch.randn(4, C * 2, generator=g).cuda()   # one row vector per slab of 25 rows
+        a = rnd(4 * 25, C * 2, seed=7).cuda()
+        _close16(ops.AddRowVec.call(a, v, 4), ops.AddRowVec.call(a.float(), v, 4), "add_rowvec", extra=1e-6)
+        cs = ops.ColSum.call(x)
+        assert cs.dtype == torch.float32
+        ref = x.double().sum(0).cpu()
+        assert float((cs.double().cpu() - ref).abs().max()) <= 1e-5 * float(x.double().abs().sum(0).max())
+        cs3 = ops.ColSum.call(x.reshape(3, 1000, C))
+        assert float((cs3.double().cpu() - x.double().reshape(3, 1000, C).sum(1).cpu()).abs().max()) <= 1e-5 * float(x.double().abs().sum(0).max())
+        assert torch.equal(cs, ops.ColSum.call(x))   # ordered partial sums: the same bits every time
+
+
+@pytest.mark.parametrize("D", [256, 512])
+def test_layernorm_twin_forward_and_first_derivative(lib, D):
+    """nn.LayerNorm (models/gpt.py:60-78, models/detr_models/transformer.py:148-232) on bf16 rows: output and dx one rounding from the
+    fp32 kernels' on the same values, fp32 parameter gradients to 1e-4 of their scale, statistics fp32."""
+    from interactron_amd import hipops as ops
+    rows = 4133
+    x = (rnd(rows, D, seed=8) * 3 + 0.5).cuda()
+    g = torch.Generator().manual_seed(9)
+    gamma, beta = (torch.rand(D, generator=g) + 0.5).cuda(), torch.randn(D, generator=g).cuda()
+    dy = rnd(rows, D, seed=10).cuda()
+
+    def run(xx, dd):
+        xx = xx.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        yy = ops.layer_norm(xx, ga, be)
+        yy.backward(dd)
+        return yy.detach(), xx.grad, ga.grad, be.grad
+
+    y16, dx16, dg16, db16 = run(x, dy)
+    y32, dx32, dg32, db32 = run(x.float(), dy.float())
+    assert dx16.dtype == torch.bfloat16 and dg16.dtype == torch.float32 and db16.dtype == torch.float32
+    _close16(y16, y32, "ln forward", extra=2e-6 * float(y32.abs().max()))
+    _close16(dx16, dx32, "ln dx", extra=2e-6 * float(dx32.abs().max()))
+    for a, b, nm in ((dg16, dg32, "dgamma"), (db16, db32, "dbeta")):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), nm
+
+
+@pytest.mark.parametrize("geom", [  # (n, H, W, Cin, Cout, k, stride, pad, dil, residual)
+    (3, 19, 19, 256, 256, 3, 1, 1, 1, False),     # layer3 conv2
+    (2, 38, 37, 128, 128, 3, 2, 1, 1, False),     # layer2.0 conv2: stride on the 3 x 3, odd width
+    (2, 19, 19, 512, 512, 3, 1, 2, 2, False),     # layer4 conv2: dilation 2
+    (2, 38, 38, 256, 512, 1, 2, 0, 1, False),     # strided 1 x 1 downsample
+    (5, 10, 10, 128, 256, 1, 1, 0, 1, True),      # plain 1 x 1 + residual (the bf16 GEMM's own epilogue)
+])
+def test_bf16_convolutions_forward_and_both_gradients(lib, stages, geom):
+    """The implicit-GEMM convolution kinds of the 16-bit mode (ix_conv_gemm_b16: forward with the frozen-BN affine + ReLU in the store,
+    data gradient, weight gradient; reference backbone.py:88-90 bottlenecks) against the fp32 path on the SAME bf16-valued inputs:
+    outputs and dx one bf16 rounding (of an accumulated value) apart, the fp32 weight gradient within 5e-3 of its scale."""
+    from interactron_amd import b16, hipops as ops
+    n, H, W, Cin, Cout, k, stride, pad, dil, use_res = geom
+    g = torch.Generator().manual_seed(11)
+    x = rnd(n, H, W, Cin, seed=12).cuda()
+    w = (torch.randn(Cout, k, k, Cin, generator=g) * (2.0 / (k * k * Cin)) ** 0.5).cuda()
+    scale, shift = (torch.rand(Cout, generator=g) + 0.5).cuda(), (torch.randn(Cout, generator=g) * 0.1).cuda()
+    OH, OW = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = rnd(n, OH, OW, Cout, seed=13).cuda() if use_res else None
+    dy = rnd(n, OH, OW, Cout, seed=14).cuda()
+    before = b16._stats["native_gemms"]
+
+    def run(xx, rr, dd, ww):
+        xx = xx.clone().requires_grad_(True)
+        ww = ww.clone().requires_grad_(True)
+        yy = ops.conv2d_nhwc_bn_act(xx, ww, scale, shift, rr, True, stride, pad, dil)
+        yy.backward(dd)
+        return yy.detach(), xx.grad, ww.grad
+
+    y16, dx16, dw16 = run(x, res, dy, w)
+    assert b16._stats["native_gemms"] >= before + 3, "the bf16 kernels did not run"
+    # the fp32 reference multiplies the SAME bf16-rounded weights
+    y32, dx32, dw32 = run(x.float(), None if res is None else res.float(), dy.float(), w.to(torch.bfloat16).float())
+    assert y16.dtype == torch.bfloat16 and dx16.dtype == torch.bfloat16 and dw16.dtype == torch.float32
+    # (dx additionally carries the bf16 rounding of the ReLU-masked gradient and, behind a residual, of the BN-scaled weights)
+    for a, b, what in ((y16, y32, "y"), (dx16, dx32, "dx")):
+        err = (a.float() - b).abs()
+        tol = b.abs() * 2.0 ** -7 + (2e-3 if what == "y" else 6e-3) * float(b.abs().max())
+        assert bool((err <= tol).all()), (what, float(err.max()), float(b.abs().max()))
+    assert float((dw16 - dw32).abs().max()) <= 5e-3 * float(dw32.abs().max()), float((dw16 - dw32).abs().max()) / float(dw32.abs().max())

@@ -30,8 +30,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--stages", type=int, default=0, help="1 / 2: force the kernel form (ix_gemm_b16_set_stages); 0: the library's default")
     args = ap.parse_args()
     lib = _lib.load()
+    if args.stages:
+        lib.ix_gemm_b16_set_stages(args.stages)
     st = torch.cuda.current_stream().cuda_stream
     ws = torch.zeros(512 << 20, dtype=torch.uint8, device="cuda")
     rows_out, tot = [], {"fwd": [0.0, 0.0], "dx": [0.0, 0.0], "dw": [0.0, 0.0]}
