@@ -598,6 +598,8 @@ def main():
     ap.add_argument("--stress-steps", type=int, default=2,
                     help="timed steps of the `stress` sub-measurement (BASELINE.json configs[4]: 1600 long edge, 200 queries, fp8 MFMA "
                          "attention forward; one episode per step, after two warm-up steps; 0 = skip it)")
+    ap.add_argument("--bf16-steps", type=int, default=10,
+                    help="timed steps of the `bf16_mode` sub-measurement (multi_frame_baseline in fp32-grade and in the 16-bit activation mode; 0 = skip it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-two-frame", action="store_true", help="skip the two-frame 800 x 800 CPU / HIP pair of the north-star object (~ 40 s)")
     ap.add_argument("--no-roofline", action="store_true")
@@ -651,6 +653,29 @@ def main():
     inner5 = None
     if headline_cfg and world == 1 and args.inner5_episodes > 0:
         inner5 = run_workload(args, 300, args.inner5_episodes, args.inner5_episodes, 3, 2, ctx, False, "bench", inner_steps=5)   # (2 warm-up steps: eager, then the capture)
+    # BASELINE.json configs[1] "multi_frame_baseline ... 1 x MI355X bf16": the 16-bit ACTIVATION mode (b16.py) on that configuration's
+    # training step, next to the same step in fp32-grade arithmetic -- its own sub-line with its own dtype, never the headline
+    b16_line = None
+    if headline_cfg and world == 1 and args.bf16_steps > 0:
+        import copy
+        sub = copy.copy(args)
+        sub.config, sub.mode = "multi_frame_baseline", "train"
+        pair = {}
+        for dt in ("f32", "bf16"):
+            sub.compute_dtype = dt
+            r = run_workload(sub, 300, 16, 16, args.bf16_steps, 3, ctx, dt == "bf16" and not args.no_roofline, "bench-mfb")
+            pair[dt] = {"value": r["frames_per_s"], "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": args.bf16_steps, "warmup": 3,
+                        "peak_memory_GB": r["peak_memory_GB"]}
+            if dt == "bf16" and r["roofline"]:
+                pair[dt]["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                                           "launches_per_step", "kernel_ms_per_step", "gflop_per_step",
+                                                                           "avg_launch_us", "bf16_gemm", "fp32_on_16bit_kernels")}
+                pair[dt]["attention_ms_per_step"] = r["roofline"]["attention_kernels"]["kernel_ms_per_step"]
+        b16_line = {"workload": "configs/multi_frame_baseline.yaml training step (detr_multiframe.forward + clip + Adam), 16 episodes/GPU x 5 frames x "
+                                "3x300x300, Q=50, fusion T=2060, procedural weights, train mode",
+                    "dtype": "bf16 (activations stored as bf16, bf16 matrix instructions with LDS-DMA operands, fp32 accumulation / statistics / "
+                             "parameters; parity at SURVEY 8d's bf16 row: tests/test_parity_gpu.py::test_config2_multiframe_bf16_activations)",
+                    "f32": pair["f32"], "bf16": pair["bf16"], "speedup_over_f32": pair["bf16"]["value"] / pair["f32"]["value"]}
     # BASELINE.json configs[4], the bandwidth-bound stress configuration: 1600 x 1600 frames, 200 queries (T = 51 005), the two
     # forward attention products on OCP e4m3 MFMA (the derivative passes stay fp32-grade: DESIGN.md 4.2a), one episode per step
     stress = None
@@ -732,6 +757,7 @@ def main():
                         "value": stress["frames_per_s"], "unit": "frames/s", "steps": args.stress_steps, "warmup": 2,
                         "ms_per_step": stress["ms_per_step"], "peak_memory_GB": stress["peak_memory_GB"], "attention_dtype": "fp8 (forward)",
                         "step_graphs": stress["step_graphs"]}),
+            "bf16_mode": b16_line,
             "inner5": ({"workload": "%d episodes/GPU x 5 frames x 3x300x300, MODEL.INNER_STEPS = 5 (BASELINE.json north_star's 5-step adapt loop; "
                                     "the reference and the headline take 1 step)" % args.inner5_episodes, "inner_steps": 5,
                         "episodes_per_gpu": args.inner5_episodes, "steps": 3, "warmup": 2, "ms_per_step": inner5["ms_per_step"],

@@ -492,6 +492,16 @@ int ix_layernorm_bwd_b16(const void* dy, const void* x, const float* gamma, cons
 int ix_workspace_bytes_colsum_b16(int64_t rows, int C, int groups, size_t* out_host);
 int ix_colsum_b16(const void* x, float* out, int64_t rows, int C, int groups, void* workspace, size_t workspace_bytes,
                   ix_stream_t stream); /* [G][rows][C] bf16 -> [G][C] fp32 (bias gradients), ordered partial sums; C % 8 == 0 */
+/*   attention in the mode: ix_attn_split_multi_b16 / ix_attn_split_dot_b16 write the kernels' operand planes from bf16 q / k / v / dO
+ *                   (every bf16 value fits the h plane; dot operand y fp32), and ix_flash_set_single_term(1) sends the head-dim-64
+ *                   passes of ix_flash_fwd_f32 / ix_flash_bwd_f32 / ix_flash_bwd_bwd_f32 to their single-term build (one matrix
+ *                   instruction per k-slice instead of three; [L, S] intermediates rounded once to fp16); returns the old setting */
+int ix_attn_split_multi_b16(int count, const void* const* x, void* const* row_planes, float* const* row_unscale, void* const* tr_planes,
+                            int tr_form, int n, const int* R, const int* Rp, const int64_t* ld, const int* off, int H, int hd,
+                            ix_stream_t stream);
+int ix_attn_split_dot_b16(const void* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R, int Rp,
+                          int64_t ld, int off, int H, int hd, const float* y, int64_t ldy, int offy, float* t, ix_stream_t stream);
+int ix_flash_set_single_term(int on);
 int ix_cast_f32_b16(const float* x, void* y, int64_t n, ix_stream_t stream);
 int ix_cast_b16_f32(const void* x, float* y, int64_t n, ix_stream_t stream);
 int ix_prof_b16(double* ms, double* flops, double* bytes, int64_t* launches);

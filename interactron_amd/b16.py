@@ -17,11 +17,15 @@ Nothing here falls back to ATen or to the CPU: the conversions are HIP kernels o
 import ctypes
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import hipops as ops
 from ._lib import HipLibraryError
 
+import os
+
 B16 = torch.bfloat16
+STEM_LAYER1 = os.environ.get("IX_B16_STEM", "1") == "1"   # "0": the frozen layer1 stays on the fp32 kernels, the cast follows it (A/B runs)
 _seen = ops._b16_seen   # [False] until this module is imported -- by the first model that runs in the mode, or by a test: the fp32 path's
 _seen[0] = True         # per-call cost stays at one list read in processes that never use 16-bit activations
 
@@ -588,3 +592,54 @@ class ConvFwdBnAct16(ops.ConvFwdBnAct):
         ctx.cg, ctx.relu, ctx.has_res = cg, relu, residual is not None
         ctx.save_for_backward(x, w, scale, out if relu else None)
         return out if fan == 1 else (out, out.view_as(out))
+
+
+# ---- attention in the mode: bf16 q / k / v / dO into the flash kernels' planes, head dim 64 on the single-term passes -------------------
+class _single_term:
+    """the head-dim-64 passes of csrc/flash16.hip in their single-term build for the duration of one launch sequence (operands that are
+    16-bit values fit the h plane exactly: one matrix instruction per k-slice instead of three)"""
+
+    def __enter__(self):
+        self.old = ops._L().ix_flash_set_single_term(1)
+        return self
+
+    def __exit__(self, *exc):
+        ops._L().ix_flash_set_single_term(self.old)
+        return False
+
+
+@_twin(ops.FlashAttention)
+class FlashAttention16(ops.FlashAttention):
+    @staticmethod
+    def forward(ctx, q, k, v, g, mask, p, seed):
+        done = {}
+        for t in (q, k, v):
+            if id(t) not in done:
+                done[id(t)] = _c16(t)
+        q, k, v = done[id(q)], done[id(k)], done[id(v)]
+        with _single_term():
+            out = ops.FlashAttention._forward(ctx, q, k, v, g, mask, p, seed)   # (saves q, k, v, the fp32 output and lse)
+        return cast_b16(out)
+
+
+@_twin(ops.FlashAttentionBwd)
+class FlashAttentionBwd16(ops.FlashAttentionBwd):
+    @staticmethod
+    def forward(ctx, q, k, v, out, lse, do, g, p, seed, pl, same_qk):
+        do = _c16(do)
+        with _single_term():
+            gq, gk, gv = ops.FlashAttentionBwd._forward(ctx, q, k, v, ops._req(out), lse, do, g, p, seed, pl, same_qk)
+        return tuple(cast_b16(t) if t is not None else None for t in (gq, gk, gv))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hq, hk, hv):
+        """double backward (the MAML meta-gradient in the mode): bf16 cotangents into the same three passes"""
+        q, k, v = ctx.saved_tensors[:3]
+        prep = lambda h, ref: _c16(h.contiguous()) if h is not None else torch.zeros(ref.shape, dtype=B16, device=ref.device)
+        hq = prep(hq, q)
+        hk = hq if ctx.same_qk[0] else prep(hk, k)
+        hv = hq if ctx.same_qk[1] else prep(hv, v)
+        with _single_term():
+            outs = ops.FlashAttentionBwd._backward_impl(ctx, hq, hk, hv)
+        return tuple(cast_b16(t) if torch.is_tensor(t) else t for t in outs)

@@ -64,7 +64,8 @@ struct SplitOps {
     SplitOp op[3];
 };
 
-template <int HD>
+// IN16: the operand is bf16 in HBM (the 16-bit activation mode: every value fits the h plane exactly, the l plane is zero)
+template <int HD, bool IN16 = false>
 __global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, int tr_form) {
     const SplitOp& o = ops.op[blockIdx.z];
     if ((int)blockIdx.x * 32 >= o.Rp) return;
@@ -83,12 +84,23 @@ __global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, in
     const int row = tid / TPR, c0 = (tid % TPR) * EPT;
     float v[EPT];
     const bool in = r0 + row < R;
-    const float* src = X + ((int64_t)b * R + r0 + row) * ld + off + h * HD + c0;
+    if (IN16) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(X) + ((int64_t)b * R + r0 + row) * ld + off + h * HD + c0;
 #pragma unroll
-    for (int i = 0; i < EPT; i += 4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) t = *reinterpret_cast<const float4*>(src + i);
-        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        for (int i = 0; i < EPT; i += 4) {
+            uint2 t = make_uint2(0u, 0u);
+            if (in) t = *reinterpret_cast<const uint2*>(src + i);
+            v[i] = __uint_as_float(t.x << 16); v[i + 1] = __uint_as_float(t.x & 0xffff0000u);
+            v[i + 2] = __uint_as_float(t.y << 16); v[i + 3] = __uint_as_float(t.y & 0xffff0000u);
+        }
+    } else {
+        const float* src = X + ((int64_t)b * R + r0 + row) * ld + off + h * HD + c0;
+#pragma unroll
+        for (int i = 0; i < EPT; i += 4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) t = *reinterpret_cast<const float4*>(src + i);
+            v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        }
     }
     if (o.dot_y) {   // (block-uniform) the TPR threads of a row are consecutive lanes: partial dot products, then a butterfly
         float d = 0.f;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_split_kernel(SplitOps ops, int H, in
 static int fl_split_launch(const char* who, int count, const float* const* x, void* const* row_planes, float* const* unscale,
                            void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
                            const int* off, int H, int hd, hipStream_t stream, const float* dot_y = nullptr, int64_t dot_ld = 0,
-                           int dot_off = 0, float* dot_out = nullptr) {
+                           int dot_off = 0, float* dot_out = nullptr, bool in16 = false) {
     IX_CHECK_ARG(count >= 1 && count <= 3, "%s: %d operands (1..3)", who, count);
     IX_CHECK_ARG(tr_form == 0 || tr_form == 1, "%s: tr_form %d (0 = three bf16 planes, 1 = two fp16 planes)", who, tr_form);
     IX_CHECK_ARG(hd == 32 || hd == 64, "%s: head dim %d (32 or 64)", who, hd);
@@ -183,7 +195,10 @@ static int fl_split_launch(const char* who, int count, const float* const* x, vo
         ops.op[0].dot_y = dot_y; ops.op[0].dot_out = dot_out; ops.op[0].dot_ld = dot_ld; ops.op[0].dot_off = dot_off;
     }
     dim3 grid(maxRp / 32, n * H, count);
-    if (hd == 64)
+    if (in16) {
+        if (hd == 64) hipLaunchKernelGGL((attn_split_kernel<64, true>), grid, dim3(256), 0, stream, ops, H, tr_form);
+        else hipLaunchKernelGGL((attn_split_kernel<32, true>), grid, dim3(256), 0, stream, ops, H, tr_form);
+    } else if (hd == 64)
         hipLaunchKernelGGL(attn_split_kernel<64>, grid, dim3(256), 0, stream, ops, H, tr_form);
     else
         hipLaunchKernelGGL(attn_split_kernel<32>, grid, dim3(256), 0, stream, ops, H, tr_form);
@@ -217,6 +232,26 @@ extern "C" int ix_attn_split_multi_f32(int count, const float* const* x, void* c
     IX_CHECK_ARG(x && row_planes && row_unscale && tr_planes && R && Rp && ld && off, "ix_attn_split_multi_f32: null array");
     return fl_split_launch("ix_attn_split_multi_f32", count, x, row_planes, row_unscale, tr_planes, tr_form, n, R, Rp, ld, off, H, hd,
                            stream);
+}
+
+// ... and for bf16 operands (the 16-bit activation mode): x points to 2-byte elements, ld / off in elements (multiples of 4); the dot
+// operand y of the single-operand form stays fp32 (the attention output as the forward kernel wrote it)
+extern "C" int ix_attn_split_multi_b16(int count, const void* const* x, void* const* row_planes, float* const* row_unscale,
+                                       void* const* tr_planes, int tr_form, int n, const int* R, const int* Rp, const int64_t* ld,
+                                       const int* off, int H, int hd, hipStream_t stream) {
+    if (n <= 0 || count <= 0) return IX_OK;
+    IX_CHECK_ARG(x && row_planes && row_unscale && tr_planes && R && Rp && ld && off, "ix_attn_split_multi_b16: null array");
+    return fl_split_launch("ix_attn_split_multi_b16", count, reinterpret_cast<const float* const*>(x), row_planes, row_unscale, tr_planes,
+                           tr_form, n, R, Rp, ld, off, H, hd, stream, nullptr, 0, 0, nullptr, true);
+}
+extern "C" int ix_attn_split_dot_b16(const void* x, void* row_planes, float* row_unscale, void* tr_planes, int tr_form, int n, int R,
+                                     int Rp, int64_t ld, int off, int H, int hd, const float* y, int64_t ldy, int offy, float* t,
+                                     hipStream_t stream) {
+    if (n <= 0 || R <= 0) return IX_OK;
+    IX_CHECK_ARG(y && t, "ix_attn_split_dot_b16: null dot operand / output");
+    const float* xf = reinterpret_cast<const float*>(x);
+    return fl_split_launch("ix_attn_split_dot_b16", 1, &xf, &row_planes, &row_unscale, &tr_planes, tr_form, n, &R, &Rp, &ld, &off, H, hd,
+                           stream, y, ldy, offy, t, true);
 }
 
 // additive key bias [n][Sp]: 0 for a valid key, -inf for a padded (mask != 0) key and for the tail S..Sp
@@ -1129,6 +1164,20 @@ void fl16_launch_bwd_kv(const FlashArgs& a, dim3 grid, hipStream_t stream);
 void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream);
 void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream);
 void fl16_launch_bb_kv(const FlashArgs& a, dim3 grid, hipStream_t stream);
+// ... and their single-term twins (flash16.hip built with -DM16_ONE): the h planes only, for operands that are 16-bit values (the
+// 16-bit activation mode).  ix_flash_set_single_term(1) routes the head-dim-64 fp16-form passes there; returns the previous setting.
+void fl16_launch_fwd_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bwd_q_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bwd_kv_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_stats_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_q_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+void fl16_launch_bb_kv_one(const FlashArgs& a, dim3 grid, hipStream_t stream);
+static int g_fl_one = 0;
+extern "C" int ix_flash_set_single_term(int on) {
+    const int old = g_fl_one;
+    if (on == 0 || on == 1) g_fl_one = on;
+    return old;
+}
 static int fl_m16_default() {
     const char* e = getenv("IX_FLASH_M16");
     return !(e && e[0] == '0');
@@ -1207,7 +1256,7 @@ extern "C" int ix_flash_fwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     }
     ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (1 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 1);
     if (m16) {
-        fl16_launch_fwd(a, grid, stream);
+        if (g_fl_one) fl16_launch_fwd_one(a, grid, stream); else fl16_launch_fwd(a, grid, stream);
     } else if (hd == 64) {
         if (form == 1) { FL_DISPATCH_FWD(64, 2) } else { FL_DISPATCH_FWD(64, 3) }
     } else {
@@ -1248,14 +1297,14 @@ extern "C" int ix_flash_bwd_f32(const ix_attn_planes* q, const ix_attn_planes* k
     if (gq) {   // S, gd, gQ
         dim3 grid((L + 127) / 128, n * H);
         ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 1 * FL_S2(form)) * FL_PRODUCT_FLOPS, 2);
-        if (m16) fl16_launch_bwd_q(a, grid, stream);
+        if (m16) { if (g_fl_one) fl16_launch_bwd_q_one(a, grid, stream); else fl16_launch_bwd_q(a, grid, stream); }
         else { FL_DISPATCH(flash_bwd_q_kernel, grid, form) }
         ix_prof_end(stream);
     }
     if (gk && gv) {   // S, gd, gK, gV
         dim3 grid((S + 127) / 128, n * H);
         ix_prof_begin(stream, 2, 2.0 * FL_PRODUCT_FLOPS, (2 * 3 + 2 * FL_S2(form)) * FL_PRODUCT_FLOPS, 3);
-        if (m16) fl16_launch_bwd_kv(a, grid, stream);
+        if (m16) { if (g_fl_one) fl16_launch_bwd_kv_one(a, grid, stream); else fl16_launch_bwd_kv(a, grid, stream); }
         else { FL_DISPATCH(flash_bwd_kv_kernel, grid, form) }
         ix_prof_end(stream);
     }
@@ -1315,13 +1364,13 @@ extern "C" int ix_flash_bwd_bwd_f32(const ix_attn_planes* q, const ix_attn_plane
 #define FL_BB_LAUNCH(HD_, DR_) if (form == 1) { FL_BB_LAUNCH2(HD_, DR_, 2) } else { FL_BB_LAUNCH2(HD_, DR_, 3) }
     if (m16) {
         ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3) * FL_PRODUCT_FLOPS, 4);
-        fl16_launch_bb_stats(a, gq, stream);
+        if (g_fl_one) fl16_launch_bb_stats_one(a, gq, stream); else fl16_launch_bb_stats(a, gq, stream);
         ix_prof_end(stream);
         ix_prof_begin(stream, 2, 4.0 * FL_PRODUCT_FLOPS, (5 * 3 + 4 * 3) * FL_PRODUCT_FLOPS, 5);
-        fl16_launch_bb_q(a, gq, stream);
+        if (g_fl_one) fl16_launch_bb_q_one(a, gq, stream); else fl16_launch_bb_q(a, gq, stream);
         ix_prof_end(stream);
         ix_prof_begin(stream, 2, 3.0 * FL_PRODUCT_FLOPS, (5 * 3 + 3 * 3) * FL_PRODUCT_FLOPS, 6);
-        fl16_launch_bb_kv(a, gk, stream);
+        if (g_fl_one) fl16_launch_bb_kv_one(a, gk, stream); else fl16_launch_bb_kv(a, gk, stream);
         ix_prof_end(stream);
     } else if (hd == 64) {
         if (a.thr16) { FL_BB_LAUNCH(64, true) } else { FL_BB_LAUNCH(64, false) }

@@ -27,6 +27,18 @@
 #include "flash_common.h"
 #include <type_traits>
 
+// Second build of this file (-DM16_ONE, Makefile: flash16_one): ONE matrix instruction per k-slice -- the h planes only -- for operands
+// that ARE 16-bit values (the 16-bit activation mode, b16.py: bf16 q / k / v / dO fit the h plane exactly, the l plane is zero), and the
+// register operands ([L, S] intermediates) rounded once to fp16.  Same kernels under the suffix _one, selected by
+// ix_flash_set_single_term (csrc/flash.hip).  M16_L(...) marks what only serves the l planes.
+#ifdef M16_ONE
+#define M16_L(...)
+#define M16_N(X) X##_one
+#else
+#define M16_L(...) __VA_ARGS__
+#define M16_N(X) X
+#endif
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -159,12 +171,13 @@ __device__ __forceinline__ void m16_stage2_load(M16Tr& a, const unsigned char* o
 __device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, const u32x4 (&bf)[2]) {
     const u32x4 (&ah)[4] = a.h;
     const u32x4 (&al)[4] = a.l;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) acc[db] = m16_mma(al[db], bf[0], acc[db]);
-#pragma unroll
-    for (int db = 0; db < 4; ++db) acc[db] = m16_mma(ah[db], bf[1], acc[db]);
+    M16_L(
+    _Pragma("unroll") for (int db = 0; db < 4; ++db) acc[db] = m16_mma(al[db], bf[0], acc[db]);
+    _Pragma("unroll") for (int db = 0; db < 4; ++db) acc[db] = m16_mma(ah[db], bf[1], acc[db]);
+    )
 #pragma unroll
     for (int db = 0; db < 4; ++db) acc[db] = m16_mma(ah[db], bf[0], acc[db]);
+    (void)al;
 }
 
 // per-thread staging geometry of one operand tile (512 threads: one 16-byte chunk per plane-row-chunk)
@@ -256,7 +269,7 @@ __device__ __forceinline__ void m16_stage2_mma(f32x4 (&acc)[4], const M16Tr& a, 
 // forward: query-owning, streams k (scores) and v (P v, transposed reads); online softmax, one query per lane quadruple
 // ============================================================================================================
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 2) void M16_N(flash16_fwd_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 2 * M16_OPB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
@@ -301,8 +314,8 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
             u32x4 k0f[2], k1f[2];
             M16_AFRAG(k0f, cur, oa, 0)
             M16_AFRAG(k1f, cur, oa, 1)
-            s[0] = m16_mma(k0f[1], qf[ks][0], s[0]); s[1] = m16_mma(k1f[1], qf[ks][0], s[1]);
-            s[0] = m16_mma(k0f[0], qf[ks][1], s[0]); s[1] = m16_mma(k1f[0], qf[ks][1], s[1]);
+            M16_L(s[0] = m16_mma(k0f[1], qf[ks][0], s[0]); s[1] = m16_mma(k1f[1], qf[ks][0], s[1]);
+                  s[0] = m16_mma(k0f[0], qf[ks][1], s[0]); s[1] = m16_mma(k1f[0], qf[ks][1], s[1]);)
             s[0] = m16_mma(k0f[0], qf[ks][0], s[0]); s[1] = m16_mma(k1f[0], qf[ks][0], s[1]);
         }
         M16_TAIL_KEYS(s, t0)
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void flash16_fwd_kernel(FlashArgs p) {
 // backward (algebra in flash.hip): gQ from query-owning workgroups, gK and gV from key-owning ones
 // ============================================================================================================
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 4) void flash16_bwd_q_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 4) void M16_N(flash16_bwd_q_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 2 * M16_OPB;
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
@@ -419,8 +432,8 @@ __global__ __launch_bounds__(512, 4) void flash16_bwd_q_kernel(FlashArgs p) {
                 u32x4 kf[2], vf[2];
                 M16_AFRAG(kf, cur, oa, blk)
                 M16_AFRAG(vf, cur + M16_OPB, oa, blk)
-                s[blk] = m16_mma(kf[1], qf[ks][0], s[blk]); gd[blk] = m16_mma(vf[1], df[ks][0], gd[blk]);
-                s[blk] = m16_mma(kf[0], qf[ks][1], s[blk]); gd[blk] = m16_mma(vf[0], df[ks][1], gd[blk]);
+                M16_L(s[blk] = m16_mma(kf[1], qf[ks][0], s[blk]); gd[blk] = m16_mma(vf[1], df[ks][0], gd[blk]);
+                      s[blk] = m16_mma(kf[0], qf[ks][1], s[blk]); gd[blk] = m16_mma(vf[0], df[ks][1], gd[blk]);)
                 s[blk] = m16_mma(kf[0], qf[ks][0], s[blk]); gd[blk] = m16_mma(vf[0], df[ks][0], gd[blk]);
             }
         }
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(512, 4) void flash16_bwd_q_kernel(FlashArgs p) {
 #define M16_NSLOT 4
 
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 2) void M16_N(flash16_bwd_kv_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 2 * M16_OPB, BUFB = OFF_ST + 256;   // q, dO rows + lse[32], delta[32]
     __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
@@ -510,8 +523,8 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
             u32x4 qa[2], da[2];                                                                              \
             M16_AFRAG(qa, (BUF), oa, blk)                                                                    \
             M16_AFRAG(da, (BUF) + M16_OPB, oa, blk)                                                          \
-            s[blk] = m16_mma(qa[1], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[1], vf[ks][0], gd[blk]);       \
-            s[blk] = m16_mma(qa[0], kf[ks][1], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][1], gd[blk]);       \
+            M16_L(s[blk] = m16_mma(qa[1], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[1], vf[ks][0], gd[blk]);  \
+                  s[blk] = m16_mma(qa[0], kf[ks][1], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][1], gd[blk]);) \
             s[blk] = m16_mma(qa[0], kf[ks][0], s[blk]); gd[blk] = m16_mma(da[0], vf[ks][0], gd[blk]);       \
         }                                                                                                    \
     }
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
             M16_AFRAG(hkf, (BUF) + M16_OPB, oa, blk)                                                         \
             M16_AFRAG(vf, (BUF) + 2 * M16_OPB, oa, blk)                                                      \
             M16_AFRAG(hvf, (BUF) + 3 * M16_OPB, oa, blk)                                                     \
-            B16_TERM(1, 0) B16_TERM(0, 1) B16_TERM(0, 0)                                                     \
+            M16_L(B16_TERM(1, 0) B16_TERM(0, 1)) B16_TERM(0, 0)                                                     \
         }                                                                                                    \
     }
 #define B16_TERM(I, J)                                                                                       \
@@ -652,7 +665,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bwd_kv_kernel(FlashArgs p) {
 // the two masked sums of w share their multiply by pm.  (Four waves per SIMD asked for explicitly: at two the compiler's schedule
 // of this pass sits at 127-129 registers, and 129 would leave one workgroup per CU.)
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 4) void M16_N(flash16_bb_stats_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
@@ -698,7 +711,7 @@ __global__ __launch_bounds__(512, 4) void flash16_bb_stats_kernel(FlashArgs p) {
 
 // (2) dq (o1), ddO (o4): split-phase
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 2) void M16_N(flash16_bb_q_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int BUFB = 4 * M16_OPB;   // k, hk, v, hv rows
     __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_q_kernel(FlashArgs p) {
 
 // (3) dk (o2), dv (o3): split-phase, key-owning
 template <bool DROP, bool BIAS>
-__global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
+__global__ __launch_bounds__(512, 2) void M16_N(flash16_bb_kv_kernel)(FlashArgs p) {
     if (DROP && p.salt) { p.seed_lo ^= p.salt[0]; p.seed_hi ^= p.salt[1]; }
     constexpr int OFF_ST = 3 * M16_OPB, BUFB = OFF_ST + 512;   // q, hq, dO rows + lse, delta, u, w [32] each
     __shared__ __attribute__((aligned(16))) unsigned char lds[M16_NSLOT * BUFB];
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
             M16_AFRAG(qa, (BUF), oa, blk)                                                                    \
             M16_AFRAG(hqa, (BUF) + M16_OPB, oa, blk)                                                         \
             M16_AFRAG(da, (BUF) + 2 * M16_OPB, oa, blk)                                                      \
-            C16_TERM(1, 0) C16_TERM(0, 1) C16_TERM(0, 0)                                                     \
+            M16_L(C16_TERM(1, 0) C16_TERM(0, 1)) C16_TERM(0, 0)                                                     \
         }                                                                                                    \
     }
     C16_LOAD(0)
@@ -936,9 +949,9 @@ __global__ __launch_bounds__(512, 2) void flash16_bb_kv_kernel(FlashArgs p) {
         else hipLaunchKernelGGL((KERNEL<false, false>), GRID, dim3(512), 0, stream, a);                      \
     }
 
-void fl16_launch_fwd(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_fwd_kernel, grid) }
-void fl16_launch_bwd_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_q_kernel, grid) }
-void fl16_launch_bwd_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bwd_kv_kernel, grid) }
-void fl16_launch_bb_stats(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_stats_kernel, grid) }
-void fl16_launch_bb_q(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_q_kernel, grid) }
-void fl16_launch_bb_kv(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(flash16_bb_kv_kernel, grid) }
+void M16_N(fl16_launch_fwd)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_fwd_kernel), grid) }
+void M16_N(fl16_launch_bwd_q)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_bwd_q_kernel), grid) }
+void M16_N(fl16_launch_bwd_kv)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_bwd_kv_kernel), grid) }
+void M16_N(fl16_launch_bb_stats)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_bb_stats_kernel), grid) }
+void M16_N(fl16_launch_bb_q)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_bb_q_kernel), grid) }
+void M16_N(fl16_launch_bb_kv)(const FlashArgs& a, dim3 grid, hipStream_t stream) { M16_LAUNCH(M16_N(flash16_bb_kv_kernel), grid) }

@@ -100,11 +100,12 @@ class ResNet50Body(nn.Module):
             x = ops.linear(cols, w).reshape(n, g.OH, g.OW, 64)
             x = self.bn1(x, relu=True)
             x = ops.maxpool_nhwc(x, 3, 2, 1)
-            x = self.layer1(x)
             if ops.b16_active():   # MODEL.COMPUTE_DTYPE bf16: from here on activations live in HBM as bf16 (b16.py)
                 from . import b16
-                x = b16.cast_b16(x)
-            return x
+                if b16.STEM_LAYER1:   # (layer1 -- frozen, 64 / 256 channels at 1/4 resolution -- on the bf16 kernels as well)
+                    return self.layer1(b16.cast_b16(x))
+                return b16.cast_b16(self.layer1(x))
+            return self.layer1(x)
 
     def forward(self, frames_nchw, stem=None):
         x = stem if stem is not None else self.frozen_stem(frames_nchw)

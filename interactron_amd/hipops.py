@@ -908,7 +908,8 @@ class AttnPlanes:
 def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None, dot=None):
     """fp32 activations [n, R, ld] (head h at columns off + h*hd) -> AttnPlanes (Rp = R rounded up to 128).
     dot = (y, ldy, offy): also t[n*H, Rp] = sum_d x[.., h, d] * y[.., h, d] from the same read of x -> (AttnPlanes, t)."""
-    x = _req(x, "attention operand")
+    in16 = x.dtype == torch.bfloat16   # (16-bit activation mode: the same planes from bf16 values, ix_attn_split_*_b16)
+    x = _req(x, "attention operand") if not in16 else (x if x.is_contiguous() else x.contiguous())
     Rp = _pad128(R)
     dev = x.device
     form = _TR_FORMS[FLASH_TR] if tr_form is None else tr_form
@@ -923,10 +924,13 @@ def attn_split(x, n, R, ld, off, H, hd, row=True, tr=True, tr_form=None, dot=Non
     if dot is not None:
         y, ldy, offy = dot
         t = torch.empty(n * H, Rp, dtype=torch.float32, device=dev)
-        _chk(_L().ix_attn_split_dot_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
-                                        trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _req(y).data_ptr(), ldy, offy,
-                                        t.data_ptr(), _stream()), "ix_attn_split_dot_f32")
+        fn = _L().ix_attn_split_dot_b16 if in16 else _L().ix_attn_split_dot_f32
+        _chk(fn(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
+                trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _req(y).data_ptr(), ldy, offy,
+                t.data_ptr(), _stream()), "ix_attn_split_dot")
         return AttnPlanes(rowp, us, trp, form), t
+    if in16:
+        return attn_split_multi([(x, R, ld, off, row, tr)], n, H, hd, tr_form=form)[0]
     _chk(_L().ix_attn_split_f32(x.data_ptr(), rowp.data_ptr() if row else None, us.data_ptr() if us is not None else None,
                                 trp.data_ptr() if tr else None, form, n, R, Rp, ld, off, H, hd, _stream()), "ix_attn_split_f32")
     return AttnPlanes(rowp, us, trp, form)
@@ -1000,10 +1004,12 @@ def attn_split_multi(ops, n, H, hd, tr_form=None):
     cnt = len(ops)
     xs, rows, uss, trs = [], [], [], []
     rows_only = _rows_only(hd, form)
+    in16 = ops[0][0].dtype == torch.bfloat16
+    assert all((o[0].dtype == torch.bfloat16) == in16 for o in ops), "the operands of one attention call share a storage dtype"
     for x, R, ld, off, row, tr in ops:
         if rows_only:
             row, tr = row or tr, False
-        x = _req(x, "attention operand")
+        x = _req(x, "attention operand") if not in16 else (x if x.is_contiguous() else x.contiguous())
         Rp, dev = _pad128(R), x.device
         xs.append(x)
         rows.append(torch.empty(2 * n * H * Rp * hd, dtype=torch.float16, device=dev) if row else None)
@@ -1012,9 +1018,10 @@ def attn_split_multi(ops, n, H, hd, tr_form=None):
                    torch.empty(3 * n * H * Rp * hd, dtype=torch.bfloat16, device=dev))
     ptr = lambda ts: (ctypes.c_void_p * cnt)(*[t.data_ptr() if t is not None else None for t in ts])
     ints = lambda vs: (ctypes.c_int * cnt)(*vs)
-    _chk(_L().ix_attn_split_multi_f32(cnt, ptr(xs), ptr(rows), ptr(uss), ptr(trs), form, n, ints([o[1] for o in ops]),
-                                      ints([_pad128(o[1]) for o in ops]), (ctypes.c_int64 * cnt)(*[o[2] for o in ops]),
-                                      ints([o[3] for o in ops]), H, hd, _stream()), "ix_attn_split_multi_f32")
+    fn = _L().ix_attn_split_multi_b16 if in16 else _L().ix_attn_split_multi_f32
+    _chk(fn(cnt, ptr(xs), ptr(rows), ptr(uss), ptr(trs), form, n, ints([o[1] for o in ops]),
+            ints([_pad128(o[1]) for o in ops]), (ctypes.c_int64 * cnt)(*[o[2] for o in ops]),
+            ints([o[3] for o in ops]), H, hd, _stream()), "ix_attn_split_multi")
     return [AttnPlanes(r, u, t, form) for r, u, t in zip(rows, uss, trs)]
 
 
@@ -1147,6 +1154,11 @@ class FlashAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, g, mask, p, seed):
         q, k, v = _req(q, "attention q"), _req(k, "attention k"), _req(v, "attention v")
+        return FlashAttention._forward(ctx, q, k, v, g, mask, p, seed)
+
+    @staticmethod
+    def _forward(ctx, q, k, v, g, mask, p, seed):
+        """(shared with the 16-bit twin, b16.FlashAttention16: q / k / v fp32 or bf16; the kernels write the output in fp32)"""
         out, lse, pl = flash_forward(q, k, v, g, mask, p, seed, need_backward=not isinstance(ctx, _NullCtx))
         ctx.g, ctx.p, ctx.seed, ctx.pl = g, p, seed, pl
         # packed projection buffers: [q | k] (nn.MultiheadAttention self-attention) or [k | q | v] (fusion blocks) in one tensor.
@@ -1192,6 +1204,11 @@ class FlashAttentionBwd(Function):
     @staticmethod
     def forward(ctx, q, k, v, out, lse, do, g, p, seed, pl, same_qk):
         do = _req(do.contiguous(), "attention dO")
+        return FlashAttentionBwd._forward(ctx, q, k, v, out, lse, do, g, p, seed, pl, same_qk)
+
+    @staticmethod
+    def _forward(ctx, q, k, v, out, lse, do, g, p, seed, pl, same_qk):
+        """(shared with the 16-bit twin: q / k / v / dO fp32 or bf16, `out` and the gradients fp32)"""
         dev = q.device
         Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
         if FLASH_SPLIT_DOT:   # the planes of dO and delta = dO . O (per query and head) from one read of dO
@@ -1229,6 +1246,14 @@ class FlashAttentionBwd(Function):
             hv = hq
         else:
             hv = _req(hv.contiguous()) if hv is not None else zeros(v)
+        return FlashAttentionBwd._backward_impl(ctx, hq, hk, hv)
+
+    @staticmethod
+    def _backward_impl(ctx, hq, hk, hv):
+        """(shared with the 16-bit twin: cotangents fp32 or bf16, all of one dtype; the results are fp32)"""
+        q, k, v, out, lse, do = ctx.saved_tensors
+        g, pl, dev = ctx.g, ctx.pl, q.device
+        Lp, Sp, E = _pad128(g.L), _pad128(g.S), g.heads * g.hd
         hqp, hkp, hvp = attn_split_multi([(hq, g.L, g.q_ld, g.q_off, True, True), (hk, g.S, g.k_ld, g.k_off, True, True),
                                           (hv, g.S, g.v_ld, g.v_off, True, True)], g.n, g.heads, g.hd, tr_form=pl["q"].tr_form)
         dq, dk, dv = _grad_buffers(g, q, k, v, ctx.same_qk)

@@ -263,3 +263,37 @@ def test_bf16_convolutions_forward_and_both_gradients(lib, stages, geom):
         tol = b.abs() * 2.0 ** -7 + (2e-3 if what == "y" else 6e-3) * float(b.abs().max())
         assert bool((err <= tol).all()), (what, float(err.max()), float(b.abs().max()))
     assert float((dw16 - dw32).abs().max()) <= 5e-3 * float(dw32.abs().max()), float((dw16 - dw32).abs().max()) / float(dw32.abs().max())
+
+
+@pytest.mark.parametrize("hd,masked,pdrop", [(64, False, 0.1), (64, True, 0.0), (32, True, 0.1)])
+def test_attention_twin_forward_and_first_derivative(lib, hd, masked, pdrop):
+    """Attention on bf16 q / k / v (packed [k | q | v] of the fusion blocks at head dim 64: the single-term passes of csrc/flash16.hip;
+    head dim 32 of the detector: the 32 x 32 family on the same planes) against float64 autograd on the same bf16 values with the
+    kernels' own dropout mask: output and gradients within 1 % of their scale (the [L, S] intermediates are rounded once to fp16 in the
+    single-term passes; results are stored as bf16)."""
+    import math
+    from interactron_amd import b16, hipops as ops
+    from tests.test_ops_gpu import _ref_attention_drop
+    n, H, L = 2, 4, 300
+    E = H * hd
+    kqv = rnd(n, L, 3 * E, seed=31).cuda()
+    scale = 1.0 / math.sqrt(hd)
+    g = ops.AttnGeom(n, H, L, L, hd, 3 * E, 3 * E, E, 0, 3 * E, 2 * E, scale)
+    mask = None
+    if masked:
+        mask = torch.zeros(n, L, dtype=torch.uint8, device="cuda")
+        mask[1, L - 40:] = 1
+    seed = 0x7654321
+    drop = ops.flash_dropmask(n * H, L, L, pdrop, seed).cpu().double() if pdrop > 0 else None
+    gy = rnd(n, L, E, seed=32).cuda()
+    a = kqv.clone().requires_grad_(True)
+    out = ops.FlashAttention.apply(a, a, a, g, mask, pdrop, seed)
+    assert out.dtype == torch.bfloat16
+    (ga,) = torch.autograd.grad(out, [a], gy)
+    assert ga.dtype == torch.bfloat16
+    r = kqv.double().cpu().requires_grad_(True)
+    ro = _ref_attention_drop(r[..., E:2 * E], r[..., :E], r[..., 2 * E:], H, scale, None if mask is None else mask.cpu(), drop)
+    (rg,) = torch.autograd.grad(ro, [r], gy.double().cpu())
+    for got, ref, what in ((out, ro, "output"), (ga, rg, "gradient")):
+        err = float((got.double().cpu() - ref.detach()).abs().max())
+        assert err <= 1e-2 * float(ref.abs().max()), (what, err, float(ref.abs().max()))

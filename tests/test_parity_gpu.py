@@ -903,6 +903,21 @@ def test_config2_multiframe_bf16_activations(golden, episode1):
         check_record(rec, pred[k], atol=rec_tol(rec), rtol=1e-3, what="f32 after bf16/" + k)
 
 
+def test_interactron_step_in_the_16_bit_mode_against_the_oracle():
+    """configs/interactron.yaml's meta-train step with MODEL.COMPUTE_DTYPE bf16 (one episode at 128 x 128, the smoke step): learned-loss
+    gradient with create_graph, clipped SGD on fp32 fast weights, second-order backward -- through bf16 activations, the bf16 GEMM /
+    convolution gathers, the single-term attention passes and, where an op has no 16-bit second-order kernel, its fp32 kernel between
+    conversion passes (b16.py).  Against the fp32 CPU oracle (reference models/interactron.py:61-151): every loss within 2 %, every
+    gradient tensor's direction cosine >= 0.99, norms within 15 %; assignments pinned to the oracle's (judged as ties at bf16 noise)."""
+    import __graft_entry__ as entry
+    from interactron_amd import b16
+    before = b16._stats["native_gemms"]
+    res = entry.smoke_check(128, cfg_extra={"COMPUTE_DTYPE": "bf16"}, f64_slack=False, norm_tol=1.5e-1, loss_tol=2e-2, cos_min=0.99,
+                            pin_matching="always")
+    assert res["checked"] >= 300
+    assert b16._stats["native_gemms"] > before + 500, "the 16-bit kernels did not run"
+
+
 @pytest.mark.usefixtures("kernel_form")
 def test_config3_interactron_random(golden, episode1):
     O = golden("golden_configs.pt")
