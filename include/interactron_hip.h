@@ -455,6 +455,10 @@ int ix_gemm_b16(const void* A, const void* B, void* C, const float* bias, int M,
 int ix_gemm_b16_supported(const void* A, const void* B, const void* C, int M, int N, int K, int a_kcontig, int b_kcontig, int64_t lda,
                           int64_t ldb, int64_t ldc, int64_t sAo, int64_t sAi, int64_t sBo, int64_t sBi, int64_t sCo, int64_t sCi);
 int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out_host);
+int ix_gemm_rowsum_b16(const void* A, const void* B, float* C, float* rowsum, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                       int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, int64_t rowsum_stride, float alpha, void* workspace,
+                       size_t workspace_bytes, ix_stream_t stream); /* C = alpha A B (fp32) and rowsum[b][m] = sum_k A(m, k), A m-contiguous,
+                       B n-contiguous: a Linear's weight gradient dY^T x with its bias gradient riding on it (the fp32 twin: ix_gemm_rowsum_f32) */
 int ix_gemm_b16_set_stages(int stages); /* 1: one LDS stage, four workgroups per CU | 2: two stages, the next K step's DMA under this one's
                                            matrix instructions; returns the previous setting (IX_GEMM16_STAGES) */
 /*   ix_conv_gemm_b16 : the three implicit-GEMM convolution kinds of ix_conv_gemm_f32 (forward, data gradient, weight gradient of a

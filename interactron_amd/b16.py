@@ -643,3 +643,34 @@ class FlashAttentionBwd16(ops.FlashAttentionBwd):
         with _single_term():
             outs = ops.FlashAttentionBwd._backward_impl(ctx, hq, hk, hv)
         return tuple(cast_b16(t) if torch.is_tensor(t) else t for t in outs)
+
+
+def gemm_rowsum(dc, a, sp, groups):
+    """(dW, dbias) = (alpha dC^T a, colsum(dC)) in ONE launch of the bf16 GEMM (ix_gemm_rowsum_b16: four more matrix instructions per
+    k-slice against a fragment of ones in the workgroups of the first N tile) -- the 16-bit twin of hipops.GemmRowsum for the
+    unrecorded backward.  sp: the weight-gradient contraction (A = dC^T m-contiguous, B = a n-contiguous).  None when the operands
+    do not qualify (recorded backward, unaligned rows): the caller then takes the two separate nodes."""
+    if torch.is_grad_enabled() and (dc.requires_grad or a.requires_grad):
+        return None
+    if not (sp.A.trans and sp.A.offset == 0 and sp.A.ld == sp.M and sp.bi == 1 and not sp.B.trans and not sp.C.trans):
+        return None
+    L = ops._L()
+    if L.ix_gemm_b16_supported((dc.data_ptr() if dc.dtype == B16 else 0), (a.data_ptr() if a.dtype == B16 else 0) + 2 * sp.B.offset,
+                               4 * sp.C.offset, sp.M, sp.N, sp.K, 0, 0, sp.A.ld, sp.B.ld, sp.C.ld, sp.A.so, 0, sp.B.so, 0, sp.C.so, 0) != 1:
+        return None
+    dc16, a16 = _c16(dc), _c16(a)
+    covered = sp.bo * sp.M * sp.N == ops._numel(sp.out_shape)
+    out = (torch.empty if covered else torch.zeros)(sp.out_shape, device=dc.device, dtype=torch.float32)
+    rs = torch.empty((groups, sp.M) if groups else (sp.M,), device=dc.device, dtype=torch.float32)
+    key = ("b16", sp.M, sp.N, sp.K, sp.bo)
+    nws = ops._ws_bytes.get(key)
+    if nws is None:
+        n = ctypes.c_size_t()
+        ops._chk(L.ix_workspace_bytes_gemm_b16(sp.M, sp.N, sp.K, sp.bo, ctypes.byref(n)), "ix_workspace_bytes_gemm_b16")
+        nws = ops._ws_bytes[key] = n.value
+    ws = ops._workspace(nws, dc.device) if nws else None
+    ops._chk(L.ix_gemm_rowsum_b16(dc16.data_ptr(), a16.data_ptr() + 2 * sp.B.offset, out.data_ptr() + 4 * sp.C.offset, rs.data_ptr(),
+                                  sp.M, sp.N, sp.K, sp.A.ld, sp.B.ld, sp.C.ld, sp.bo, sp.A.so, sp.B.so, sp.C.so, sp.M, sp.alpha,
+                                  ws.data_ptr() if nws else None, nws, ops._stream()), "ix_gemm_rowsum_b16")
+    _stats["native_gemms"] += 1
+    return out, rs

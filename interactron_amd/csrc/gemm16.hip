@@ -71,6 +71,9 @@ struct G16Args {
     const float *scale, *shift;
     const void* res;
     float* planes;          // split-K partial planes [split][batch][M][N] (fp32) or null
+    float* rowsum;          // optional side output (m-contiguous A: the weight gradient's dY): rowsum[batch][m] = sum_k A(m, k) -- the bias
+    float* rs_planes;       // gradient riding on the weight-gradient contraction; with split-K per-split partials [split][batch][M]
+    int64_t sRowsum;
     int64_t lda, ldb, ldc, sAo, sAi, sBo, sBi, sCo, sCi, sBias;
     unsigned extA, extB;    // bytes addressable from a batch slice's base (buffer bounds)
     int M, N, K, nk, kps, split, tiles_m, tiles_n, batch_inner;
@@ -109,8 +112,10 @@ __device__ __forceinline__ float g16_act(float v, int act) {
 // CONV: 0 plain operands; 1 / 2: the gathering operand of an implicit-GEMM convolution (G16Conv.mode)
 // STAGES: 1 = one 32 KB LDS stage, four workgroups per CU cover each other's DMA latency; 2 = two stages, the next K step's DMA in
 // flight under this one's matrix instructions (counted vmcnt, raw barriers), two workgroups per CU
-template <bool A_KC, bool B_KC, bool F32OUT, int CONV = 0, int STAGES = 1>
-__global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm16_kernel(G16Args p) {
+// RS: also rowsum[m] = sum_k A(m, k) (four more matrix instructions per k-slice against a fragment of ones, in the workgroups of the
+// first N tile only)
+template <bool A_KC, bool B_KC, bool F32OUT, int CONV = 0, int STAGES = 1, bool RS = false>
+__global__ __launch_bounds__(256, STAGES == 1 ? (RS ? 3 : 4) : 2) void gemm16_kernel(G16Args p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * 2 * G16_IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, g = lane >> 4;
@@ -192,6 +197,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm16_kernel(G16Arg
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accr[4];   // RS: (ones x A^T) blocks -- every row of a block is the row sum of its 16 m
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool rs_here = RS && tn == 0 && wn == 0;
 
     // the DMA requests of K step kt into the images at imgA / imgB
     auto issue = [&](int kt, unsigned char* imgA, unsigned char* imgB) {
@@ -283,6 +292,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm16_kernel(G16Arg
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fn[j]), __builtin_bit_cast(bf16x8, fm[i]),
                                                                         acc[i][j], 0, 0, 0);
+            if (RS && rs_here) {   // (wave-uniform)
+                const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, fm[i]), accr[i], 0, 0, 0);
+            }
         }
         if (STAGES == 2) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -292,6 +307,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 4 : 2) void gemm16_kernel(G16Arg
         }
     }
 
+    if (RS && rs_here && g == 0) {   // lane (idx, 0), register 0 of block i: the sum over this split's k of row m = wm + 16 i + idx
+        float* R = p.rs_planes ? p.rs_planes + ((int64_t)ks * gridDim.y + zb) * p.M : p.rowsum + bo * p.sRowsum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m < p.M) R[m] = accr[i].x;
+        }
+    }
     // ---- epilogue: lane (idx, g) of block (i, j) holds row m = wm + 16 i + idx, columns n = wn + 16 j + 4 g .. + 3 -----------------
     if (p.planes) {   // split-K: the raw partial sums of this split, fp32, dense [M][N]
         float* P = p.planes + ((int64_t)ks * gridDim.y + zb) * (int64_t)p.M * p.N;
@@ -369,6 +392,13 @@ __global__ __launch_bounds__(256) void gemm16_reduce_kernel(G16Args p, int nbatc
         if (F32OUT) *reinterpret_cast<f32x4*>((float*)p.C + o) = v;
         else *reinterpret_cast<u32x2*>((unsigned short*)p.C + o) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
     }
+    if (p.rs_planes)   // the per-split partial row sums, in split order
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < (int64_t)nbatch * p.M; t += (int64_t)gridDim.x * 256) {
+            float a = p.rs_planes[t];
+            for (int s = 1; s < p.split; ++s) a += p.rs_planes[(int64_t)s * nbatch * p.M + t];
+            const int zb = (int)(t / p.M);
+            p.rowsum[(int64_t)(zb / p.batch_inner) * p.sRowsum + (t - (int64_t)zb * p.M)] = a;
+        }
 }
 
 // ---- plan: how many splits of K ------------------------------------------------------------------------------------------------
@@ -381,6 +411,11 @@ static void g16_plan(int M, int N, int K, int nbatch, int* split, int* kps) {
         s = (int)((1024 + tiles - 1) / tiles);
         if (s > nk / 4) s = nk / 4;
         if (s > 64) s = 64;
+        // ... and the planes are written and read once each: no more than ~24 MB of them (a 2048 x 512 output cut 16 ways moved 128 MB
+        // for a 70 us contraction)
+        const int64_t plane = (int64_t)M * N * nbatch * 4;
+        const int cap = (int)((24ll << 20) / (plane > 0 ? plane : 1));
+        if (s > cap) s = cap;
         if (s < 1) s = 1;
     }
     const int per = ix_div_up(nk, s);
@@ -392,7 +427,8 @@ extern "C" int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size
     IX_CHECK_ARG(out && M >= 0 && N >= 0 && K >= 0 && nbatch >= 0, "ix_workspace_bytes_gemm_b16: bad args");
     int split = 1, kps = 1;
     if (M > 0 && N > 0 && K > 0 && nbatch > 0) g16_plan(M, N, K, nbatch, &split, &kps);
-    *out = split > 1 ? IX_TICKET_BYTES + (size_t)split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float) : 0;
+    // (+ M floats per plane: the partial row sums of ix_gemm_rowsum_b16 ride in the same scratch)
+    *out = split > 1 ? IX_TICKET_BYTES + (size_t)split * (size_t)nbatch * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float) : 0;
     return IX_OK;
 }
 
@@ -434,10 +470,14 @@ static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void*
     g16_plan(M, N, K, nbatch, &a.split, &a.kps);
     a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN);
     a.planes = nullptr;
+    a.rs_planes = nullptr;
     if (a.split > 1) {
-        const size_t need = (size_t)a.split * (size_t)nbatch * (size_t)M * (size_t)N * sizeof(float);
+        const size_t need = (size_t)a.split * (size_t)nbatch * ((size_t)M * (size_t)N + (a.rowsum ? (size_t)M : 0)) * sizeof(float);
         if (!workspace || workspace_bytes < need + IX_TICKET_BYTES) { a.split = 1; a.kps = a.nk; }   // no scratch: one pass over K
-        else a.planes = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+        else {
+            a.planes = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + IX_TICKET_BYTES);
+            if (a.rowsum) a.rs_planes = a.planes + (size_t)a.split * (size_t)nbatch * (size_t)M * (size_t)N;
+        }
     }
     IX_CHECK_ARG(nbatch <= 65535 && a.split <= 65535, "%s: too many batch slices", name);
     const dim3 grid(a.tiles_m * a.tiles_n, nbatch, a.split);
@@ -448,7 +488,9 @@ static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void*
         if (g16_stages() == 2) hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 2>), grid, dim3(256), 0, stream, a);    \
         else hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 1>), grid, dim3(256), 0, stream, a);                      \
     } while (0)
-    if (a.cg.mode == 1) {
+    if (a.rowsum) {   // (the weight gradient of a Linear with its bias gradient: dY m-contiguous, x n-contiguous, fp32 result)
+        hipLaunchKernelGGL((gemm16_kernel<false, false, true, 0, 1, true>), grid, dim3(256), 0, stream, a);
+    } else if (a.cg.mode == 1) {
         if (b_kc) { if (f32) G16_LAUNCH(true, true, true, 1); else G16_LAUNCH(true, true, false, 1); }
         else { if (f32) G16_LAUNCH(true, false, true, 1); else G16_LAUNCH(true, false, false, 1); }
     } else if (a.cg.mode == 2) {
@@ -492,7 +534,27 @@ extern "C" int ix_gemm_b16(const void* A, const void* B, void* C, const float* b
     a.M = M; a.N = N; a.K = K; a.batch_inner = batch_inner;
     a.alpha = alpha; a.act = act;
     a.cg.mode = 0; a.cg.btap = 0;
+    a.rowsum = nullptr; a.sRowsum = 0;
     return g16_run(a, a_kcontig != 0, b_kcontig != 0, c_f32 != 0, nbatch, workspace, workspace_bytes, stream, "ix_gemm_b16");
+}
+
+// C[b] = alpha A[b] B[b] (fp32) AND rowsum[b][m] = sum_k A(m, k) for an m-contiguous A and an n-contiguous B -- the weight gradient of a
+// Linear layer, dW = dY^T x, with its bias gradient colsum(dY) riding on it (the fp32 twin: ix_gemm_rowsum_f32)
+extern "C" int ix_gemm_rowsum_b16(const void* A, const void* B, float* C, float* rowsum, int M, int N, int K, int64_t lda, int64_t ldb,
+                                  int64_t ldc, int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, int64_t rowsum_stride, float alpha,
+                                  void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || batch_outer <= 0) return IX_OK;
+    IX_CHECK_ARG(A && B && C && rowsum && K > 0, "ix_gemm_rowsum_b16: null operand or K <= 0");
+    IX_CHECK_ARG(ix_gemm_b16_supported(A, B, C, M, N, K, 0, 0, lda, ldb, ldc, sAo, 0, sBo, 0, sCo, 0), "ix_gemm_rowsum_b16: operands must have 16-byte aligned rows");
+    G16Args a;
+    a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.C = C; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr; a.res = nullptr;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sAo = sAo; a.sAi = 0; a.sBo = sBo; a.sBi = 0; a.sCo = sCo; a.sCi = 0; a.sBias = 0;
+    a.extA = (unsigned)(2 * ((int64_t)(K - 1) * lda + M));
+    a.extB = (unsigned)(2 * ((int64_t)(K - 1) * ldb + N));
+    a.M = M; a.N = N; a.K = K; a.batch_inner = 1; a.alpha = alpha; a.act = 0;
+    a.cg.mode = 0; a.cg.btap = 0;
+    a.rowsum = rowsum; a.sRowsum = rowsum_stride;
+    return g16_run(a, false, false, true, batch_outer, workspace, workspace_bytes, stream, "ix_gemm_rowsum_b16");
 }
 
 // ---- implicit-GEMM convolution on bf16 NHWC activations (the three kinds of ix_conv_gemm_f32; csrc/gemm.hip has the fp32 twin) ------
@@ -546,6 +608,7 @@ extern "C" int ix_conv_gemm_b16(int kind, const void* src, const void* other, vo
     a.C = out; a.bias = nullptr; a.scale = scale; a.shift = shift; a.res = residual;
     a.M = M; a.N = N; a.K = K; a.batch_inner = 1; a.alpha = 1.f; a.act = relu ? 1 : 0; a.sBias = 0;
     a.sAi = a.sBi = a.sCi = 0;
+    a.rowsum = nullptr; a.sRowsum = 0;
     a.ldc = N; a.sCo = (int64_t)M * N;
     G16Conv& g = a.cg;
     g.btap = 0; g.bcol = 0; g.KW = KW;

@@ -534,8 +534,8 @@ class Gemm(Function):
         need_bias = ctx.has_bias and ctx.needs_input_grad[2] and not _is_unwanted(ctx.bias_key, skip)
         # the bias gradient colsum(dC) rides on the weight-gradient contraction dB^T = dC^T A (ix_gemm_rowsum_f32: the
         # A-producer waves of that launch sum the dC tiles they stream anyway) whenever dC is its plain m-contiguous A operand
-        fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0 and dc.dtype == torch.float32
-                and a.dtype == torch.float32
+        fuse = (GEMM_ROWSUM and need_bias and need_b and sp.B.trans and sp.bi == 1 and sp.C.offset == 0
+                and (dc.dtype == a.dtype or b.dtype == torch.float32)   # (16-bit mode: bf16 dC and activation, fp32 weight)
                 and sp.C.ld == sp.N and (ctx.bias_groups == sp.bo or (ctx.bias_groups == 0 and sp.bo == 1))
                 and (sp.bo == 1 or sp.C.so == sp.M * sp.N))
         # (recorded backward: dC feeds up to three nodes -- one alias each, so that ITS gradient is one sum, Fanout)
@@ -545,6 +545,18 @@ class Gemm(Function):
         if fuse:
             s = GemmSpec(sp.N, sp.K, sp.M, sp.bo, sp.bi, _flip(sp.C), sp.A,
                          View(sp.B.offset, sp.B.ld, False, sp.B.so, sp.B.si), ctx.b_shape, sp.alpha)
+            if dc.dtype == torch.bfloat16 or a.dtype == torch.bfloat16:
+                from . import b16
+                fused = b16.gemm_rowsum(dcs[-1], a, s, ctx.bias_groups)
+                if fused is None:   # (rows not 16-byte aligned: the two separate nodes)
+                    fuse = False
+                    db = _gemm_backward(sp, a, b, ctx.a_shape, ctx.b_shape, dc, False, True, [dcs.pop()])[1]
+                    d = dc
+                    dbias = ColSum.call(d.reshape(ctx.bias_groups, -1, sp.N) if ctx.bias_groups else d.reshape(-1, sp.N))
+                else:
+                    dcs.pop()
+                    db, dbias = fused
+                return da, db, dbias, None
             db, dbias = GemmRowsum.call(dcs.pop(), a, s, ctx.bias_groups)
         elif need_bias:
             d = dcs.pop()

@@ -297,3 +297,22 @@ def test_attention_twin_forward_and_first_derivative(lib, hd, masked, pdrop):
     for got, ref, what in ((out, ro, "output"), (ga, rg, "gradient")):
         err = float((got.double().cpu() - ref.detach()).abs().max())
         assert err <= 1e-2 * float(ref.abs().max()), (what, err, float(ref.abs().max()))
+
+
+def test_bias_gradient_rides_on_the_weight_gradient_contraction(lib):
+    """ix_gemm_rowsum_b16: dW = dY^T x (fp32) and dbias = colsum(dY) from ONE launch -- a Linear's weight and bias gradient in the
+    16-bit mode (with and without the split along K) against float64."""
+    from interactron_amd import hipops as ops
+    for rows, out, inn in ((28880, 256, 512), (700, 264, 136), (4000, 2048, 256)):
+        x, w = rnd(rows, inn, seed=41).cuda(), rnd(out, inn, seed=42, scale=0.1).cuda().float().requires_grad_(True)
+        bias = torch.zeros(out, device="cuda", requires_grad=True)
+        dy = rnd(rows, out, seed=43).cuda()
+        xg = x.clone().requires_grad_(True)
+        y = ops.linear(xg, w, bias)
+        assert y.dtype == torch.bfloat16
+        y.backward(dy)
+        ref_w = dy.double().cpu().t() @ x.double().cpu()
+        ref_b = dy.double().cpu().sum(0)
+        assert w.grad.dtype == torch.float32 and bias.grad.dtype == torch.float32
+        assert float((w.grad.double().cpu() - ref_w).abs().max()) <= 1e-5 * float((dy.double().cpu().abs().t() @ x.double().cpu().abs()).max())
+        assert float((bias.grad.double().cpu() - ref_b).abs().max()) <= 1e-5 * float(dy.double().cpu().abs().sum(0).max())

@@ -178,7 +178,9 @@ def test_stress_config_training_step_with_fp8_attention_against_the_oracle():
     # (200 near-identical queries on RNG-free weights: the Hungarian optimum is full of ties -- both runs take the oracle's assignments)
     # (fp32-grade run: 1e-2 on the norms without the float64 slack run -- the first trainable convolution sits at 7e-3 here, as in the
     #  128 x 128 smoke step before its slack is counted; the point of this test is the fp8 run below)
-    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=1e-2, pin_matching="ties")
+    # (losses at the fp8 bound for both runs: with 200 near-identical queries an image presented to several criterion calls may take
+    #  another call's recorded assignment -- a tie for the matcher, not for the loss of THAT call)
+    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=1e-2, loss_tol=FP8_TRAIN_LOSS, pin_matching="ties")
     assert hipops.ATTENTION_DTYPE == "fp32"
     hipops.ATTENTION_DTYPE = "fp8"
     try:
