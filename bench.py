@@ -671,7 +671,23 @@ def main():
                                                                            "launches_per_step", "kernel_ms_per_step", "gflop_per_step",
                                                                            "avg_launch_us", "bf16_gemm", "fp32_on_16bit_kernels")}
                 pair[dt]["attention_ms_per_step"] = r["roofline"]["attention_kernels"]["kernel_ms_per_step"]
-        b16_line = {"workload": "configs/multi_frame_baseline.yaml training step (detr_multiframe.forward + clip + Adam), 16 episodes/GPU x 5 frames x "
+        # ... and the headline configuration itself in the mode (configs/interactron.yaml: second-order backward through bf16 activations,
+        # fp32 fast weights), at the reference's 300 x 300 shape, the north-star 800 x 800 shape and the 2-episode share of an 8-GPU step
+        sub.config = "interactron"
+        inter = {}
+        for name, (size, eps, steps, warm) in (("p300_e16", (300, 16, 10, 3)), ("small_e", (300, 2, 10, 3)), ("n800_e8", (800, 8, 5, 2))):
+            if (name == "n800_e8" and args.n800_episodes <= 0) or (name == "small_e" and args.small_e <= 0):
+                continue
+            try:
+                r = run_workload(sub, size, eps, eps, steps, warm, ctx, False, "bench-b16-" + name)
+                inter[name] = {"workload": "%d episodes/GPU x 5 frames x 3x%dx%d, same meta-train step" % (eps, size, size), "value": r["frames_per_s"],
+                               "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warm,
+                               "peak_memory_GB": r["peak_memory_GB"], "step_graphs": r["step_graphs"]}
+            except torch.cuda.OutOfMemoryError as e:
+                inter[name] = {"error": "out of memory: %s" % str(e)[:200]}
+                torch.cuda.empty_cache()
+        b16_line = {"interactron": inter,
+                    "workload": "configs/multi_frame_baseline.yaml training step (detr_multiframe.forward + clip + Adam), 16 episodes/GPU x 5 frames x "
                                 "3x300x300, Q=50, fusion T=2060, procedural weights, train mode",
                     "dtype": "bf16 (activations stored as bf16, bf16 matrix instructions with LDS-DMA operands, fp32 accumulation / statistics / "
                              "parameters; parity at SURVEY 8d's bf16 row: tests/test_parity_gpu.py::test_config2_multiframe_bf16_activations)",
