@@ -692,18 +692,26 @@ def main():
                     "dtype": "bf16 (activations stored as bf16, bf16 matrix instructions with LDS-DMA operands, fp32 accumulation / statistics / "
                              "parameters; parity at SURVEY 8d's bf16 row: tests/test_parity_gpu.py::test_config2_multiframe_bf16_activations)",
                     "f32": pair["f32"], "bf16": pair["bf16"], "speedup_over_f32": pair["bf16"]["value"] / pair["f32"]["value"]}
-    # BASELINE.json configs[4], the bandwidth-bound stress configuration: 1600 x 1600 frames, 200 queries (T = 51 005), the two
-    # forward attention products on OCP e4m3 MFMA (the derivative passes stay fp32-grade: DESIGN.md 4.2a), one episode per step
+    # BASELINE.json configs[4], the bandwidth-bound stress configuration: 1600 x 1600 frames, 200 queries (T = 51 005), one episode
+    # per step.  The training step runs fp32-grade attention (a differentiated call never takes the fp8 forward: hipops/attn.py
+    # flash_forward); the configuration's fp8 MFMA attention is what predict() runs -- measured beside it, with
+    # the fp32-grade predict for comparison.
     stress = None
     if headline_cfg and world == 1 and args.stress_steps > 0 and args.attention_dtype == "fp32":
-        q0, _ops.ATTENTION_DTYPE, args.queries = args.queries, "fp8", 200
+        q0, args.queries, mode0 = args.queries, 200, args.mode
         try:
             stress = run_workload(args, 1600, 1, 1, args.stress_steps, 2, ctx, False, "bench1600")   # (2 warm-up steps: eager, then the capture)
+            args.mode = "predict"
+            for dt in ("fp32", "fp8"):
+                _ops.ATTENTION_DTYPE = dt
+                r = run_workload(args, 1600, 1, 1, args.stress_steps, 1, ctx, False, "bench1600")
+                stress["predict_" + dt] = {"value": r["frames_per_s"], "unit": "frames/s", "ms_per_step": r["ms_per_step"],
+                                           "peak_memory_GB": r["peak_memory_GB"]}
         except torch.cuda.OutOfMemoryError as e:
             stress = {"error": "out of memory: %s" % str(e)[:200]}
             torch.cuda.empty_cache()
         finally:
-            _ops.ATTENTION_DTYPE, args.queries = args.attention_dtype, q0
+            _ops.ATTENTION_DTYPE, args.queries, args.mode = args.attention_dtype, q0, mode0
     # The north-star shape (BASELINE.json: synthetic 5 x 3x800x800 episodes; fusion BLOCK_SIZE = 12 755),
     # measured in the same process after the headline: same step definition, fewer episodes per pass, its own warm-up.
     n800 = r8 = None
@@ -768,10 +776,14 @@ def main():
                             "cpu_baseline": None} if n800 is not None and "error" not in n800 else None),
             "small_e": None, "strong": None,
             "stress": (stress if stress is None or "error" in stress else
-                       {"workload": "BASELINE.json configs[4]: 1 episode/GPU x 5 frames x 3x1600x1600, Q=200, fusion T=%d, same training step, "
-                                    "attention forward products on fp8 (OCP e4m3) MFMA, derivative passes fp32-grade" % stress["block_size"],
+                       {"workload": "BASELINE.json configs[4]: 1 episode/GPU x 5 frames x 3x1600x1600, Q=200, fusion T=%d, same training step "
+                                    "(fp32-grade attention: differentiated calls never take the fp8 forward, its output breaks the derivative "
+                                    "passes' dO . O identity -- tests/test_ops_gpu.py::test_fp8_attention_is_for_calls_that_are_not_differentiated); "
+                                    "predict_fp8 / predict_fp32: predict() on the same episode with the forward attention products on fp8 "
+                                    "(OCP e4m3) MFMA / fp32-grade" % stress["block_size"],
                         "value": stress["frames_per_s"], "unit": "frames/s", "steps": args.stress_steps, "warmup": 2,
-                        "ms_per_step": stress["ms_per_step"], "peak_memory_GB": stress["peak_memory_GB"], "attention_dtype": "fp8 (forward)",
+                        "ms_per_step": stress["ms_per_step"], "peak_memory_GB": stress["peak_memory_GB"], "attention_dtype": "fp32 (training step)",
+                        "predict_fp8": stress.get("predict_fp8"), "predict_fp32": stress.get("predict_fp32"),
                         "step_graphs": stress["step_graphs"]}),
             "bf16_mode": b16_line,
             "inner5": ({"workload": "%d episodes/GPU x 5 frames x 3x300x300, MODEL.INNER_STEPS = 5 (BASELINE.json north_star's 5-step adapt loop; "

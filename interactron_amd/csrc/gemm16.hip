@@ -107,6 +107,11 @@ __device__ __forceinline__ float g16_act(float v, int act) {
 }
 
 #define G16_OOB 0x7ffffff0
+// Diagnostic builds (`make diag16`, tools/gemm16_bench.py under IX_LIB_PATH; never loaded by the package): what one launch costs
+// without one of its three parts.  1: no LDS reads / matrix instructions;  2: no DMA requests;  3: no epilogue stores
+#ifndef G16_DIAG
+#define G16_DIAG 0
+#endif
 
 // A_KC / B_KC: the operand's contracted index is contiguous in HBM.  F32OUT: C (and the residual) are fp32.
 // CONV: 0 plain operands; 1 / 2: the gathering operand of an implicit-GEMM convolution (G16Conv.mode)
@@ -248,26 +253,26 @@ __global__ __launch_bounds__(256, STAGES == 1 ? (RS ? 3 : 4) : 2) void gemm16_ke
             for (int q = 0; q < 4; ++q) g16_dma16(rB, kb[q] < klim ? vb[q] : G16_OOB, sb, dB + q * 1024);
         }
     };
-    if (STAGES == 2) issue(kt0, lds, lds + G16_IMG);
+    if (STAGES == 2 && G16_DIAG != 2) issue(kt0, lds, lds + G16_IMG);
     for (int kt = kt0; kt < kt1; ++kt) {
         unsigned char* const imgA = lds + (STAGES == 2 ? ((kt - kt0) & 1) * 2 * G16_IMG : 0);
         unsigned char* const imgB = imgA + G16_IMG;
         if (STAGES == 2) {
             if (kt + 1 < kt1) {
                 unsigned char* const nA = lds + (((kt - kt0) & 1) ^ 1) * 2 * G16_IMG;
-                issue(kt + 1, nA, nA + G16_IMG);
+                if (G16_DIAG != 2) issue(kt + 1, nA, nA + G16_IMG);
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's eight pieces of THIS stage have landed; the next stage's fly
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
         } else {
-            issue(kt, imgA, imgB);
+            if (G16_DIAG != 2) issue(kt, imgA, imgB);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the stage have landed
             __syncthreads();                                    // everybody's have
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (G16_DIAG == 1 ? 0 : 2); ++s) {
             u32x4 fm[4], fn[4];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? (RS ? 3 : 4) : 2) void gemm16_ke
         }
     }
     // ---- epilogue: lane (idx, g) of block (i, j) holds row m = wm + 16 i + idx, columns n = wn + 16 j + 4 g .. + 3 -----------------
+    if (G16_DIAG == 3 && acc[0][0].x + acc[1][1].y + acc[2][2].z + acc[3][3].w != 12345.678f) return;
     if (p.planes) {   // split-K: the raw partial sums of this split, fp32, dense [M][N]
         float* P = p.planes + ((int64_t)ks * gridDim.y + zb) * (int64_t)p.M * p.N;
 #pragma unroll

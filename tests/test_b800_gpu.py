@@ -162,38 +162,36 @@ def test_stress_config_200_queries_fp32_and_fp8_attention():
     assert float((d8["pred_logits"] - d["pred_logits"]).abs().max()) > 0   # (the fp8 path really ran)
 
 
-FP8_TRAIN_LOSS, FP8_TRAIN_COS, FP8_TRAIN_NORM, FP8_TENSOR_COS = 5e-2, 0.99, 0.15, 0.95
-
-
-def test_stress_config_training_step_with_fp8_attention_against_the_oracle():
+def test_stress_config_training_step_under_the_fp8_switch_against_the_oracle():
     """BASELINE.json configs[4] as a TRAINING step at a size the oracle finishes in seconds: one 5-frame episode of 256 x 256
     frames, NUM_QUERIES = 200 (fusion T = 5 (256 + 200) + 5 = 2285), the whole meta-train step of models/interactron.py:61-151
-    with the opt-in fp8 attention products on (``hipops.ATTENTION_DTYPE = "fp8"``: e4m3 MFMA in the forward products of every
-    attention call; the derivative kernels take their own fp16 normalisers, csrc/flash.hip) against the float32 CPU oracle:
-    every loss within 5 %, the WHOLE gradient (all tensors as one vector) within cosine >= 0.99 of the oracle's and every single tensor
-    >= 0.95 (measured worst 0.984, on the 2 560-element fusion.action_tokens that only the policy loss reaches), norms within 15 %
-    (e4m3 has 3 mantissa bits: 6 % element error on the probabilities).  The fp32-grade path on the same inputs meets the usual bounds."""
+    against the float32 CPU oracle -- every loss, every gradient tensor's norm and direction (cosine >= 0.999) -- and then once more
+    with ``hipops.ATTENTION_DTYPE = "fp8"``: a training step differentiates every attention call, differentiated calls keep the
+    fp32-grade forward (hipops/attn.py flash_forward), so the step under the switch is the SAME step, loss for loss and gradient norm
+    for gradient norm.  History (round 6, profiles/r6k_16_bit_step_survey.txt): with the e4m3 forward products left on in
+    differentiated calls this test measured whole-gradient cosine 0.175 against the oracle and backbone gradient norms 30-40 x too
+    large, at losses within 3.5 % -- the forward was fine and the derivative passes were fine, their combination was not
+    (tests/test_ops_gpu.py::test_fp8_attention_is_for_calls_that_are_not_differentiated has the arithmetic).  fp8 is a predict-time
+    option (test_stress_config_200_queries_fp32_and_fp8_attention, test_stress_config_full_size_predict_properties)."""
     import __graft_entry__ as entry
     from interactron_amd import hipops
     extra = dict(NUM_QUERIES=200, BLOCK_SIZE=5 * (16 * 16 + 200) + 5)
-    # (200 near-identical queries on RNG-free weights: the Hungarian optimum is full of ties -- both runs take the oracle's assignments)
-    # (fp32-grade run: 1e-2 on the norms without the float64 slack run -- the first trainable convolution sits at 7e-3 here, as in the
-    #  128 x 128 smoke step before its slack is counted; the point of this test is the fp8 run below)
-    # (losses at the fp8 bound for both runs: with 200 near-identical queries an image presented to several criterion calls may take
-    #  another call's recorded assignment -- a tie for the matcher, not for the loss of THAT call)
-    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=1e-2, loss_tol=FP8_TRAIN_LOSS, pin_matching="ties")
+    # (200 near-identical queries on RNG-free weights: the Hungarian optimum is full of ties -- the runs take the oracle's assignments)
+    # (1e-2 on the norms without the float64 slack run -- the first trainable convolution sits at 7e-3 here, as in the 128 x 128 smoke
+    #  step before its slack is counted; losses at 5 %: with 200 near-identical queries an image presented to several criterion calls
+    #  may take another call's recorded assignment -- a tie for the matcher, not for the loss of THAT call)
+    ref = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=1e-2, loss_tol=5e-2, cos_min=0.999, pin_matching="ties")
+    assert ref["whole_gradient_cosine"] >= 0.9999, ref["whole_gradient_cosine"]
     assert hipops.ATTENTION_DTYPE == "fp32"
     hipops.ATTENTION_DTYPE = "fp8"
     try:
-        got = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=FP8_TRAIN_NORM, loss_tol=FP8_TRAIN_LOSS,
-                                cos_min=FP8_TENSOR_COS, pin_matching="always")
-        print("fp8 training step: whole-gradient cosine %.5f, worst tensor %.4f on %s, loss deviations %s"
-              % ((got["whole_gradient_cosine"],) + got["worst_cosine"] + ({k: round(v, 4) for k, v in got["loss_deviations"].items()},)))
-        assert got["whole_gradient_cosine"] >= FP8_TRAIN_COS, got["whole_gradient_cosine"]
+        got = entry.smoke_check(256, cfg_extra=extra, f64_slack=False, norm_tol=1e-2, loss_tol=5e-2, cos_min=0.999, pin_matching="ties")
     finally:
         hipops.ATTENTION_DTYPE = "fp32"
-    assert got["checked"] >= 300
-    assert any(got["norms"][k] != ref["norms"][k] for k in ref["norms"])   # (the fp8 products really ran)
+    assert got["checked"] == ref["checked"] >= 300
+    for part in ("losses", "norms"):   # (1e-5: the step is the same sequence of launches)
+        for k, v in ref[part].items():
+            assert abs(got[part][k] - v) <= 1e-5 * max(abs(v), 1e-6), (k, got[part][k], v, "a training step changed under ATTENTION_DTYPE = fp8")
 
 
 def test_stress_config_full_size_predict_properties():

@@ -1555,45 +1555,48 @@ def test_flash_forward_fp8(ops, n, H, L, S, hd, masked):
 
 @pytest.mark.parametrize("hd", [64, 32])
 @pytest.mark.usefixtures("flash_form")
-def test_flash_fp8_forward_with_the_derivative_passes_of_either_family(ops, hd):
-    """ATTENTION_DTYPE = fp8 in a differentiated call (BASELINE.json configs[4] as a training step): the forward products run on
-    e4m3 operands, the derivative passes -- first and second order, the 16 x 16 family at head dim 64 or the 32 x 32 family
-    (``flash_form``) -- recompute the probabilities from the fp16 planes with normalisers of THEIR scores (an lse-only pass of the
-    32 x 32 forward kernel; the same fp16x3 products in another accumulation order than flash16's, so consistent to fp32
-    rounding, not bit for bit).  What the fp8 forward leaves in the gradients is its output through delta = dO . O.  Against
-    float64 autograd: everything finite, forward within the fp8 forward's 7 % relative L2, gradients within 3 %, second-order
-    cotangents within 2 % (measured r6a: forward 5.5 %, gradients <= 1.1 %, second order <= 0.6 %; printed)."""
+def test_fp8_attention_is_for_calls_that_are_not_differentiated(ops, hd):
+    """ATTENTION_DTYPE = fp8 (BASELINE.json configs[4]) applies to calls without a derivative (predict); a differentiated call runs the
+    fp32-grade forward, bit for bit the one of ATTENTION_DTYPE = fp32, and so keeps its first- and second-order parity (hipops/attn.py
+    flash_forward).  The reason is checked here as arithmetic, on keys that share a large common component like DETR's biased key
+    projections do (k = noise + 4): with delta_i = dO_i . O_i taken from an output of OTHER probabilities than the derivative pass
+    recomputes, sum_j dS_ij != 0 and dq_i picks up (delta error) x (the mean key) -- on these operands the fp8 forward's 5 % output
+    error becomes > 30 % of dq (float64 model of exactly that substitution), where the fp32-grade output leaves < 0.1 %."""
     n, H, L, S = 1, 4, 300, 517
     E = H * hd
-    q, k, v = rnd(n, L, E, seed=21), rnd(n, S, E, seed=22), rnd(n, S, E, seed=23)
+    q, k, v = rnd(n, L, E, seed=21), rnd(n, S, E, seed=22) + 4.0, rnd(n, S, E, seed=23)
     scale = 1.0 / math.sqrt(hd)
     g = ops.AttnGeom(n, H, L, S, hd, E, E, 0, 0, E, 0, scale)
     gy = rnd(n, L, E, seed=25)
-    ws = [rnd(n, L, E, seed=26), rnd(n, S, E, seed=27), rnd(n, S, E, seed=28)]
 
-    def second(dev, dt, fn):
-        x = [t.to(dev, dt).requires_grad_(True) for t in (q, k, v)]
-        gyd = gy.to(dev, dt).requires_grad_(True)
-        out = fn(*x)
-        g1 = torch.autograd.grad(out, x, gyd, create_graph=True)
-        s = sum((a * w.to(dev, dt)).sum() for a, w in zip(g1, ws))
-        return out, g1, torch.autograd.grad(s, x + [gyd])
+    def run(dtype, grad):
+        old, ops.ATTENTION_DTYPE = ops.ATTENTION_DTYPE, dtype
+        try:
+            x = [t.cuda().requires_grad_(grad) for t in (q, k, v)]
+            out = ops.FlashAttention.apply(*x, g, None, 0.0, 0)
+            return out, (torch.autograd.grad(out, x, gy.cuda()) if grad else None)
+        finally:
+            ops.ATTENTION_DTYPE = old
 
-    old, ops.ATTENTION_DTYPE = ops.ATTENTION_DTYPE, "fp8"
-    try:
-        oh, g1h, g2h = second("cuda", torch.float32, lambda a, b, c: ops.FlashAttention.apply(a, b, c, g, None, 0.0, 0))
-    finally:
-        ops.ATTENTION_DTYPE = old
-    orf, g1r, g2r = second("cpu", torch.float64, lambda a, b, c: _ref_attention_drop(a, b, c, H, scale, None, None))
-    rel = lambda a, b: float((a.detach().cpu().double() - b).norm() / b.norm())
-    errs = [("forward", rel(oh, orf), 0.07)] + [("grad " + nm, rel(a, b), 0.03) for nm, a, b in zip("qkv", g1h, g1r)] + \
-        [("second-order " + nm, rel(a, b), 0.02) for nm, a, b in zip(["q", "k", "v", "dO"], g2h, g2r)]
-    print("fp8 forward + fp16 derivative passes, head dim %d: " % hd + ", ".join("%s %.3f" % (nm, e) for nm, e, _ in errs))
-    for t in [oh] + list(g1h) + list(g2h):
-        assert bool(torch.isfinite(t).all())
-    for nm, e, bound in errs:
-        assert e <= bound, (nm, e, bound)
-    assert errs[0][1] > 1e-3   # (the fp8 products really ran)
+    o32, g32 = run("fp32", True)
+    o8g, g8g = run("fp8", True)
+    assert torch.equal(o32, o8g) and all(torch.equal(a, b) for a, b in zip(g32, g8g))   # differentiated: the switch changes nothing
+    o8, _ = run("fp8", False)
+    o32n, _ = run("fp32", False)
+    rel = lambda a, b: float((a.detach().cpu().double() - b.detach().cpu().double()).norm() / b.detach().cpu().double().norm())
+    assert 1e-3 < rel(o8, o32n) < 0.07, rel(o8, o32n)   # not differentiated: the e4m3 products ran, within their stated 7 %
+    # the float64 model: dq with delta from (a) the exact output, (b) the fp8 output, (c) the fp32-grade output
+    qd, kd, vd, gyd = [t.double().view(n, -1, H, hd).transpose(1, 2) for t in (q, k, v, gy)]
+    P = torch.softmax(scale * qd @ kd.transpose(-1, -2), -1)
+    dP = gyd @ vd.transpose(-1, -2)
+    heads = lambda o: o.detach().cpu().double().view(n, L, H, hd).transpose(1, 2)
+    dq = lambda o: scale * (P * (dP - (gyd * o).sum(-1, keepdim=True))) @ kd
+    exact = dq(P @ vd)
+    e8, e32 = float((dq(heads(o8)) - exact).norm() / exact.norm()), float((dq(heads(o32n)) - exact).norm() / exact.norm())
+    print("head dim %d: dq with delta from the fp8 output %.3f off, from the fp32-grade output %.2e off; the kernels' dq %.2e off"
+          % (hd, e8, e32, rel(g32[0].view(n, L, H, hd).transpose(1, 2), exact)))
+    assert e8 > 0.3 and e32 < 1e-3, (e8, e32)
+    assert rel(g32[0].view(n, L, H, hd).transpose(1, 2), exact) < 1e-3
 
 
 def test_sustained_mfma_rate_probe(ops):
