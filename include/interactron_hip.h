@@ -459,6 +459,9 @@ int ix_gemm_rowsum_b16(const void* A, const void* B, float* C, float* rowsum, in
                        int batch_outer, int64_t sAo, int64_t sBo, int64_t sCo, int64_t rowsum_stride, float alpha, void* workspace,
                        size_t workspace_bytes, ix_stream_t stream); /* C = alpha A B (fp32) and rowsum[b][m] = sum_k A(m, k), A m-contiguous,
                        B n-contiguous: a Linear's weight gradient dY^T x with its bias gradient riding on it (the fp32 twin: ix_gemm_rowsum_f32) */
+int ix_gemm_b16_set_big(int on);  /* the 256 x 256-tile form of the kernel (one eight-wave workgroup per CU, two 64 KB LDS stages): 1 (default)
+                                     where the launch still fills the chip | 0 never | 2 for every plain contraction (tests) | < 0 query;
+                                     returns the previous setting (IX_GEMM16_BIG) */
 int ix_gemm_b16_set_stages(int stages); /* 1: one LDS stage, four workgroups per CU | 2: two stages, the next K step's DMA under this one's
                                            matrix instructions; returns the previous setting (IX_GEMM16_STAGES) */
 /*   ix_conv_gemm_b16 : the three implicit-GEMM convolution kinds of ix_conv_gemm_f32 (forward, data gradient, weight gradient of a

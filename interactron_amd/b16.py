@@ -54,6 +54,15 @@ def cast_b16(x):
     return y
 
 
+def cast_b16_into(x, y):
+    """fp32 -> bf16 into an existing tensor of the same element count (the flat parameter shadow, trainer.FlatBuffers.sync_b16)"""
+    x = ops._req(x)
+    assert y.dtype == B16 and y.numel() == x.numel() and y.is_contiguous() and x.is_contiguous()
+    ops._chk(ops._L().ix_cast_f32_b16(x.data_ptr(), y.data_ptr(), x.numel(), ops._stream()), "ix_cast_f32_b16")
+    _seen[0] = True
+    return y
+
+
 def cast_f32(x):
     x = _reqd(x)
     if x.dtype == torch.float32:
@@ -132,11 +141,17 @@ _stats = {"weight_casts": 0, "native_gemms": 0, "fallback_gemms": 0}
 def weight_b16(w):
     if w.dtype == B16:
         return w
+    fl = w.__dict__.get("_ix_b16_flat")   # a trainable parameter's view of the flat bf16 shadow (trainer.FlatBuffers.sync_b16)
+    if fl is not None and fl[1] == ops._wp_epoch[0] and fl[2] == w._version and fl[3] == w.data_ptr():
+        return fl[0]
     cap = ops._capture[0]
     if cap is not None:
         store, tag = cap, ("b16", ops._scratch_slot[0], id(w), ops._wp_epoch[0])
     else:
-        store, tag = w.__dict__.setdefault("_ix_b16", {}), ops._wp_epoch[0]
+        # (the epoch moves with every raw-pointer update of the TRAINABLE parameters -- the optimiser step; a frozen parameter changes only
+        #  through copy_ / load_state_dict, which its version counter sees: it is not converted again after every step)
+        frozen = isinstance(w, torch.nn.Parameter) and not w.requires_grad
+        store, tag = w.__dict__.setdefault("_ix_b16", {}), (-1 if frozen else ops._wp_epoch[0])
         if len(store) > 2:
             store.clear()
     hit = store.get(tag)

@@ -79,6 +79,7 @@ struct G16Args {
     int M, N, K, nk, kps, split, tiles_m, tiles_n, batch_inner;
     float alpha;
     int act;                // 0 none, 1 ReLU, 2 GELU (tanh-free erf form, as F.gelu)
+    int cst;                // bf16 C (and residual) rows start on 16 bytes: the epilogue stores whole row pieces through LDS
 };
 
 __device__ __forceinline__ int g16_xcd_swizzle(int bid, int nwg) {
@@ -339,6 +340,87 @@ __global__ __launch_bounds__(256, STAGES == 1 ? (RS ? 3 : 4) : 2) void gemm16_ke
     }
     const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
     const int64_t cbase = bo * p.sCo + bi * p.sCi;
+    if (!F32OUT && p.cst) {
+        // bf16 result, rows of C on 16 bytes: through the (now free) LDS stage, so that HBM sees whole 256-byte row pieces instead of the
+        // matrix instruction's layout (a lane holds 4 consecutive n: 8-byte stores, a wave instruction = sixteen 32-byte pieces of sixteen
+        // rows -- measured round 6, `make diag16`: the stores were 6 of the 14.5 ms of the step's Linear shapes)
+        unsigned short* const Cb = (unsigned short*)p.C + cbase;
+        if (!p.res) {
+            // the finished tile as bf16 [128 rows][256 B], 16-byte chunks XOR-swizzled with the row (& 15: = idx for every block)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn + 16 * j + 4 * g;
+                if (n >= p.N) continue;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+                if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+                const int chunk = (((wn >> 3) + 2 * j + (g >> 1)) ^ idx) << 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 v = (acc[i][j] * p.alpha + bv) * sc + sh;
+                    v.x = g16_act(v.x, p.act); v.y = g16_act(v.y, p.act); v.z = g16_act(v.z, p.act); v.w = g16_act(v.w, p.act);
+                    *reinterpret_cast<u32x2*>(lds + (wm + 16 * i + idx) * 256 + chunk + (g & 1) * 8) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = q * 16 + (tid >> 4), c = tid & 15;
+                const int m = m0 + row, n = n0 + c * 8;
+                if (m >= p.M || n >= p.N) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * 256 + ((c ^ (row & 15)) << 4));
+                unsigned short* dst = Cb + (int64_t)m * p.ldc + n;
+                if (n + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = v;
+                else *reinterpret_cast<u32x2*>(dst) = u32x2{v.x, v.y};   // (N % 4 == 0)
+            }
+        } else {
+            // with a residual: the pre-residual values stay fp32 (one rounding, at the end) -- two halves of 64 rows x 512 B
+            const unsigned short* const Rb = (const unsigned short*)p.res + cbase;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((wave >> 1) == h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn + 16 * j + 4 * g;
+                        if (n >= p.N) continue;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+                        if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+                        const int chunk = (((wn >> 2) + 4 * j + g) ^ idx) << 4;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            *reinterpret_cast<f32x4*>(lds + (16 * i + idx) * 512 + chunk) = (acc[i][j] * p.alpha + bv) * sc + sh;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = q * 16 + (tid >> 4), c = tid & 15;
+                    const int m = m0 + 64 * h + row, n = n0 + c * 8;
+                    if (m < p.M && n < p.N) {
+                        const unsigned char* src = lds + row * 512;
+                        f32x4 a = *reinterpret_cast<const f32x4*>(src + (((2 * c) ^ (row & 15)) << 4));
+                        f32x4 b = *reinterpret_cast<const f32x4*>(src + (((2 * c + 1) ^ (row & 15)) << 4));
+                        const int64_t o = (int64_t)m * p.ldc + n;
+                        const bool full = n + 8 <= p.N;
+                        u32x4 r = {0u, 0u, 0u, 0u};
+                        if (full) r = *reinterpret_cast<const u32x4*>(Rb + o);
+                        else { const u32x2 r2 = *reinterpret_cast<const u32x2*>(Rb + o); r.x = r2.x; r.y = r2.y; }
+                        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
+                        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
+                        b.x += __uint_as_float(r.z << 16); b.y += __uint_as_float(r.z & 0xffff0000u);
+                        b.z += __uint_as_float(r.w << 16); b.w += __uint_as_float(r.w & 0xffff0000u);
+                        a.x = g16_act(a.x, p.act); a.y = g16_act(a.y, p.act); a.z = g16_act(a.z, p.act); a.w = g16_act(a.w, p.act);
+                        b.x = g16_act(b.x, p.act); b.y = g16_act(b.y, p.act); b.z = g16_act(b.z, p.act); b.w = g16_act(b.w, p.act);
+                        if (full) *reinterpret_cast<u32x4*>(Cb + o) = u32x4{g16_pack2(a.x, a.y), g16_pack2(a.z, a.w), g16_pack2(b.x, b.y), g16_pack2(b.z, b.w)};
+                        else *reinterpret_cast<u32x2*>(Cb + o) = u32x2{g16_pack2(a.x, a.y), g16_pack2(a.z, a.w)};
+                    }
+                }
+                if (h == 0) __syncthreads();
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn + 16 * j + 4 * g;
@@ -348,6 +430,270 @@ __global__ __launch_bounds__(256, STAGES == 1 ? (RS ? 3 : 4) : 2) void gemm16_ke
         if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m >= p.M) continue;
+            const int64_t o = cbase + (int64_t)m * p.ldc + n;
+            f32x4 v = (acc[i][j] * p.alpha + bv) * sc + sh;
+            if (p.res) {
+                if (F32OUT) v += *reinterpret_cast<const f32x4*>((const float*)p.res + o);
+                else {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>((const unsigned short*)p.res + o);
+                    v.x += __uint_as_float(r.x << 16); v.y += __uint_as_float(r.x & 0xffff0000u);
+                    v.z += __uint_as_float(r.y << 16); v.w += __uint_as_float(r.y & 0xffff0000u);
+                }
+            }
+            v.x = g16_act(v.x, p.act); v.y = g16_act(v.y, p.act); v.z = g16_act(v.z, p.act); v.w = g16_act(v.w, p.act);
+            if (F32OUT) *reinterpret_cast<f32x4*>((float*)p.C + o) = v;
+            else *reinterpret_cast<u32x2*>((unsigned short*)p.C + o) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
+        }
+    }
+}
+
+// ---- the 256 x 256 tile form (round 6) ----------------------------------------------------------------------------------------------
+// `make diag16` on the 128 x 128 kernel: operand traffic L2 -> LDS (2 bytes x (1/128 + 1/128) per multiply-add: 100 GB per step's Linear
+// shapes, ~19 TB/s), the matrix instructions and the stores each cost about a third of a launch and barely overlap.  This form halves
+// the operand traffic (1/256 + 1/256), runs ONE workgroup of eight waves per CU -- each wave 128 x 64 outputs, 128 accumulator
+// registers -- and overlaps the DMA of K step k + 1 with the matrix instructions of K step k inside the workgroup: two 64 KB LDS stages
+// (A rows 0..127, A rows 128..255, B rows 0..127, B rows 128..255: four images in the layouts of the 128 x 128 kernel, each filled by
+// two waves), counted vmcnt, raw barriers.  Taken for plain operands where it measured faster (g16_use_big).
+constexpr int GB_T = 256;
+constexpr int GB_STAGE = 4 * G16_IMG;
+
+template <bool A_KC, bool B_KC, bool F32OUT, bool RS>
+__global__ __launch_bounds__(512, 1) void gemm16_big_kernel(G16Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // 2 x GB_STAGE
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, g = lane >> 4;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int tile = g16_xcd_swizzle(blockIdx.x, nwg);
+    constexpr int GROUP_M = 8;
+    const int group_size = GROUP_M * p.tiles_n;
+    const int first_m = (tile / group_size) * GROUP_M;
+    const int gm = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (tile % group_size) % gm, tn = (tile % group_size) / gm;
+    const int m0 = tm * GB_T, n0 = tn * GB_T;
+    const int zb = blockIdx.y, bo = zb / p.batch_inner, bi = zb - bo * p.batch_inner;
+    const int ks = blockIdx.z;
+    const int kt0 = ks * p.kps, kt1 = min(p.nk, kt0 + p.kps);
+    const unsigned short* A = p.A + bo * p.sAo + bi * p.sAi;
+    const unsigned short* B = p.B + bo * p.sBo + bi * p.sBi;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, p.extA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, p.extB, 0x00020000);
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64, wnl = wn & 127;
+
+    // ---- DMA: waves 2 h, 2 h + 1 fill image h (0, 1: A rows 0..127 / 128..255; 2, 3: B likewise), eight pieces of 64 slots each --------
+    const int img = wave >> 1;
+    const bool isA = img < 2;   // (wave-uniform)
+    const int rbase = (isA ? m0 : n0) + 128 * (img & 1);
+    int vo[8], kk[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int slot = ((wave & 1) * 8 + q) * 64 + lane;
+        const bool kc = isA ? A_KC : B_KC;
+        const int ld = isA ? (int)p.lda : (int)p.ldb, lim = isA ? p.M : p.N;
+        if (kc) {
+            const int row = slot >> 3, c = (slot & 7) ^ ((row >> 1) & 7);
+            vo[q] = (min(rbase + row, lim - 1) * ld + c * 8) * 2;
+            kk[q] = c * 8;
+        } else {
+            const int kr = slot >> 4, u = (slot & 15) ^ (2 * ((kr & 3) + 4 * ((kr >> 3) & 1)));
+            vo[q] = (kr * ld + rbase + u * 8) * 2;
+            kk[q] = kr;
+        }
+    }
+    const int stepA = A_KC ? G16_BK * 2 : G16_BK * (int)p.lda * 2;
+    const int stepB = B_KC ? G16_BK * 2 : G16_BK * (int)p.ldb * 2;
+    const int step = isA ? stepA : stepB;
+
+    const int swz = (idx >> 1) & 7;
+    const int kc0 = ((g ^ swz) << 4), kc1 = (((4 + g) ^ swz) << 4);
+    const int trk = (8 * g + (idx >> 2)) * 256 + 8 * (idx & 1);
+    const int trf = 2 * ((idx >> 2) + 4 * (g & 1));
+    const int tru0 = (idx & 3) >> 1;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool rs_here = RS && tn == 0 && wn == 0;
+
+    auto issue = [&](int kt, unsigned char* stage) {
+        unsigned char* d = stage + img * G16_IMG + (wave & 1) * 8192;
+        const int klim = p.K - kt * G16_BK;
+        const int so = kt * step;
+        if (isA) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g16_dma16(rA, kk[q] < klim ? vo[q] : G16_OOB, so, d + q * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) g16_dma16(rB, kk[q] < klim ? vo[q] : G16_OOB, so, d + q * 1024);
+        }
+    };
+    issue(kt0, lds);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        unsigned char* const stage = lds + ((kt - kt0) & 1) * GB_STAGE;
+        if (kt + 1 < kt1) {
+            issue(kt + 1, lds + (((kt - kt0) & 1) ^ 1) * GB_STAGE);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's eight pieces of THIS stage have landed; the next stage's fly
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* const imgA = stage + (wm >> 7) * G16_IMG;
+        const unsigned char* const imgB = stage + (2 + (wn >> 7)) * G16_IMG;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 fn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (B_KC) {
+                    fn[j] = *reinterpret_cast<const u32x4*>(imgB + (wnl + idx) * 128 + j * 2048 + (s ? kc1 : kc0));
+                } else {
+                    const unsigned char* b0 = imgB + trk + s * 8192 + ((((wnl >> 3) + tru0 + 2 * j) ^ trf) << 4);
+                    const u32x2 lo = g16_tr(b0), hi = g16_tr(b0 + 4 * 256);
+                    fn[j] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u32x4 fm;
+                if (A_KC) {
+                    fm = *reinterpret_cast<const u32x4*>(imgA + idx * 128 + i * 2048 + (s ? kc1 : kc0));
+                } else {
+                    const unsigned char* b0 = imgA + trk + s * 8192 + (((tru0 + 2 * i) ^ trf) << 4);
+                    const u32x2 lo = g16_tr(b0), hi = g16_tr(b0 + 4 * 256);
+                    fm = u32x4{lo.x, lo.y, hi.x, hi.y};
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fn[j]), __builtin_bit_cast(bf16x8, fm), acc[i][j], 0, 0, 0);
+                if (RS && rs_here) {   // (wave-uniform)
+                    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                    accr[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, fm), accr[i], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // everybody has read this stage: the DMA of K step kt + 2 may overwrite it
+    }
+
+    if (RS && rs_here && g == 0) {
+        float* R = p.rs_planes ? p.rs_planes + ((int64_t)ks * gridDim.y + zb) * p.M : p.rowsum + bo * p.sRowsum;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m < p.M) R[m] = accr[i].x;
+        }
+    }
+    // ---- epilogue: lane (idx, g) of block (i, j) holds row m = wm + 16 i + idx, columns n = wn + 16 j + 4 g .. + 3 -----------------
+    if (p.planes) {
+        float* P = p.planes + ((int64_t)ks * gridDim.y + zb) * (int64_t)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm + 16 * i + idx;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn + 16 * j + 4 * g;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(P + (int64_t)m * p.N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    const float* bias = p.bias ? p.bias + bo * p.sBias : nullptr;
+    const int64_t cbase = bo * p.sCo + bi * p.sCi;
+    if (!F32OUT && p.cst) {
+        unsigned short* const Cb = (unsigned short*)p.C + cbase;
+        if (!p.res) {
+            // the finished tile as bf16 [256 rows][512 B] over both stages, 16-byte chunks XOR-swizzled with the row (& 15)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn + 16 * j + 4 * g;
+                if (n >= p.N) continue;
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+                if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+                const int chunk = (((wn >> 3) + 2 * j + (g >> 1)) ^ idx) << 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v = (acc[i][j] * p.alpha + bv) * sc + sh;
+                    v.x = g16_act(v.x, p.act); v.y = g16_act(v.y, p.act); v.z = g16_act(v.z, p.act); v.w = g16_act(v.w, p.act);
+                    *reinterpret_cast<u32x2*>(lds + (wm + 16 * i + idx) * 512 + chunk + (g & 1) * 8) = u32x2{g16_pack2(v.x, v.y), g16_pack2(v.z, v.w)};
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = q * 16 + (tid >> 5), c = tid & 31;
+                const int m = m0 + row, n = n0 + c * 8;
+                if (m >= p.M || n >= p.N) continue;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * 512 + ((c ^ (row & 15)) << 4));
+                unsigned short* dst = Cb + (int64_t)m * p.ldc + n;
+                if (n + 8 <= p.N) *reinterpret_cast<u32x4*>(dst) = v;
+                else *reinterpret_cast<u32x2*>(dst) = u32x2{v.x, v.y};
+            }
+        } else {
+            // with a residual: fp32 pre-residual values, two halves of 128 rows x 1024 B
+            const unsigned short* const Rb = (const unsigned short*)p.res + cbase;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if ((wave >> 2) == h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn + 16 * j + 4 * g;
+                        if (n >= p.N) continue;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+                        if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+                        const int chunk = (((wn >> 2) + 4 * j + g) ^ idx) << 4;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            *reinterpret_cast<f32x4*>(lds + (16 * i + idx) * 1024 + chunk) = (acc[i][j] * p.alpha + bv) * sc + sh;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = q * 16 + (tid >> 5), c = tid & 31;
+                    const int m = m0 + 128 * h + row, n = n0 + c * 8;
+                    if (m < p.M && n < p.N) {
+                        const unsigned char* src = lds + row * 1024;
+                        f32x4 a = *reinterpret_cast<const f32x4*>(src + (((2 * c) ^ (row & 15)) << 4));
+                        f32x4 b = *reinterpret_cast<const f32x4*>(src + (((2 * c + 1) ^ (row & 15)) << 4));
+                        const int64_t o = (int64_t)m * p.ldc + n;
+                        const bool full = n + 8 <= p.N;
+                        u32x4 r = {0u, 0u, 0u, 0u};
+                        if (full) r = *reinterpret_cast<const u32x4*>(Rb + o);
+                        else { const u32x2 r2 = *reinterpret_cast<const u32x2*>(Rb + o); r.x = r2.x; r.y = r2.y; }
+                        a.x += __uint_as_float(r.x << 16); a.y += __uint_as_float(r.x & 0xffff0000u);
+                        a.z += __uint_as_float(r.y << 16); a.w += __uint_as_float(r.y & 0xffff0000u);
+                        b.x += __uint_as_float(r.z << 16); b.y += __uint_as_float(r.z & 0xffff0000u);
+                        b.z += __uint_as_float(r.w << 16); b.w += __uint_as_float(r.w & 0xffff0000u);
+                        a.x = g16_act(a.x, p.act); a.y = g16_act(a.y, p.act); a.z = g16_act(a.z, p.act); a.w = g16_act(a.w, p.act);
+                        b.x = g16_act(b.x, p.act); b.y = g16_act(b.y, p.act); b.z = g16_act(b.z, p.act); b.w = g16_act(b.w, p.act);
+                        if (full) *reinterpret_cast<u32x4*>(Cb + o) = u32x4{g16_pack2(a.x, a.y), g16_pack2(a.z, a.w), g16_pack2(b.x, b.y), g16_pack2(b.z, b.w)};
+                        else *reinterpret_cast<u32x2*>(Cb + o) = u32x2{g16_pack2(a.x, a.y), g16_pack2(a.z, a.w)};
+                    }
+                }
+                if (h == 0) __syncthreads();
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn + 16 * j + 4 * g;
+        if (n >= p.N) continue;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+        if (p.scale) { sc = *reinterpret_cast<const f32x4*>(p.scale + n); sh = *reinterpret_cast<const f32x4*>(p.shift + n); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
             const int m = m0 + wm + 16 * i + idx;
             if (m >= p.M) continue;
             const int64_t o = cbase + (int64_t)m * p.ldc + n;
@@ -429,10 +775,61 @@ static void g16_plan(int M, int N, int K, int nbatch, int* split, int* kps) {
     *split = ix_div_up(nk, per);
 }
 
+// the 256 x 256 form: one workgroup per CU -- a launch of fewer than ~256 tiles with a long K is cut along K
+static void g16_plan_big(int M, int N, int K, int nbatch, int* split, int* kps) {
+    const int nk = ix_div_up(K, G16_BK);
+    const int64_t tiles = (int64_t)ix_div_up(M, GB_T) * ix_div_up(N, GB_T) * nbatch;
+    int s = 1;
+    if (tiles < 192 && nk >= 8) {
+        s = (int)((256 + tiles - 1) / tiles);
+        if (s > nk / 4) s = nk / 4;
+        if (s > 64) s = 64;
+        const int64_t plane = (int64_t)M * N * nbatch * 4;
+        const int cap = (int)((24ll << 20) / (plane > 0 ? plane : 1));
+        if (s > cap) s = cap;
+        if (s < 1) s = 1;
+    }
+    const int per = ix_div_up(nk, s);
+    *kps = per;
+    *split = ix_div_up(nk, per);
+}
+// 1 (default): where g16_use_big says | 0: never | 2: for every plain contraction (tests) -- ix_gemm_b16_set_big / IX_GEMM16_BIG
+static int g_g16_big = -1;
+static int g16_big() {
+    if (g_g16_big < 0) {
+        const char* e = getenv("IX_GEMM16_BIG");
+        g_g16_big = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+    }
+    return g_g16_big;
+}
+extern "C" int ix_gemm_b16_set_big(int on) {
+    const int old = g16_big();
+    if (on >= 0) g_g16_big = on > 2 ? 1 : on;
+    return old;
+}
+// plain operands whose launch in 256 x 256 tiles still gives (nearly) every CU a workgroup
+static bool g16_use_big(int M, int N, int K, int nbatch, bool conv) {
+    if (!g16_big() || conv) return false;
+    if (g16_big() == 2) return true;
+    if (M < 192 || N < 192 || K < 128) return false;
+    // measured (r6o, the step's Linear shapes): the form wins 5-15 % where ITS launch is one round of workgroups cut along K (weight
+    // gradients, N = 256 layers with K >= 1024) and loses 20-40 % where it takes several rounds -- one workgroup per CU leaves a tile's
+    // stores and the next tile's first loads uncovered, which four 128 x 128 workgroups per CU overlap
+    int split, kps;
+    g16_plan_big(M, N, K, nbatch, &split, &kps);
+    const int64_t tiles = (int64_t)ix_div_up(M, GB_T) * ix_div_up(N, GB_T) * nbatch;
+    return tiles < 192 && tiles * split >= 200;
+}
+
 extern "C" int ix_workspace_bytes_gemm_b16(int M, int N, int K, int nbatch, size_t* out) {
     IX_CHECK_ARG(out && M >= 0 && N >= 0 && K >= 0 && nbatch >= 0, "ix_workspace_bytes_gemm_b16: bad args");
     int split = 1, kps = 1;
-    if (M > 0 && N > 0 && K > 0 && nbatch > 0) g16_plan(M, N, K, nbatch, &split, &kps);
+    if (M > 0 && N > 0 && K > 0 && nbatch > 0) {
+        g16_plan(M, N, K, nbatch, &split, &kps);
+        int sb = 1, kb = 1;
+        g16_plan_big(M, N, K, nbatch, &sb, &kb);   // (either form may run: ix_gemm_b16_set_big)
+        if (sb > split) split = sb;
+    }
     // (+ M floats per plane: the partial row sums of ix_gemm_rowsum_b16 ride in the same scratch)
     *out = split > 1 ? IX_TICKET_BYTES + (size_t)split * (size_t)nbatch * ((size_t)M * (size_t)N + (size_t)M) * sizeof(float) : 0;
     return IX_OK;
@@ -468,13 +865,26 @@ extern "C" int ix_gemm_b16_set_stages(int stages) {
     return old;
 }
 
+// IX_GEMM16_CST=0: the epilogue stores from the matrix instruction's layout, as before round 6's LDS pass (A/B runs)
+static int g16_coalesced_stores() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("IX_GEMM16_CST"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
+
 // plan + launch (+ the split-K tail) of a prepared argument block: the plain contraction and the three convolution kinds share it
 static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void* workspace, size_t workspace_bytes, hipStream_t stream,
                    const char* name) {
     const int M = a.M, N = a.N, K = a.K;
     a.nk = ix_div_up(K, G16_BK);
-    g16_plan(M, N, K, nbatch, &a.split, &a.kps);
-    a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN);
+    const bool big = g16_use_big(M, N, K, nbatch, a.cg.mode != 0) && g16_stages() == 1;
+    if (big) {
+        g16_plan_big(M, N, K, nbatch, &a.split, &a.kps);
+        a.tiles_m = ix_div_up(M, GB_T); a.tiles_n = ix_div_up(N, GB_T);
+    } else {
+        g16_plan(M, N, K, nbatch, &a.split, &a.kps);
+        a.tiles_m = ix_div_up(M, G16_BM); a.tiles_n = ix_div_up(N, G16_BN);
+    }
     a.planes = nullptr;
     a.rs_planes = nullptr;
     if (a.split > 1) {
@@ -486,6 +896,7 @@ static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void*
         }
     }
     IX_CHECK_ARG(nbatch <= 65535 && a.split <= 65535, "%s: too many batch slices", name);
+    a.cst = (!f32 && g16_coalesced_stores() && a.ldc % 8 == 0 && a.sCo % 8 == 0 && a.sCi % 8 == 0 && ix_al16(a.C) && (!a.res || ix_al16(a.res))) ? 1 : 0;
     const dim3 grid(a.tiles_m * a.tiles_n, nbatch, a.split);
     const double bytes = 2.0 * ((double)M * K + (double)K * N) * nbatch + (f32 ? 4.0 : 2.0) * (double)M * N * nbatch;
     ix_prof_begin_b16(stream, M, N, K, nbatch, bytes);
@@ -494,7 +905,24 @@ static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void*
         if (g16_stages() == 2) hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 2>), grid, dim3(256), 0, stream, a);    \
         else hipLaunchKernelGGL((gemm16_kernel<AK, BK_, F, CV, 1>), grid, dim3(256), 0, stream, a);                      \
     } while (0)
-    if (a.rowsum) {   // (the weight gradient of a Linear with its bias gradient: dY m-contiguous, x n-contiguous, fp32 result)
+#define G16_BIG(AK, BK_, F, R)                                                                                                     \
+    do {                                                                                                                           \
+        static bool attr = false;   /* (128 KB of dynamic LDS: allowed once per kernel) */                                         \
+        if (!attr) {                                                                                                               \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_big_kernel<AK, BK_, F, R>),             \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GB_STAGE);                    \
+            IX_CHECK_ARG(e_ == hipSuccess, "%s: 128 KB of LDS per workgroup refused: %s", name, hipGetErrorString(e_));             \
+            attr = true;                                                                                                           \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((gemm16_big_kernel<AK, BK_, F, R>), grid, dim3(512), 2 * GB_STAGE, stream, a);                           \
+    } while (0)
+    if (big) {
+        if (a.rowsum) G16_BIG(false, false, true, true);
+        else if (a_kc && b_kc) { if (f32) G16_BIG(true, true, true, false); else G16_BIG(true, true, false, false); }
+        else if (a_kc && !b_kc) { if (f32) G16_BIG(true, false, true, false); else G16_BIG(true, false, false, false); }
+        else if (!a_kc && b_kc) { if (f32) G16_BIG(false, true, true, false); else G16_BIG(false, true, false, false); }
+        else { if (f32) G16_BIG(false, false, true, false); else G16_BIG(false, false, false, false); }
+    } else if (a.rowsum) {   // (the weight gradient of a Linear with its bias gradient: dY m-contiguous, x n-contiguous, fp32 result)
         hipLaunchKernelGGL((gemm16_kernel<false, false, true, 0, 1, true>), grid, dim3(256), 0, stream, a);
     } else if (a.cg.mode == 1) {
         if (b_kc) { if (f32) G16_LAUNCH(true, true, true, 1); else G16_LAUNCH(true, true, false, 1); }
@@ -506,6 +934,7 @@ static int g16_run(G16Args& a, bool a_kc, bool b_kc, bool f32, int nbatch, void*
     else if (!a_kc && b_kc) { if (f32) G16_LAUNCH(false, true, true, 0); else G16_LAUNCH(false, true, false, 0); }
     else { if (f32) G16_LAUNCH(false, false, true, 0); else G16_LAUNCH(false, false, false, 0); }
 #undef G16_LAUNCH
+#undef G16_BIG
     if (a.planes) {
         const int64_t work = (int64_t)nbatch * M * (N / 4);
         const int g = ix_grid_1d(work, 256);

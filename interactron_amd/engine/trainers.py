@@ -98,6 +98,8 @@ class _TrainerBase:
                 self.model.invalidate_graphs()    # captured graphs / folds made before the sync read the old values
             from .. import hipops
             hipops.weights_changed()              # (the flat buffer was rewritten under the parameters' views)
+            if getattr(outer, "shadow_b16", False):
+                outer.flat.sync_b16()             # (16-bit mode: the bf16 shadow of the flat buffer follows)
             self._check_replicas(outer)
 
     def _check_replicas(self, outer):

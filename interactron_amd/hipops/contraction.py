@@ -389,6 +389,10 @@ class SplitRows(Function):
         parts = tuple(w.split(list(sizes), 0))
         for t in parts:
             t._ix_of_param = id(w)   # (skip_param_grads: the blocks stand for the Parameter they were cut from)
+        fl = w.__dict__.get("_ix_b16_flat")   # 16-bit mode: the blocks of the parameter's bf16 shadow go with them (b16.weight_b16)
+        if fl is not None and fl[1] == core._wp_epoch[0] and fl[2] == w._version and fl[3] == w.data_ptr():
+            for t, sh in zip(parts, fl[0].split(list(sizes), 0)):
+                t.__dict__["_ix_b16_flat"] = (sh, fl[1], t._version, t.data_ptr())
         return parts
 
     @staticmethod

@@ -89,6 +89,26 @@ class FlatBuffers:
             from . import hipops
             hipops.weights_changed()
 
+    def sync_b16(self):
+        """16-bit activation mode: ONE conversion pass over the flat parameter buffer into a flat bf16 shadow, and every parameter's
+        view of it handed to the weight cache (b16.weight_b16) -- instead of one pass per weight tensor after every optimiser step
+        (286 launches, 1.6 ms per multi_frame_baseline step, profiles/r6g_mfb_bf16_kernel_stats.csv).  Valid until the parameters
+        change again (the cache epoch, the tensor's version and address are recorded)."""
+        from . import b16, hipops as ops
+        if getattr(self, "params_b16", None) is None:
+            self.params_b16 = torch.empty(self.params.numel(), device=self.params.device, dtype=torch.bfloat16)
+            self._b16_views = []
+            o = 0
+            for g in self.groups:
+                for p in g:
+                    n = p.numel()
+                    self._b16_views.append((p, self.params_b16[o:o + n].view(p.shape)))
+                    o += (n + ALIGN - 1) // ALIGN * ALIGN
+        b16.cast_b16_into(self.params, self.params_b16)
+        epoch = ops._wp_epoch[0]
+        for p, v in self._b16_views:
+            p.__dict__["_ix_b16_flat"] = (v, epoch, p._version, p.data_ptr())
+
     def all_reduce_grads(self):
         """The path's single data-path collective: SUM of the flat meta-gradient buffer over all ranks."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -115,6 +135,9 @@ class FlatOuterStep:
         self.v = torch.zeros_like(self.flat.params)
         self.sumsq = torch.zeros((), device=self.flat.params.device, dtype=torch.float32)
         self.max_norm, self.betas, self.eps, self.t = max_norm, betas, eps, 0
+        self.shadow_b16 = getattr(model, "compute_dtype", "f32") == "bf16" and self.flat.params.is_cuda
+        if self.shadow_b16:
+            self.flat.sync_b16()
 
     def step(self, all_reduce=True):
         """``all_reduce=False``: the caller has already summed the gradients over the ranks (tests that inspect them)."""
@@ -128,4 +151,6 @@ class FlatOuterStep:
         for (a, b), lr in zip(f.segments, self.lrs):
             ops.adam_step(f.params[a:b], f.grads[a:b], self.m[a:b], self.v[a:b], lr, self.betas[0], self.betas[1],
                           self.eps, self.t, self.sumsq, self.max_norm, zero_grad=True)
+        if self.shadow_b16:
+            f.sync_b16()
         return torch.sqrt(self.sumsq)

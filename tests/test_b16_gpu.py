@@ -19,13 +19,16 @@ def lib():
     return _lib.load()
 
 
-@pytest.fixture(params=[1, 2])
+@pytest.fixture(params=[1, 2, "big"])
 def stages(request, lib):
-    """every bf16 GEMM test runs on both forms of the kernel: one LDS stage / four workgroups per CU, and two stages with the next K
-    step's DMA in flight (ix_gemm_b16_set_stages)"""
-    old = lib.ix_gemm_b16_set_stages(request.param)
+    """every bf16 GEMM test runs on the three forms of the kernel: 128 x 128 tiles with one LDS stage / four workgroups per CU, with two
+    stages and the next K step's DMA in flight (ix_gemm_b16_set_stages), and the 256 x 256-tile form forced onto every plain contraction
+    (ix_gemm_b16_set_big(2); the convolution gathers have no such form and run the default one)"""
+    old = lib.ix_gemm_b16_set_stages(1 if request.param == "big" else request.param)
+    old_big = lib.ix_gemm_b16_set_big(2 if request.param == "big" else 0)
     yield request.param
     lib.ix_gemm_b16_set_stages(old)
+    lib.ix_gemm_b16_set_big(old_big)
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -96,6 +99,33 @@ def test_bf16_gemm_batches_bias_affine_residual_and_activations(lib, stages):
                 ref = fn(ref)
                 tol = 1e-5 * float(ref.abs().max()) if c_f32 else 2.0 ** -8 * ref.abs() + 1e-5 * float(ref.abs().max())
                 assert bool(((C.double().cpu() - ref).abs() <= tol).all()), (act, use_res, c_f32, float((C.double().cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False)])
+def test_bf16_gemm_256_tile_form_is_what_large_launches_run_and_equals_the_128_tile_form(lib, a_kc, b_kc):
+    """A launch of >= ~200 tiles of 256 x 256 takes the eight-wave form by itself (ix_gemm_b16_set_big(1), the default): same k order,
+    same fp32 accumulation -- bit for bit the 128 x 128 kernel's result (no split-K in either plan at this shape), bf16 with bias + GELU
+    through the LDS store pass and fp32; ragged M (not a multiple of 256) and N = 1000 (a partial last tile, N = 8 (mod 16))."""
+    M, N, K = 16384 + 72, 1000, 520
+    A = rnd(M if a_kc else K, K if a_kc else M, seed=31).cuda()
+    B = rnd(N if b_kc else K, K if b_kc else N, seed=32, scale=0.1).cuda()
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(33)).cuda()
+    res = rnd(M, N, seed=34).cuda()
+    outs = {}
+    for big in (0, 1):
+        old = lib.ix_gemm_b16_set_big(big)
+        try:
+            outs[big] = [gemm_b16(lib, A, B, M, N, K, a_kc, b_kc, K if a_kc else M, K if b_kc else N, bias=bias, c_f32=f, act=2, res=r)[0]
+                         for f, r in ((False, None), (False, res), (True, None))]
+        finally:
+            lib.ix_gemm_b16_set_big(old)
+    for a, b in zip(outs[0], outs[1]):
+        assert bool(torch.isfinite(b).all())
+        assert torch.equal(a, b)
+    a = A.double().cpu() if a_kc else A.double().cpu().t()
+    b = B.double().cpu().t() if b_kc else B.double().cpu()
+    ref = torch.nn.functional.gelu(a[:512] @ b + bias.double().cpu())
+    assert float((outs[1][2][0, 0, :512].double().cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
 def test_bf16_gemm_split_k_is_ordered_and_equals_one_pass(lib, stages):

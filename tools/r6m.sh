@@ -13,3 +13,5 @@ for i, r in enumerate(runs['full']['shapes']):
 for k, v in runs.items():
     print(k, {a: round(b['ms_per_step'], 2) for a, b in v['summary'].items()})
 PY
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_b800_gpu.py -m gpu -q -k "fp8" > gpurun_out/r6m_fp8_tests.txt 2>&1
+tail -4 gpurun_out/r6m_fp8_tests.txt
