@@ -586,7 +586,7 @@ def main():
                          "batch on 8 GPUs; replayed from HIP graphs); 0 = skip it")
     ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
                     help="MODEL.STEP_GRAPH: replay the chunk's launch sequence from captured HIP graphs (auto: whenever the capture fits in free device memory)")
-    ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16", "single_pass"],
+    ap.add_argument("--compute-dtype", default="f32", choices=["f32", "bf16", "bf16_fusion", "single_pass"],
                     help="MODEL.COMPUTE_DTYPE: f32 = fp32-grade contractions (the parity path, every headline); bf16 = the 16-bit ACTIVATION "
                          "mode (activations stored as bf16, bf16 GEMM with LDS-DMA operands; BASELINE.json configs[1]: --config "
                          "multi_frame_baseline --compute-dtype bf16); single_pass = fp32 storage, single-pass 16-bit contractions (round 4) "
@@ -686,7 +686,24 @@ def main():
             except torch.cuda.OutOfMemoryError as e:
                 inter[name] = {"error": "out of memory: %s" % str(e)[:200]}
                 torch.cuda.empty_cache()
+        # ... and with only the FUSION transformer in the mode (MODEL.COMPUTE_DTYPE bf16_fusion: the detector stays fp32-grade): the
+        # interactron step keeps whole-gradient cosine 0.979 / losses 0.35 % against the oracle there (0.935 / 5 % with everything in bf16)
+        sub.compute_dtype = "bf16_fusion"
+        inter_f = {}
+        for name, (size, eps, steps, warm) in (("p300_e16", (300, 16, 10, 3)), ("n800_e8", (800, 8, 5, 2))):
+            if name == "n800_e8" and args.n800_episodes <= 0:
+                continue
+            try:
+                r = run_workload(sub, size, eps, eps, steps, warm, ctx, False, "bench-b16f-" + name)
+                inter_f[name] = {"workload": "%d episodes/GPU x 5 frames x 3x%dx%d, same meta-train step" % (eps, size, size), "value": r["frames_per_s"],
+                                 "unit": "frames/s", "ms_per_step": r["ms_per_step"], "steps": steps, "warmup": warm,
+                                 "peak_memory_GB": r["peak_memory_GB"], "step_graphs": r["step_graphs"]}
+            except torch.cuda.OutOfMemoryError as e:
+                inter_f[name] = {"error": "out of memory: %s" % str(e)[:200]}
+                torch.cuda.empty_cache()
         b16_line = {"interactron": inter,
+                    "interactron_bf16_fusion": dict(inter_f, dtype="fp32-grade detector + bf16 fusion transformer (MODEL.COMPUTE_DTYPE bf16_fusion); gradient "
+                                                    "fidelity: tests/test_parity_gpu.py::test_interactron_step_with_the_fusion_transformer_in_the_16_bit_mode"),
                     "workload": "configs/multi_frame_baseline.yaml training step (detr_multiframe.forward + clip + Adam), 16 episodes/GPU x 5 frames x "
                                 "3x300x300, Q=50, fusion T=2060, procedural weights, train mode",
                     "dtype": "bf16 (activations stored as bf16, bf16 matrix instructions with LDS-DMA operands, fp32 accumulation / statistics / "
@@ -738,6 +755,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16 (activations stored as bf16, bf16 matrix instructions, fp32 accumulation / statistics / parameters)",
+                      "bf16_fusion": "f32 detector (fp32-grade) + bf16 fusion transformer (activations stored as bf16, bf16 matrix instructions, single-term "
+                                     "attention; fp32 accumulation / statistics / parameters)",
                       "single_pass": "bf16-class (single-pass 16-bit contractions: fp16 x 2^E per 32x32 block, fp32 accumulation; fp32 storage, "
                                      "fp32-grade attention / norms)"}[args.compute_dtype],
             "data": "synthetic",

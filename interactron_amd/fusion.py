@@ -111,8 +111,13 @@ def _like(t, ref):
 
 
 def _token_inputs(mod, x):
-    img = mod.img_feature_embedding(x["embedded_memory_features"].permute(0, 1, 3, 4, 2))
-    bf = x["box_features"]
+    emf, bf = x["embedded_memory_features"], x["box_features"]
+    if ops.b16_fusion_only() and emf.dtype == torch.float32:
+        # MODEL.COMPUTE_DTYPE bf16_fusion: the detector ran fp32-grade; from here to the decoders activations are bf16 (the conversions are
+        # differentiable: the gradient re-enters the detector as fp32)
+        from . import b16
+        emf, bf = b16.to_b16(emf), b16.to_b16(bf)
+    img = mod.img_feature_embedding(emf.permute(0, 1, 3, 4, 2))
     if bf.dtype == torch.bfloat16:
         # 16-bit mode: the prediction embedding reads the detector's fp32 logits (|logit| up to ~10: bf16 would round them by 0.02-0.04)
         # and is tiny (50 rows per frame) -- it runs fp32-grade, its output joins the bf16 token sequence

@@ -300,7 +300,7 @@ def contraction_form():
     lib = _L()
     cur = lib.ix_gemm_set_x3(1)
     lib.ix_gemm_set_x3(cur)
-    return cur + {"f32": 0, "single_pass": 2, "bf16": 4}[COMPUTE_DTYPE]
+    return cur + {"f32": 0, "single_pass": 2, "bf16": 4, "bf16_fusion": 6}[COMPUTE_DTYPE]
 
 
 # MODEL.COMPUTE_DTYPE -- a property of a MODEL (episode._EpisodeModel.compute_dtype), put in force for the duration of each of its
@@ -315,13 +315,14 @@ def contraction_form():
 #       of x * 2^-E with one exponent per 32 x 32 sub-block) and issue ONE matrix instruction per k-slice.
 COMPUTE_DTYPE = "f32"
 _DTYPE_NAMES = {"float32": "f32", "fp32": "f32", "f32": "f32", "bf16": "bf16", "bfloat16": "bf16", "fp16": "single_pass",
-                "half": "single_pass", "f16": "single_pass", "single_pass": "single_pass"}
+                "half": "single_pass", "f16": "single_pass", "single_pass": "single_pass", "bf16_fusion": "bf16_fusion"}
 
 
 def normalize_compute_dtype(name):
     out = _DTYPE_NAMES.get(str(name).lower())
     if out is None:
-        raise ValueError("MODEL.COMPUTE_DTYPE must be f32, bf16 (16-bit activations) or single_pass / fp16 (fp32 storage, 16-bit single-pass contractions)")
+        raise ValueError("MODEL.COMPUTE_DTYPE must be f32, bf16 (16-bit activations), bf16_fusion (16-bit activations in the fusion transformer only) "
+                         "or single_pass / fp16 (fp32 storage, 16-bit single-pass contractions)")
     return out
 
 
@@ -354,6 +355,11 @@ class compute_mode:
 
 def b16_active():
     return COMPUTE_DTYPE == "bf16"
+
+
+def b16_fusion_only():
+    """MODEL.COMPUTE_DTYPE bf16_fusion: the detector computes fp32-grade, the fusion transformer casts its inputs to bf16 (fusion._token_inputs)"""
+    return COMPUTE_DTYPE == "bf16_fusion"
 
 
 _bias_cache = {}

@@ -135,7 +135,7 @@ class FlatOuterStep:
         self.v = torch.zeros_like(self.flat.params)
         self.sumsq = torch.zeros((), device=self.flat.params.device, dtype=torch.float32)
         self.max_norm, self.betas, self.eps, self.t = max_norm, betas, eps, 0
-        self.shadow_b16 = getattr(model, "compute_dtype", "f32") == "bf16" and self.flat.params.is_cuda
+        self.shadow_b16 = getattr(model, "compute_dtype", "f32") in ("bf16", "bf16_fusion") and self.flat.params.is_cuda
         if self.shadow_b16:
             self.flat.sync_b16()
 
