@@ -96,6 +96,22 @@ def pmc_traffic(kernel, size):
     return None
 
 
+def pmc_traffic_b16():
+    """HBM bytes per launch of the bf16 GEMM (gemm16_kernel + its 256-tile form + split-K tails), launch-weighted over the GEMM launches, from
+    the committed PMC passes of `bench.py --config multi_frame_baseline --compute-dtype bf16` (profiles/*_pmc_hbm_traffic_mfb_bf16.json)"""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic_mfb_bf16.json")))):
+        try:
+            ks = json.load(open(f))["kernels"]
+        except (KeyError, ValueError, OSError):
+            continue
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if k.startswith("gemm16_"))
+        n = sum(v["launches"] for k, v in ks.items() if k.startswith("gemm16_") and "reduce" not in k)
+        if n:
+            return tot / n
+    return None
+
+
 def usable_cores():
     """Host cores this process may actually use: min(affinity, cgroup CPU quota).  The GPU boxes expose 256 logical
     CPUs behind a 16-CPU cgroup quota; running 256 threads against that quota throttles the oracle ~100x."""
@@ -418,7 +434,7 @@ def run_workload(args, size, episodes, chunk, steps, warmup, ctx, want_roofline,
                    "frac": bfl.value / (bms.value * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "launches_per_step": int(bn.value),
                    "kernel_ms_per_step": bms.value, "gflop_per_step": bfl.value / 1e9, "avg_launch_us": bms.value * 1e3 / bn.value,
                    "algorithmic_bytes_per_launch": bby.value / bn.value, "algorithmic_GBps": bby.value / (bms.value * 1e-3) / 1e9,
-                   "traffic": None}
+                   "traffic": pmc_traffic_b16() if args.config == "multi_frame_baseline" else None}
             r["bf16_gemm"] = b16
             if bms.value > r["kernel_ms_per_step"]:   # it IS the dominant kernel of this run: the top-level fields describe it
                 r["fp32_on_16bit_kernels"] = {k: r[k] for k in ("kernel", "achieved", "frac", "launches_per_step", "gflop_per_step",

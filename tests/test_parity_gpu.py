@@ -941,12 +941,13 @@ def test_interactron_step_with_the_fusion_transformer_in_the_16_bit_mode():
     """MODEL.COMPUTE_DTYPE bf16_fusion: the detector (backbone, encoder / decoder, heads: the weights the inner step adapts) computes
     fp32-grade, the GPT fusion transformer -- where the 800 x 800 step spends its time: T = 12 755 attention -- runs on bf16 activations.
     The same smoke step as above against the fp32 oracle, ADAPTIVE_LR = 1e-3, assignments pinned: losses within 1 % (measured 0.35 %),
-    whole-gradient cosine >= 0.97 (measured 0.979; everything in bf16: 0.935), every tensor >= 0.85 (measured 0.908, on the layer3
+    whole-gradient cosine >= 0.97 (measured 0.979; everything in bf16: 0.935), norms within 30 % (measured 23 %; the one-element bias of the loss
+    head 48 %), every tensor >= 0.85 (measured 0.908, on the layer3
     convolution that falls to 0.34-0.68 with everything in bf16)."""
     import __graft_entry__ as entry
     from interactron_amd import b16
     before = b16._stats["native_gemms"]
-    res = entry.smoke_check(128, cfg_extra={"COMPUTE_DTYPE": "bf16_fusion"}, f64_slack=False, norm_tol=2.5e-1, loss_tol=1e-2, cos_min=0.85,
+    res = entry.smoke_check(128, cfg_extra={"COMPUTE_DTYPE": "bf16_fusion"}, f64_slack=False, norm_tol=3e-1, loss_tol=1e-2, cos_min=0.85,
                             pin_matching="always", zero_grad_noise=1e-2, scalar_tol=7e-1)   # (the one-element bias of the loss head: 48 % measured)
     print("interactron step, bf16 fusion transformer: whole-gradient cosine %.5f, worst tensor %.4f on %s, loss deviations %s"
           % ((res["whole_gradient_cosine"],) + res["worst_cosine"] + ({k: round(v, 4) for k, v in res["loss_deviations"].items()},)))

@@ -8,7 +8,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(gemm_f32_\w+?kernel|gemm_wp_kernel|flash_\w+?_kernel)", r["Kernel_Name"])
+        m = re.search(r"(gemm_f32_\w+?kernel|gemm_wp_kernel|gemm16_\w*?kernel|flash\w*?_kernel\w*)", r["Kernel_Name"])
         if not m:
             continue
         tot[m.group(1)] += float(r["Counter_Value"]) * 1024.0   # both counters are in KiB
