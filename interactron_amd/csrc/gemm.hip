@@ -3106,6 +3106,15 @@ static double x6_step_cycles() {
     if (forced >= 100.0) return forced;
     return x3k_enabled() ? 950.0 : 1900.0;
 }
+// what the cost model charges for the separate reduction launch of a split contraction, in cycles (IX_SPLITK_LAUNCH_CYCLES: tuning runs)
+static double splitk_launch_cycles() {
+    static double v = -1.0;
+    if (v < 0) {
+        const char* e = getenv("IX_SPLITK_LAUNCH_CYCLES");
+        v = e ? atof(e) : 6000.0;
+    }
+    return v;
+}
 static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int tile_hint, int split_k_hint, double step128 = 0.0) {
     if (step128 <= 0.0) step128 = x6_step_cycles();
     int bm = 64, split = 1;
@@ -3132,7 +3141,7 @@ static TilePlan plan_tiles(int M, int N, int K, int nbatch, bool want_x6, int ti
             double cost = (double)per_cu * ksteps * step_cycles + (double)((per_cu + 1) / 2) * 7000.0;
             if (real_split > 1) {
                 const double cbytes = 4.0 * (double)M * (double)N * (double)nbatch;
-                cost += 6000.0 + cbytes / 2048.0 + cbytes * real_split / 1024.0;  // reduction launch + partial planes
+                cost += splitk_launch_cycles() + cbytes / 2048.0 + cbytes * real_split / 1024.0;  // reduction launch + partial planes
             }
             if (cost < best) {
                 best = cost;
