@@ -575,7 +575,20 @@ def test_chunk_graph_replay_equals_eager_launches(model_type):
     four steps on alternating batches, each followed by clip + Adam -- losses, predictions, every gradient and every
     updated parameter must be BIT-identical (eval mode: no dropout; step 1 is the eager warm-up of the graph model, step 2
     captures, steps 3-4 replay with other inputs)."""
-    (me, oe), (mg, og) = _graph_vs_eager_models(model_type)
+    _check_graph_replay(model_type)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "bf16_fusion"])
+def test_chunk_graph_replay_equals_eager_launches_in_the_16_bit_modes(dtype):
+    """The same four steps with MODEL.COMPUTE_DTYPE bf16 / bf16_fusion: under a replay the parameters reach the matrix cores through the
+    flat bf16 shadow that FlatOuterStep converts after every optimiser step (trainer.FlatBuffers.sync_b16) -- static addresses the
+    captured segments read -- and the adapted fast weights are converted inside the graph; everything must stay BIT-identical to the
+    launch-by-launch run, updated parameters included."""
+    _check_graph_replay("interactron", COMPUTE_DTYPE=dtype)
+
+
+def _check_graph_replay(model_type, **extra):
+    (me, oe), (mg, og) = _graph_vs_eager_models(model_type, **extra)
     hw = (128, 160) if model_type == "interactron" else (300, 300)   # (the decoder fusion's position table is 19 x 19)
     batches = [to_gpu(synthetic_episodes(2, height=hw[0], width=hw[1], tag="graph-%s" % t)) for t in ("a", "b")]
     for m in (me, mg):
