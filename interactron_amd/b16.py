@@ -610,12 +610,15 @@ class ConvFwdBnAct16(ops.ConvFwdBnAct):
 
 
 # ---- attention in the mode: bf16 q / k / v / dO into the flash kernels' planes, head dim 64 on the single-term passes -------------------
+SINGLE_TERM = 0 if os.environ.get("IX_B16_SINGLE_TERM", "1") == "0" else 1   # "0": the three-term passes on the same planes (A/B runs)
+
+
 class _single_term:
     """the head-dim-64 passes of csrc/flash16.hip in their single-term build for the duration of one launch sequence (operands that are
     16-bit values fit the h plane exactly: one matrix instruction per k-slice instead of three)"""
 
     def __enter__(self):
-        self.old = ops._L().ix_flash_set_single_term(1)
+        self.old = ops._L().ix_flash_set_single_term(SINGLE_TERM)
         return self
 
     def __exit__(self, *exc):
