@@ -968,9 +968,9 @@ def test_interactron_step_with_the_fusion_transformer_in_the_16_bit_mode():
     assert res["checked"] >= 300
     assert b16._stats["native_gemms"] > before + 100, "the 16-bit kernels did not run"
     # ... and without the adaptation (every kernel of the step still runs): the arithmetic of the mode by itself -- whole-gradient cosine
-    # 0.99992, worst tensor 0.9959 (measured r6ab; the same with every op on its fp32 kernel between bf16 stores, and with three-term attention:
+    # 0.99992, worst tensor 0.9959, norms within 5 % (measured 2.8 %; r6ab / r6ac; the same with every op on its fp32 kernel between bf16 stores, and with three-term attention:
     # what the 1e-3 step loses is the amplification of storage rounding by the clipped update, not a kernel)
-    res = entry.smoke_check(128, cfg_extra={"COMPUTE_DTYPE": "bf16_fusion", "ADAPTIVE_LR": 0.0}, f64_slack=False, norm_tol=1e-1, loss_tol=5e-3,
+    res = entry.smoke_check(128, cfg_extra={"COMPUTE_DTYPE": "bf16_fusion", "ADAPTIVE_LR": 0.0}, f64_slack=False, norm_tol=5e-2, loss_tol=5e-3,
                             cos_min=0.99, pin_matching="always", zero_grad_noise=1e-2, scalar_tol=5e-1)
     print("interactron step, bf16 fusion transformer, no adaptation: whole-gradient cosine %.5f, worst tensor %.4f on %s"
           % ((res["whole_gradient_cosine"],) + res["worst_cosine"]))
