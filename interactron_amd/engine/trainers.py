@@ -187,7 +187,7 @@ class _TrainerBase:
 
         def run_evaluation():
             run_epoch("test")   # (the reference's test epoch also back-propagates inside model(); those grads are dropped)
-            outer.flat.grads.zero_()
+            outer.zero_grads()
             if self.evaluator is None:
                 return None
             m50, m, tps, fps, fns = self.evaluator.evaluate(save_results=False)

@@ -31,6 +31,16 @@ def _size_array(tensors):
     return arr
 
 
+def copy_multi(srcs, dsts):
+    """dst_i = src_i for a list of fp32 tensor pairs in one multi-tensor launch set (ix_reduce_multi_f32 over ONE copy): the gradients
+    autograd left on the parameters into their slots of the flat gradient buffer (trainer.FlatOuterStep, models without step graphs)"""
+    if not srcs:
+        return
+    srcs = [_req(t) for t in srcs]
+    assert all(a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous() and b.dtype == torch.float32 for a, b in zip(srcs, dsts))
+    _chk(_L().ix_reduce_multi_f32(_ptr_array(srcs), _ptr_array(dsts), _size_array(dsts), len(srcs), 1, _stream()), "ix_reduce_multi_f32")
+
+
 class ExpandEpisodes(Function):
     """apply(E, p_1..p_n) -> ([E, *p_1.shape], ..): the per-episode copies of a parameter list in one multi-tensor launch
     set (199 single-tensor launches before).  Backward = ReduceEpisodes: the sum over the E copies, i.e. the reference's

@@ -78,6 +78,7 @@ class FlatBuffers:
         dev = params[0].device
         self.params = torch.zeros(total, device=dev, dtype=torch.float32)
         self.grads = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad_views = []   # (parameter, its slot of the flat gradient buffer)
         for p, o in zip(params, offs):
             n = p.numel()
             self.params[o:o + n].copy_(p.data.reshape(-1))
@@ -85,6 +86,7 @@ class FlatBuffers:
                 self.grads[o:o + n].copy_(p.grad.reshape(-1))
             p.data = self.params[o:o + n].view(p.shape)
             p.grad = self.grads[o:o + n].view(p.shape)
+            self.grad_views.append((p, p.grad))
         if dev.type == "cuda":
             from . import hipops
             hipops.weights_changed()
@@ -119,7 +121,7 @@ class FlatOuterStep:
     """clip_grad_norm_(all, max_norm) + Adam(detector) + Adam(fusion) on the flat buffers (HIP kernels)."""
 
     def __init__(self, model, detector_lr=1e-5, fusion_lr=1e-4, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8, groups=None,
-                 lrs=None):
+                 lrs=None, steal_grads=None):
         """Default: Adam(detector, detector_lr) + Adam(fusion, fusion_lr) like the interactron trainers; ``groups`` /
         ``lrs`` give explicit parameter lists and learning rates (direct-supervision trainer: one group)."""
         if groups is not None:
@@ -135,14 +137,48 @@ class FlatOuterStep:
         self.v = torch.zeros_like(self.flat.params)
         self.sumsq = torch.zeros((), device=self.flat.params.device, dtype=torch.float32)
         self.max_norm, self.betas, self.eps, self.t = max_norm, betas, eps, 0
+        # Models whose step is ONE plain backward pass and no captured graph (detr, detr_multiframe): the parameters go into the backward
+        # WITHOUT a .grad, so autograd's AccumulateGrad keeps the incoming gradient tensor instead of launching one at::add per parameter
+        # into the flat views (316 launches, 1.4 ms of the 41 ms multi_frame_baseline step in the 16-bit mode); step() copies them into
+        # the flat buffer with one multi-tensor launch set and drops them again.  The episode models (two backward passes, gradients
+        # accumulated in place by captured graphs: graphs.chunk_runner) keep the persistent views.
+        from .episode import _Adaptive
+        if steal_grads is None:
+            steal_grads = os.environ.get("IX_STEAL_GRADS", "1") == "1"
+        self.steal_grads = bool(steal_grads) and (not isinstance(model, _Adaptive)) and self.flat.params.is_cuda
+        if self.steal_grads:
+            self._release_grads()
         self.shadow_b16 = getattr(model, "compute_dtype", "f32") in ("bf16", "bf16_fusion") and self.flat.params.is_cuda
         if self.shadow_b16:
             self.flat.sync_b16()
+
+    def zero_grads(self):
+        """Drop whatever gradients are pending (the reference's test epoch back-propagates inside model() too; those are discarded)."""
+        self.flat.grads.zero_()
+        if self.steal_grads:
+            self._release_grads()
+
+    def _release_grads(self):
+        for p, _ in self.flat.grad_views:
+            p.grad = None
+
+    def _collect_grads(self):
+        from . import hipops as ops
+        src, dst = [], []
+        for p, view in self.flat.grad_views:
+            g = p.grad
+            if g is None or g.data_ptr() == view.data_ptr():
+                continue   # (no gradient this step: the slot is zero since the last optimiser step | already the flat view)
+            src.append(g if g.is_contiguous() else g.contiguous())
+            dst.append(view)
+        ops.copy_multi(src, dst)
 
     def step(self, all_reduce=True):
         """``all_reduce=False``: the caller has already summed the gradients over the ranks (tests that inspect them)."""
         from . import hipops as ops
         f = self.flat
+        if self.steal_grads:
+            self._collect_grads()
         if all_reduce:
             f.all_reduce_grads()
         self.t += 1
@@ -153,4 +189,6 @@ class FlatOuterStep:
                           self.eps, self.t, self.sumsq, self.max_norm, zero_grad=True)
         if self.shadow_b16:
             f.sync_b16()
+        if self.steal_grads:
+            self._release_grads()
         return torch.sqrt(self.sumsq)

@@ -557,6 +557,42 @@ def test_step_is_bit_reproducible():
     assert not bad, ("updated parameters differ between two runs", len(bad), bad[:5])
 
 
+@pytest.mark.parametrize("model_type,dtype", [("detr_multiframe", "f32"), ("detr_multiframe", "bf16"), ("detr", "f32")])
+def test_outer_step_without_persistent_grad_views_equals_the_accumulating_one(model_type, dtype):
+    """FlatOuterStep on the models whose step is one plain backward pass: the parameters enter the backward without a .grad (autograd keeps
+    the incoming gradient tensors: no at::add per parameter), step() copies them into the flat buffer in one multi-tensor launch set --
+    against the same three steps with persistent flat .grad views (steal_grads=False): losses and updated parameters BIT-identical
+    (0 + g == g), no gradient left on a parameter after the step, and what run_evaluation drops is really dropped (zero_grads)."""
+    from interactron_amd import Config, build_model
+    from interactron_amd.trainer import FlatOuterStep
+    hist = []
+    for steal in (False, True):
+        m = build_model(Config(**dict(MODEL_CFG, TYPE=model_type, COMPUTE_DTYPE=dtype)))
+        if hasattr(m, "fusion"):
+            load_procedural(m.fusion, "fusion.")
+        m = m.cuda().eval()
+        outer = FlatOuterStep(m, max_norm=1.0, groups=[list(m.parameters())], lrs=[1e-5], steal_grads=steal)
+        assert outer.steal_grads == steal
+        steps = []
+        for k in range(3):
+            data = to_gpu(synthetic_episodes(2, height=128, width=160, tag="steal-%d" % k))
+            random.seed(4 + k)
+            if k == 1:   # a discarded backward pass in between (the trainers' test epoch)
+                m(data)
+                outer.zero_grads()
+            _, losses = m(data)
+            if steal:
+                assert sum(p.grad is not None and p.grad.data_ptr() != v.data_ptr() for p, v in outer.flat.grad_views) > 50
+            outer.step()
+            if steal:
+                assert all(p.grad is None for p, _ in outer.flat.grad_views)
+            steps.append(({k2: float(v) for k2, v in losses.items()}, outer.flat.params.clone()))
+        hist.append(steps)
+    for (l0, p0), (l1, p1) in zip(*hist):
+        assert l0 == l1, (l0, l1)
+        assert torch.equal(p0, p1)
+
+
 def _graph_vs_eager_models(model_type, **extra):
     from interactron_amd import Config, build_model
     from interactron_amd.trainer import FlatOuterStep
