@@ -276,6 +276,16 @@ def weight_view(w, *shape):
     v = w.reshape(*shape)
     if v is not w:
         v._ix_of_param = _param_key(w)
+        # 16-bit mode: the view of the parameter's bf16 copy goes with the view -- the flat shadow of a trainable parameter
+        # (trainer.FlatBuffers.sync_b16) or the once-converted copy of a frozen one (b16.weight_b16); otherwise every call converts again
+        fl = w.__dict__.get("_ix_b16_flat")
+        if fl is not None and fl[1] == _wp_epoch[0] and fl[2] == w._version and fl[3] == w.data_ptr() and v.data_ptr() == w.data_ptr():
+            v.__dict__["_ix_b16_flat"] = (fl[0].reshape(*shape), fl[1], v._version, v.data_ptr())
+        elif _b16_seen[0] and isinstance(w, torch.nn.Parameter) and not w.requires_grad and v.data_ptr() == w.data_ptr():
+            from .. import b16
+            if COMPUTE_DTYPE in ("bf16", "bf16_fusion"):
+                c = b16.weight_b16(w)
+                v.__dict__["_ix_b16_flat"] = (c.reshape(*shape), _wp_epoch[0], v._version, v.data_ptr())
     return mark_weight(v)
 
 
